@@ -1,0 +1,164 @@
+/*
+ * lite_llama_amd -- C ABI of the MI355X (gfx950) decode hot path.
+ *
+ * Drop-in boundary for the kernel layer of harleyszhang/lite_llama: every entry
+ * point below replaces one Triton host wrapper of the reference (cited per
+ * function as  lite_llama/kernels/<file>:<lines>).  The reference is pure
+ * Python + Triton, so the binding a maintainer adds is a ctypes stub (shown in
+ * INTEGRATION.md); the shipped Python mirror lives in lite_llama_amd/kernels/.
+ *
+ * Conventions (all entry points):
+ *   - plain pointers are DEVICE pointers unless the name says host;
+ *   - strides are in ELEMENTS, sizes in elements unless suffixed _bytes;
+ *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream);
+ *   - asynchronous, re-entrant, no global mutable state, NO allocation and no
+ *     device synchronisation -> every call is hipGraph-capturable; scratch is
+ *     passed in by the caller (sizes from the *_workspace helpers);
+ *   - return 0 on success, a negative LL_ERR_* code on an argument error (the
+ *     Python mirror raises the same exception types the reference raises);
+ *     kernels themselves never report errors (same as the reference).
+ */
+#ifndef LITE_LLAMA_AMD_H
+#define LITE_LLAMA_AMD_H
+
+#include <stdint.h>
+
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+/* element types */
+#define LL_F16 0
+#define LL_BF16 1
+#define LL_F32 2
+/* index widths (reference passes int32 or int64 index tensors) */
+#define LL_I32 0
+#define LL_I64 1
+/* 8-bit weight formats (w8a16.py:155-216, fused_moe.py:36-38) */
+#define LL_W_F16 0
+#define LL_W_FP8E4M3 1
+#define LL_W_INT8 2
+
+#define LL_OK 0
+#define LL_ERR_DTYPE (-1)
+#define LL_ERR_SHAPE (-2)
+#define LL_ERR_ARG (-3)
+#define LL_ERR_LAUNCH (-4)
+
+/* Library / ABI version; bumped on any signature change. */
+int ll_abi_version(void);
+
+/* ---- a1: skip_rmsnorm  (kernels/skip_rmsnorm.py:192-234) -------------------
+ * s = x + r (fp32); r <- s rounded (IN PLACE, when residual != NULL);
+ * var = sum(s*s/n); y = (s*rsqrt(var+eps)).to(dtype) * w.  rows x n, contiguous. */
+int ll_skip_rmsnorm(void* y, const void* x, void* residual, const void* weight,
+                    int64_t rows, int64_t n, float eps, int dtype, void* stream);
+
+/* ---- a7: swiglu_forward  (kernels/swiglu.py:45-65) --------------------------
+ * c = silu(a.f32) * b, rows x n, contiguous. */
+int ll_swiglu(void* c, const void* a, const void* b, int64_t rows, int64_t n, int dtype,
+              void* stream);
+
+/* ---- a2: rope_emb_forward  (kernels/rope_emb.py:86-134) ---------------------
+ * In-place half-split rotation of q [tokens, n_qh, hd] and k [tokens, n_kh, hd]
+ * (head and dim contiguous, row strides given).  Token t reads
+ * cos[t / seq_len, t % seq_len, : hd/2].  cs_dtype is the table dtype. */
+int ll_rope(void* q, void* k, const void* cos_t, const void* sin_t, int64_t tokens, int n_qh,
+            int n_kh, int hd, int64_t q_row_stride, int64_t k_row_stride, int64_t seq_len,
+            int64_t cos_b_stride, int64_t cos_s_stride, int64_t sin_b_stride, int64_t sin_s_stride,
+            int qk_dtype, int cs_dtype, void* stream);
+
+/* ---- a3: update_kv_buffer  (kernels/update_kv_buffer.py:54-89) ---------------
+ * buf[idx[i], h, :] = vals[i, h, :]  (bit-exact copy; 2-byte elements). */
+int ll_update_kv_buffer(const void* vals, const void* select_index, void* buf, int64_t tokens,
+                        int heads, int hd, int64_t v_stride_t, int64_t v_stride_h,
+                        int64_t b_stride_t, int64_t b_stride_h, int idx_width, void* stream);
+
+/* ---- a4: update_kv_index  (kernels/update_kv_index.py:50-88) -----------------
+ * table[b_req_idx[i], b_seq_len[i]-1] = select_index[i]; table is int32. */
+int ll_update_kv_index(int32_t* table, const void* b_req_idx, const void* b_seq_len,
+                       const void* select_index, int64_t n, int64_t stride_b, int64_t stride_s,
+                       int req_width, int seq_width, int sel_width, void* stream);
+
+/* ---- a5: flash_decoding  (kernels/flashdecoding.py:316-380) ------------------
+ * out[b,h,:] = softmax(q[b,h] . K[rows]^T * scale) V[rows],
+ * rows = table[b_req_idx[b], :b_seq_len[b]], kv head = h / (hq/hkv).
+ * K/V are (possibly strided) views [tokens, hkv, d], d contiguous.  Scratch:
+ * mid_o fp32 [batch, hq, nparts, d], mid_lse fp32 [batch, hq, nparts], with
+ * nparts = ll_flash_decoding_num_partitions(max_len). */
+int ll_flash_decoding_num_partitions(int64_t max_len);
+int ll_flash_decoding(void* out, const void* q, const void* k_cache, const void* v_cache,
+                      const int32_t* table, const void* b_req_idx, const void* b_seq_len,
+                      float* mid_o, float* mid_lse, int batch, int hq, int hkv, int d,
+                      int64_t max_len, float qk_scale, int64_t q_stride_b, int64_t q_stride_h,
+                      int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t,
+                      int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
+                      int64_t table_stride_b, int dtype, int req_width, int seq_width,
+                      void* stream);
+
+/* ---- a6: flash_attention2_no_pad  (kernels/flashattention2_nopad.py:175-231) --
+ * Varlen causal prefill over freshly projected q/k/v (exp2 softmax; sm_scale
+ * already carries log2 e).  q/o [tokens, hq, d], k/v [tokens, hkv, d]. */
+int ll_flash_attention_nopad(void* out, const void* q, const void* k, const void* v,
+                             const void* b_start_loc, const void* b_seq_len, int batch, int hq,
+                             int hkv, int d, int64_t max_seq_len, float sm_scale,
+                             int64_t q_stride_t, int64_t q_stride_h, int64_t k_stride_t,
+                             int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
+                             int64_t o_stride_t, int64_t o_stride_h, int dtype, int start_width,
+                             int seq_width, void* stream);
+
+/* ---- a8: w4a16_matmul  (kernels/quantization/w4a16.py:152-207) ---------------
+ * out[m,n] = sum_k x[m,k] * ((nib(qweight[n,k/8],k%8) - zeros[n,k/g]) * scales[n,k/g]) (+bias)
+ * x fp16 [M,K] (row stride given), qweight int32 [N,K/8], scales/zeros fp32
+ * [N,K/g] (row stride given), bias fp16 [N] or NULL, out fp16 [M,N] contiguous.
+ * `workspace` (fp32) and `counters` (int32, must be zero on entry; left zero on
+ * exit) are stream-K scratch sized by ll_gemm_workspace(m, n, k). */
+int ll_gemm_workspace(int64_t m, int64_t n, int64_t k, int64_t* workspace_floats,
+                      int64_t* counter_ints);
+int ll_w4a16_matmul(void* out, const void* x, const int32_t* qweight, const float* scales,
+                    const float* zeros, const void* bias, int64_t m, int64_t n, int64_t k,
+                    int group_size, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
+                    float* workspace, int32_t* counters, void* stream);
+
+/* ---- a9: w8a16_matmul  (kernels/quantization/w8a16.py:155-216) ---------------
+ * qweight [N,K] uint8 (fp8-e4m3 bits) or int8; scales fp32 [ceil(N/gn), ceil(K/gk)]. */
+int ll_w8a16_matmul(void* out, const void* x, const void* qweight, const float* scales,
+                    const void* bias, int64_t m, int64_t n, int64_t k, int group_n, int64_t group_k,
+                    int wfmt, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
+                    int64_t s_stride_k, float* workspace, int32_t* counters, void* stream);
+
+/* ---- a10: smoothquant_matmul  (kernels/quantization/w8a8.py:151-217) ----------
+ * step 1: per-row scale = absmax/127 (1.0 if 0), q = trunc(x/scale) int8;
+ * step 2: int8 x int8 -> int32 (exact) -> * a_scale[m] * w_scale[n] (+bias) -> fp16. */
+int ll_quantize_activations_int8(int8_t* q, float* a_scale, const void* x, int64_t m, int64_t k,
+                                 int64_t x_stride_m, void* stream);
+int ll_w8a8_matmul(void* out, const int8_t* qa, const float* a_scale, const int8_t* qweight,
+                   const float* w_scale, const void* bias, int64_t m, int64_t n, int64_t k,
+                   int64_t qw_stride_n, int32_t* acc_out /* nullable: raw int32 accumulators [M,N] */,
+                   int32_t* workspace, int32_t* counters, void* stream);
+
+/* ---- a11: fused_moe pieces  (kernels/fused_moe.py:45-99, :236-292, :298-335) ---
+ * moe_align_block_size: sorted_ids int32[num_slots + E*(block-1)] (sentinel =
+ * num_slots), expert_ids int32[ceil(max_padded/block)], num_post int32[1]. */
+int ll_moe_align_block_size(const void* topk_ids, int ids_width, int64_t num_slots, int num_experts,
+                            int block_size, int32_t* sorted_ids, int32_t* expert_ids,
+                            int32_t* num_post, void* stream);
+/* c[slot, :] = (a[slot / top_k, :] @ w[expert(slot)].T) (* topk_w[slot]) */
+int ll_moe_gemm(void* c, const void* a, const void* w, const float* w_scale, const void* topk_w,
+                const int32_t* sorted_ids, const int32_t* expert_ids, const int32_t* num_post,
+                int64_t num_slots, int64_t em, int block_m, int64_t n, int64_t k, int top_k,
+                int mul_routed_weight, int wfmt, int group_n, int64_t group_k, int64_t a_stride_m,
+                int64_t w_stride_e, int64_t w_stride_n, int64_t s_stride_e, int64_t s_stride_n,
+                int64_t s_stride_k, int dtype, void* stream);
+int ll_silu_and_mul(void* out, const void* x, int64_t rows, int64_t n, int dtype, void* stream);
+int ll_moe_sum(void* out, const void* x, int64_t tokens, int top_k, int64_t n, int dtype,
+               void* stream);
+
+/* ---- a16: greedy argmax over logits [rows, n] (engine/sampler.py:227-228) ----- */
+int ll_argmax(int64_t* out, const void* logits, int64_t rows, int64_t n, int64_t stride_row,
+              int dtype, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif /* LITE_LLAMA_AMD_H */

@@ -1,0 +1,140 @@
+"""ctypes binding of the C-ABI shared library (include/lite_llama_amd.h).
+
+The product path has NO fallback: if the HIP library is missing or a symbol is absent
+this module raises, loudly.  Build it with ``python -m lite_llama_amd.build``.
+"""
+
+from __future__ import annotations
+
+import ctypes
+import os
+from ctypes import c_float, c_int, c_int64, c_void_p
+
+import torch
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "lib", "liblite_llama_amd.so")
+
+LL_F16, LL_BF16, LL_F32 = 0, 1, 2
+LL_I32, LL_I64 = 0, 1
+LL_W_F16, LL_W_FP8E4M3, LL_W_INT8 = 0, 1, 2
+ABI_VERSION = 1
+
+P, I, L, F = c_void_p, c_int, c_int64, c_float
+
+# name -> argtypes, exactly the declarations of include/lite_llama_amd.h
+SIGNATURES = {
+    "ll_abi_version": [],
+    "ll_skip_rmsnorm": [P, P, P, P, L, L, F, I, P],
+    "ll_swiglu": [P, P, P, L, L, I, P],
+    "ll_rope": [P, P, P, P, L, I, I, I, L, L, L, L, L, L, L, I, I, P],
+    "ll_update_kv_buffer": [P, P, P, L, I, I, L, L, L, L, I, P],
+    "ll_update_kv_index": [P, P, P, P, L, L, L, I, I, I, P],
+    "ll_flash_decoding_num_partitions": [L],
+    "ll_flash_decoding": [P, P, P, P, P, P, P, P, P, I, I, I, I, L, F, L, L, L, L, L, L, L, L, L, I, I, I, P],
+    "ll_flash_attention_nopad": [P, P, P, P, P, P, I, I, I, I, L, F, L, L, L, L, L, L, L, L, I, I, I, P],
+    "ll_gemm_workspace": [L, L, L, P, P],
+    "ll_w4a16_matmul": [P, P, P, P, P, P, L, L, L, I, L, L, L, P, P, P],
+    "ll_w8a16_matmul": [P, P, P, P, P, L, L, L, I, L, I, L, L, L, L, P, P, P],
+    "ll_quantize_activations_int8": [P, P, P, L, L, L, P],
+    "ll_w8a8_matmul": [P, P, P, P, P, P, L, L, L, L, P, P, P, P],
+    "ll_moe_align_block_size": [P, I, L, I, I, P, P, P, P],
+    "ll_moe_gemm": [P, P, P, P, P, P, P, P, L, L, I, L, L, I, I, I, I, L, L, L, L, L, L, L, I, P],
+    "ll_silu_and_mul": [P, P, L, L, I, P],
+    "ll_moe_sum": [P, P, L, I, L, I, P],
+    "ll_argmax": [P, P, L, L, L, I, P],
+}
+
+_lib = None
+
+
+class KernelError(RuntimeError):
+    """A C-ABI entry point returned a negative status."""
+
+
+def lib() -> ctypes.CDLL:
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise RuntimeError(
+                f"lite_llama_amd: HIP library not found at {LIB_PATH}; run "
+                "`python -m lite_llama_amd.build` (there is no CPU/eager fallback)"
+            )
+        handle = ctypes.CDLL(LIB_PATH)
+        for name, argtypes in SIGNATURES.items():
+            fn = getattr(handle, name)  # AttributeError if the symbol is missing -> loud
+            fn.argtypes = argtypes
+            fn.restype = c_int
+        if handle.ll_abi_version() != ABI_VERSION:
+            raise RuntimeError("lite_llama_amd: ABI version mismatch between _lib.py and the .so")
+        _lib = handle
+    return _lib
+
+
+def stream_ptr() -> int:
+    return torch.cuda.current_stream().cuda_stream
+
+
+def dtype_code(dt: torch.dtype) -> int:
+    if dt == torch.float16:
+        return LL_F16
+    if dt == torch.bfloat16:
+        return LL_BF16
+    if dt == torch.float32:
+        return LL_F32
+    raise TypeError(f"unsupported dtype {dt}")
+
+
+def index_width(t: torch.Tensor) -> int:
+    if t.dtype == torch.int32:
+        return LL_I32
+    if t.dtype == torch.int64:
+        return LL_I64
+    raise TypeError(f"index tensors must be int32 or int64, got {t.dtype}")
+
+
+def require_cuda(*tensors) -> None:
+    for t in tensors:
+        if t is not None and not t.is_cuda:
+            raise RuntimeError(
+                "lite_llama_amd kernels run on the GPU only (got a CPU tensor); there is no CPU fallback"
+            )
+
+
+def check(status: int, what: str) -> None:
+    if status != 0:
+        names = {-1: "LL_ERR_DTYPE", -2: "LL_ERR_SHAPE", -3: "LL_ERR_ARG", -4: "LL_ERR_LAUNCH"}
+        raise KernelError(f"{what} failed: {names.get(status, status)}")
+
+
+def ptr(t) -> int:
+    return 0 if t is None else t.data_ptr()
+
+
+# --------------------------------------------------------------------------- #
+# split-K scratch for the streaming GEMMs: one persistent buffer per device, grown on
+# demand OUTSIDE graph capture (kernels never allocate; counters stay zero between calls).
+# --------------------------------------------------------------------------- #
+_gemm_ws: dict = {}
+_gemm_ws_keepalive: list = []  # captured hipGraphs may still point at outgrown buffers
+
+
+def gemm_workspace(device: torch.device, m: int, n: int, k: int):
+    floats, ints = c_int64(0), c_int64(0)
+    lib().ll_gemm_workspace(m, n, k, ctypes.byref(floats), ctypes.byref(ints))
+    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
+    ws = _gemm_ws.get(key)
+    if ws is None or ws[0].numel() < floats.value or ws[1].numel() < ints.value:
+        if torch.cuda.is_current_stream_capturing():
+            raise RuntimeError(
+                "GEMM split-K workspace must be sized before graph capture (run one eager warm-up step)"
+            )
+        nf = max(floats.value, ws[0].numel() if ws else 0)
+        ni = max(ints.value, ws[1].numel() if ws else 0, 4096)
+        ws = (
+            torch.empty(nf, dtype=torch.float32, device=device),
+            torch.zeros(ni, dtype=torch.int32, device=device),
+        )
+        _gemm_ws[key] = ws
+        _gemm_ws_keepalive.append(ws)
+    return ws

@@ -1,0 +1,96 @@
+// Shared device helpers for the gfx950 kernels (wave64, 16-byte vector I/O).
+#pragma once
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+
+#include "../../include/lite_llama_amd.h"
+
+#define LL_WAVE 64
+
+typedef _Float16 f16;
+typedef _Float16 f16x2 __attribute__((ext_vector_type(2)));
+typedef _Float16 f16x4 __attribute__((ext_vector_type(4)));
+typedef _Float16 f16x8 __attribute__((ext_vector_type(8)));
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+typedef float f32x4 __attribute__((ext_vector_type(4)));
+typedef float f32x16 __attribute__((ext_vector_type(16)));
+typedef int i32x4 __attribute__((ext_vector_type(4)));
+typedef int i32x16 __attribute__((ext_vector_type(16)));
+
+__device__ __forceinline__ float bf16_bits_to_f32(uint16_t b) {
+  return __uint_as_float(((uint32_t)b) << 16);
+}
+// round-to-nearest-even, NaN preserved (quiet)
+__device__ __forceinline__ uint16_t f32_to_bf16_bits(float f) {
+  uint32_t u = __float_as_uint(f);
+  if ((u & 0x7fffffffu) > 0x7f800000u) return (uint16_t)((u >> 16) | 0x40);
+  u += 0x7fffu + ((u >> 16) & 1u);
+  return (uint16_t)(u >> 16);
+}
+__device__ __forceinline__ float f16_bits_to_f32(uint16_t h) {
+  return (float)__builtin_bit_cast(f16, h);
+}
+__device__ __forceinline__ uint16_t f32_to_f16_bits(float f) {
+  return __builtin_bit_cast(uint16_t, (f16)f);
+}
+
+// 16-bit storage type <-> fp32, selected by the LL_F16 / LL_BF16 code.
+template <int DT>
+__device__ __forceinline__ float to_f32(uint16_t b) {
+  if constexpr (DT == LL_F16) return f16_bits_to_f32(b);
+  else return bf16_bits_to_f32(b);
+}
+template <int DT>
+__device__ __forceinline__ uint16_t from_f32(float f) {
+  if constexpr (DT == LL_F16) return f32_to_f16_bits(f);
+  else return f32_to_bf16_bits(f);
+}
+
+// Product of two storage-dtype values rounded once to the storage dtype (what
+// a fp16*fp16 / bf16*bf16 multiply yields: the fp32 product is exact).
+template <int DT>
+__device__ __forceinline__ uint16_t mul_storage(uint16_t a, uint16_t b) {
+  return from_f32<DT>(to_f32<DT>(a) * to_f32<DT>(b));
+}
+
+struct alignas(16) U16x8 {
+  uint16_t v[8];
+};
+
+template <int VEC>
+struct VecIO;
+template <>
+struct VecIO<8> {
+  __device__ static __forceinline__ void load(const uint16_t* p, uint16_t (&o)[8]) {
+    U16x8 t = *reinterpret_cast<const U16x8*>(p);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) o[i] = t.v[i];
+  }
+  __device__ static __forceinline__ void store(uint16_t* p, const uint16_t (&o)[8]) {
+    U16x8 t;
+#pragma unroll
+    for (int i = 0; i < 8; ++i) t.v[i] = o[i];
+    *reinterpret_cast<U16x8*>(p) = t;
+  }
+};
+template <>
+struct VecIO<1> {
+  __device__ static __forceinline__ void load(const uint16_t* p, uint16_t (&o)[1]) { o[0] = p[0]; }
+  __device__ static __forceinline__ void store(uint16_t* p, const uint16_t (&o)[1]) { p[0] = o[0]; }
+};
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
+  return v;
+}
+
+static inline bool ll_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
+
+#define LL_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? LL_OK : LL_ERR_LAUNCH)

@@ -1,0 +1,274 @@
+// flash_decoding (a5) -- reference lite_llama/kernels/flashdecoding.py:23-380.
+//
+// MI355X design (NOT the reference's one-program-per-q-head layout):
+//   * stage 1: one wave per (batch row, KV head, 128-token partition) serves ALL
+//     hq/hkv query heads of that KV head, so every K/V byte is read from HBM once
+//     (the reference re-reads it hq/hkv times).
+//   * S^T = K.Q^T on MFMA 16x16x32 (tokens x heads): K fragments are loaded straight
+//     from the token-attention pool in fragment layout (64 contiguous bytes per lane
+//     per gathered row), q-heads sit in the 16 MFMA columns, so the online softmax
+//     is lane-local per head plus two cross-row shuffles.
+//   * O^T = V^T.P^T on MFMA: the S^T accumulator registers ARE the P^T B-operand
+//     (no data movement); V rows are staged once through LDS to be read k(token)-major.
+//   * stage 2: log-sum-exp merge of the per-partition partials (fp32 scratch).
+// Numerics follow the reference: fp32 scores/accumulators, plain exp, plain scale.
+#include "common.h"
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+#define FD_PART 128  // tokens per partition (reference PARTITION_SIZE, flashdecoding.py:343)
+
+struct alignas(16) Q4 {
+  uint32_t x, y, z, w;
+};
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(const Q4& a, const Q4& b, f32x4 c) {
+  if constexpr (DT == LL_F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int DT>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)from_f32<DT>(lo) | ((uint32_t)from_f32<DT>(hi) << 16);
+}
+
+__device__ __forceinline__ int64_t fd_load_idx(const void* p, int64_t i, int w) {
+  return w == LL_I32 ? (int64_t)((const int32_t*)p)[i] : ((const int64_t*)p)[i];
+}
+
+// grid = (nparts, hkv * head_groups, batch), block = 64 (one wave)
+template <int DT, int D>
+__global__ __launch_bounds__(64) void fd_stage1(
+    const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
+    const int32_t* __restrict__ table, const void* __restrict__ b_req_idx,
+    const void* __restrict__ b_seq_len, float* __restrict__ mid_o, float* __restrict__ mid_lse,
+    int hq, int hkv, int nparts, float scale, int64_t q_sb, int64_t q_sh, int64_t k_st, int64_t k_sh,
+    int64_t v_st, int64_t v_sh, int64_t t_sb, int req_w, int seq_w) {
+  constexpr int NS = D / 32;      // MFMA k-steps over the head dim
+  constexpr int DQ = D / 4;       // contiguous d-range owned by one lane row-group
+  constexpr int NT = D / 16;      // output d-tiles
+  constexpr int VSTR = D + 8;     // padded LDS row stride (elements)
+  __shared__ __attribute__((aligned(16))) uint16_t lds_v[32 * VSTR];
+
+  const int lane = threadIdx.x;
+  const int t = lane & 15, c = lane >> 4;
+  const int part = blockIdx.x;
+  const int kvh = blockIdx.y % hkv;
+  const int hg = blockIdx.y / hkv;
+  const int b = blockIdx.z;
+  const int groups = hq / hkv;
+  const int hl = hg * 16 + t;            // head within the KV group (MFMA column)
+  const bool head_ok = hl < groups;
+  const int head = kvh * groups + hl;
+
+  const int64_t seq_len = fd_load_idx(b_seq_len, b, seq_w);
+  const int64_t start = (int64_t)part * FD_PART;
+  if (start >= seq_len) return;  // empty partition stores nothing (flashdecoding.py:141-161)
+  const int64_t end = seq_len < start + FD_PART ? seq_len : start + FD_PART;
+  const int64_t req = fd_load_idx(b_req_idx, b, req_w);
+  const int32_t* trow = table + req * t_sb;
+
+  // Q^T fragments (MFMA B operand): lane (head t, group c) holds q[head][c*DQ + s*8 .. +8]
+  Q4 qf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s) {
+    if (head_ok)
+      qf[s] = *reinterpret_cast<const Q4*>(q + b * q_sb + (int64_t)head * q_sh + c * DQ + s * 8);
+    else
+      qf[s] = Q4{0, 0, 0, 0};
+  }
+
+  float m_i = -INFINITY, d_i = 0.f;
+  f32x4 ot[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  for (int64_t pos0 = start; pos0 < end; pos0 += 32) {
+    // ---- gather: lane (t, c) fetches rows pos0+t and pos0+16+t, d-range [c*DQ, +DQ) ----
+    const int64_t tokA = pos0 + t, tokB = pos0 + 16 + t;
+    const bool okA = tokA < end, okB = tokB < end;
+    const int64_t rowA = okA ? (int64_t)trow[tokA] : 0;
+    const int64_t rowB = okB ? (int64_t)trow[tokB] : 0;
+    const uint16_t* kA = kc + rowA * k_st + (int64_t)kvh * k_sh + c * DQ;
+    const uint16_t* kB = kc + rowB * k_st + (int64_t)kvh * k_sh + c * DQ;
+    const uint16_t* vA = vc + rowA * v_st + (int64_t)kvh * v_sh + c * DQ;
+    const uint16_t* vB = vc + rowB * v_st + (int64_t)kvh * v_sh + c * DQ;
+    Q4 ka[NS], kb[NS], va[NS], vb[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) ka[s] = *reinterpret_cast<const Q4*>(kA + s * 8);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) kb[s] = *reinterpret_cast<const Q4*>(kB + s * 8);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) va[s] = *reinterpret_cast<const Q4*>(vA + s * 8);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) vb[s] = *reinterpret_cast<const Q4*>(vB + s * 8);
+
+    // ---- S^T tiles: rows = tokens (4c+r), cols = heads (t) ----
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sa = mfma16<DT>(ka[s], qf[s], sa);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sb = mfma16<DT>(kb[s], qf[s], sb);
+
+    float sc[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const bool va_ok = pos0 + 4 * c + r < end;
+      const bool vb_ok = pos0 + 16 + 4 * c + r < end;
+      sc[r] = va_ok ? sa[r] * scale : -INFINITY;
+      sc[4 + r] = vb_ok ? sb[r] * scale : -INFINITY;
+      mx = fmaxf(mx, fmaxf(sc[r], sc[4 + r]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_i, mx);  // finite: token pos0 is always valid
+    const float alpha = expf(m_i - m_new);
+    float p[8];
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      p[j] = expf(sc[j] - m_new);
+      ps += p[j];
+    }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    d_i = d_i * alpha + ps;
+    m_i = m_new;
+
+    // P^T fragment (MFMA B operand): k-slot j <-> token 16*(j>>2) + 4c + (j&3)
+    Q4 pf;
+    pf.x = pack2<DT>(p[0], p[1]);
+    pf.y = pack2<DT>(p[2], p[3]);
+    pf.z = pack2<DT>(p[4], p[5]);
+    pf.w = pack2<DT>(p[6], p[7]);
+
+    // ---- stage V rows through LDS (zero rows past the end: garbage could be NaN) ----
+    __syncthreads();  // previous tile's reads done
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      *reinterpret_cast<Q4*>(&lds_v[t * VSTR + c * DQ + s * 8]) = okA ? va[s] : Q4{0, 0, 0, 0};
+      *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + c * DQ + s * 8]) = okB ? vb[s] : Q4{0, 0, 0, 0};
+    }
+    __syncthreads();
+
+    // ---- O^T[d][head] += V^T[d][tok] . P^T[tok][head] ----
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) {
+      uint32_t w[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j0 = 2 * jj, j1 = 2 * jj + 1;
+        const int r0 = 16 * (j0 >> 2) + 4 * c + (j0 & 3);
+        const int r1 = 16 * (j1 >> 2) + 4 * c + (j1 & 3);
+        const uint32_t lo = lds_v[r0 * VSTR + dt * 16 + t];
+        const uint32_t hi = lds_v[r1 * VSTR + dt * 16 + t];
+        w[jj] = lo | (hi << 16);
+      }
+      const Q4 vf = {w[0], w[1], w[2], w[3]};
+      f32x4 acc = ot[dt];
+      acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+      ot[dt] = mfma16<DT>(vf, pf, acc);
+    }
+  }
+
+  if (head_ok) {
+    const float inv = 1.0f / d_i;
+    float* mo = mid_o + (((int64_t)b * hq + head) * nparts + part) * D;
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) {
+      f32x4 o = ot[dt];
+      o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
+      *reinterpret_cast<f32x4*>(mo + dt * 16 + 4 * c) = o;
+    }
+    if (c == 0) mid_lse[((int64_t)b * hq + head) * nparts + part] = m_i + logf(d_i);
+  }
+}
+
+// grid = (hq, batch), block = D threads
+template <int DT>
+__global__ void fd_stage2(uint16_t* __restrict__ out, const float* __restrict__ mid_o,
+                          const float* __restrict__ mid_lse, const void* __restrict__ b_seq_len,
+                          int hq, int d, int nparts, int64_t o_sb, int64_t o_sh, int seq_w) {
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int64_t seq_len = fd_load_idx(b_seq_len, b, seq_w);
+  int np = (int)((seq_len + FD_PART - 1) / FD_PART);
+  if (np > nparts) np = nparts;
+  const float* mo = mid_o + ((int64_t)b * hq + h) * nparts * d;
+  const float* ml = mid_lse + ((int64_t)b * hq + h) * nparts;
+  float m_i = -INFINITY, d_i = 0.f, acc = 0.f;
+  for (int pp = 0; pp < np; ++pp) {
+    const float lse = ml[pp];
+    const float m_new = fmaxf(m_i, lse);
+    const float alpha = expf(m_i - m_new);
+    const float w = expf(lse - m_new);
+    acc = acc * alpha + w * mo[(int64_t)pp * d + threadIdx.x];
+    d_i = d_i * alpha + w;
+    m_i = m_new;
+  }
+  out[b * o_sb + (int64_t)h * o_sh + threadIdx.x] = from_f32<DT>(acc / d_i);  // 0/0 -> NaN like the reference
+}
+
+extern "C" int ll_flash_decoding_num_partitions(int64_t max_len) {
+  return (int)((max_len + FD_PART - 1) / FD_PART);
+}
+
+template <int DT>
+static int launch_fd(void* out, const void* q, const void* kc, const void* vc, const int32_t* table,
+                     const void* req, const void* seq, float* mid_o, float* mid_lse, int batch, int hq,
+                     int hkv, int d, int64_t max_len, float scale, int64_t q_sb, int64_t q_sh,
+                     int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_sh,
+                     int64_t t_sb, int req_w, int seq_w, hipStream_t st) {
+  const int nparts = ll_flash_decoding_num_partitions(max_len);
+  const int groups = hq / hkv;
+  const int hgroups = (groups + 15) / 16;
+  dim3 grid((unsigned)nparts, (unsigned)(hkv * hgroups), (unsigned)batch);
+#define LL_FD1(DD)                                                                                   \
+  fd_stage1<DT, DD><<<grid, 64, 0, st>>>((const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, \
+                                         table, req, seq, mid_o, mid_lse, hq, hkv, nparts, scale, q_sb, \
+                                         q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w)
+  switch (d) {
+    case 32: LL_FD1(32); break;
+    case 64: LL_FD1(64); break;
+    case 128: LL_FD1(128); break;
+    case 256: LL_FD1(256); break;
+    default: return LL_ERR_SHAPE;
+  }
+#undef LL_FD1
+  fd_stage2<DT><<<dim3((unsigned)hq, (unsigned)batch), d, 0, st>>>((uint16_t*)out, mid_o, mid_lse, seq, hq, d,
+                                                                   nparts, o_sb, o_sh, seq_w);
+  return LL_LAUNCH_CHECK();
+}
+
+extern "C" int ll_flash_decoding(void* out, const void* q, const void* k_cache, const void* v_cache,
+                                 const int32_t* table, const void* b_req_idx, const void* b_seq_len,
+                                 float* mid_o, float* mid_lse, int batch, int hq, int hkv, int d,
+                                 int64_t max_len, float qk_scale, int64_t q_stride_b, int64_t q_stride_h,
+                                 int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t,
+                                 int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
+                                 int64_t table_stride_b, int dtype, int req_width, int seq_width,
+                                 void* stream) {
+  if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if ((req_width | seq_width) & ~1) return LL_ERR_DTYPE;
+  if (batch < 0 || hq <= 0 || hkv <= 0 || hq % hkv != 0 || max_len < 0) return LL_ERR_SHAPE;
+  if (batch == 0) return LL_OK;
+  // 16-byte fragment loads: every row/head stride and base must be 8-element aligned
+  if ((q_stride_b | q_stride_h | k_stride_t | k_stride_h | v_stride_t | v_stride_h) % 8 != 0 ||
+      !ll_aligned16(q) || !ll_aligned16(k_cache) || !ll_aligned16(v_cache))
+    return LL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LL_F16)
+    return launch_fd<LL_F16>(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch,
+                             hq, hkv, d, max_len, qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h,
+                             v_stride_t, v_stride_h, o_stride_b, o_stride_h, table_stride_b, req_width,
+                             seq_width, st);
+  return launch_fd<LL_BF16>(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch, hq,
+                            hkv, d, max_len, qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h,
+                            v_stride_t, v_stride_h, o_stride_b, o_stride_h, table_stride_b, req_width,
+                            seq_width, st);
+}

@@ -1,0 +1,76 @@
+// KV-cache bookkeeping kernels (token-attention layout, block_size = 1).
+//   update_kv_buffer -- reference lite_llama/kernels/update_kv_buffer.py:15-89
+//   update_kv_index  -- reference lite_llama/kernels/update_kv_index.py:15-88
+// Pure integer / byte moves: bit-exact by construction.
+#include "common.h"
+
+template <int W>
+__device__ __forceinline__ int64_t load_idx(const void* p, int64_t i) {
+  if constexpr (W == LL_I32) return (int64_t)((const int32_t*)p)[i];
+  else return ((const int64_t*)p)[i];
+}
+__device__ __forceinline__ int64_t load_idx_rt(const void* p, int64_t i, int w) {
+  return w == LL_I32 ? (int64_t)((const int32_t*)p)[i] : ((const int64_t*)p)[i];
+}
+
+// One block per token; rows of [heads, hd] 16-bit elements copied as 16-byte vectors.
+template <int VEC>
+__global__ __launch_bounds__(256) void update_kv_buffer_kernel(
+    const uint16_t* __restrict__ vals, const void* __restrict__ sel, uint16_t* __restrict__ buf,
+    int heads, int hd, int64_t vst, int64_t vsh, int64_t bst, int64_t bsh, int idx_w) {
+  const int64_t tok = blockIdx.x;
+  const int64_t dst = load_idx_rt(sel, tok, idx_w);
+  const int vph = hd / VEC;
+  const int total = heads * vph;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int h = i / vph, j = (i % vph) * VEC;
+    uint16_t v[VEC];
+    VecIO<VEC>::load(vals + tok * vst + (int64_t)h * vsh + j, v);
+    VecIO<VEC>::store(buf + dst * bst + (int64_t)h * bsh + j, v);
+  }
+}
+
+extern "C" int ll_update_kv_buffer(const void* vals, const void* select_index, void* buf,
+                                   int64_t tokens, int heads, int hd, int64_t v_stride_t,
+                                   int64_t v_stride_h, int64_t b_stride_t, int64_t b_stride_h,
+                                   int idx_width, void* stream) {
+  if (idx_width != LL_I32 && idx_width != LL_I64) return LL_ERR_DTYPE;
+  if (tokens < 0 || heads <= 0 || hd <= 0) return LL_ERR_SHAPE;
+  if (tokens == 0) return LL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (hd % 8 == 0) && ll_aligned16(vals) && ll_aligned16(buf) && (v_stride_t % 8 == 0) &&
+                   (v_stride_h % 8 == 0) && (b_stride_t % 8 == 0) && (b_stride_h % 8 == 0);
+  if (vec)
+    update_kv_buffer_kernel<8><<<dim3((unsigned)tokens), 256, 0, st>>>(
+        (const uint16_t*)vals, select_index, (uint16_t*)buf, heads, hd, v_stride_t, v_stride_h,
+        b_stride_t, b_stride_h, idx_width);
+  else
+    update_kv_buffer_kernel<1><<<dim3((unsigned)tokens), 256, 0, st>>>(
+        (const uint16_t*)vals, select_index, (uint16_t*)buf, heads, hd, v_stride_t, v_stride_h,
+        b_stride_t, b_stride_h, idx_width);
+  return LL_LAUNCH_CHECK();
+}
+
+__global__ void update_kv_index_kernel(int32_t* __restrict__ table, const void* __restrict__ req,
+                                       const void* __restrict__ seq, const void* __restrict__ sel,
+                                       int64_t n, int64_t sb, int64_t ss, int rw, int sw, int lw) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n) return;
+  const int64_t r = load_idx_rt(req, i, rw);
+  const int64_t l = load_idx_rt(seq, i, sw);
+  table[r * sb + (l - 1) * ss] = (int32_t)load_idx_rt(sel, i, lw);
+}
+
+extern "C" int ll_update_kv_index(int32_t* table, const void* b_req_idx, const void* b_seq_len,
+                                  const void* select_index, int64_t n, int64_t stride_b,
+                                  int64_t stride_s, int req_width, int seq_width, int sel_width,
+                                  void* stream) {
+  if ((req_width | seq_width | sel_width) & ~1) return LL_ERR_DTYPE;
+  if (n < 0) return LL_ERR_SHAPE;
+  if (n == 0) return LL_OK;
+  update_kv_index_kernel<<<dim3((unsigned)((n + 63) / 64)), 64, 0, (hipStream_t)stream>>>(
+      table, b_req_idx, b_seq_len, select_index, n, stride_b, stride_s, req_width, seq_width, sel_width);
+  return LL_LAUNCH_CHECK();
+}
+
+extern "C" int ll_abi_version(void) { return 1; }

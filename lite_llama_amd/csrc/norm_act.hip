@@ -1,0 +1,416 @@
+// Bandwidth-bound row kernels of the decode step: skip_rmsnorm (a1), swiglu (a7),
+// rope (a2), silu_and_mul / moe_sum (a11 pieces), greedy argmax (a16).
+// All HBM-bound: 16-byte vector loads, wave64 shuffles, one pass over the data.
+#include "common.h"
+
+// --------------------------------------------------------------------------- //
+// skip_rmsnorm  -- reference lite_llama/kernels/skip_rmsnorm.py:126-234
+// --------------------------------------------------------------------------- //
+template <int TPR>
+__device__ __forceinline__ float row_sum(float v, float* lds) {
+  if constexpr (TPR <= 64) {
+#pragma unroll
+    for (int off = TPR / 2; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
+    return v;
+  } else {
+    v = wave_sum(v);
+    const int wid = threadIdx.x >> 6;
+    if ((threadIdx.x & 63) == 0) lds[wid] = v;
+    __syncthreads();
+    float t = lds[0] + lds[1] + lds[2] + lds[3];
+    return t;
+  }
+}
+
+// Cached variant: the whole row lives in registers (VPT vectors of 8 per thread).
+template <int DT, int TPR, int VPT, bool HAS_RES>
+__global__ __launch_bounds__(256) void skip_rmsnorm_cached(uint16_t* __restrict__ y,
+                                                           const uint16_t* __restrict__ x,
+                                                           uint16_t* __restrict__ r,
+                                                           const uint16_t* __restrict__ w,
+                                                           int64_t rows, int n, float eps) {
+  __shared__ float lds[4];
+  constexpr int RPB = 256 / TPR;
+  const int tr = threadIdx.x % TPR;
+  const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
+  const bool active = row < rows;
+  const float nf = (float)n;
+  float s[VPT][8];
+  float ssq = 0.f;
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    const int col = (v * TPR + tr) * 8;
+    if (active && col < n) {
+      uint16_t xv[8];
+      VecIO<8>::load(x + row * n + col, xv);
+      if constexpr (HAS_RES) {
+        uint16_t rv[8];
+        VecIO<8>::load(r + row * n + col, rv);
+#pragma unroll
+        for (int i = 0; i < 8; ++i) {
+          s[v][i] = to_f32<DT>(xv[i]) + to_f32<DT>(rv[i]);
+          rv[i] = from_f32<DT>(s[v][i]);
+        }
+        VecIO<8>::store(r + row * n + col, rv);
+      } else {
+#pragma unroll
+        for (int i = 0; i < 8; ++i) s[v][i] = to_f32<DT>(xv[i]);
+      }
+#pragma unroll
+      for (int i = 0; i < 8; ++i) ssq += s[v][i] * s[v][i] / nf;
+    } else {
+#pragma unroll
+      for (int i = 0; i < 8; ++i) s[v][i] = 0.f;
+    }
+  }
+  const float var = row_sum<TPR>(ssq, lds);
+  const float rrms = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    const int col = (v * TPR + tr) * 8;
+    if (active && col < n) {
+      uint16_t wv[8], yv[8];
+      VecIO<8>::load(w + col, wv);
+#pragma unroll
+      for (int i = 0; i < 8; ++i) yv[i] = mul_storage<DT>(from_f32<DT>(s[v][i] * rrms), wv[i]);
+      VecIO<8>::store(y + row * n + col, yv);
+    }
+  }
+}
+
+// Generic two-pass variant (any n, any alignment when VEC == 1): one row per block.
+template <int DT, int VEC, bool HAS_RES>
+__global__ __launch_bounds__(256) void skip_rmsnorm_twopass(uint16_t* __restrict__ y,
+                                                            const uint16_t* __restrict__ x,
+                                                            uint16_t* __restrict__ r,
+                                                            const uint16_t* __restrict__ w,
+                                                            int64_t rows, int n, float eps) {
+  __shared__ float lds[4];
+  const int64_t row = blockIdx.x;
+  const float nf = (float)n;
+  const int nvec = n / VEC;
+  float ssq = 0.f;
+  for (int v = threadIdx.x; v < nvec; v += 256) {
+    uint16_t xv[VEC], rv[VEC];
+    VecIO<VEC>::load(x + row * n + (int64_t)v * VEC, xv);
+    if constexpr (HAS_RES) VecIO<VEC>::load(r + row * n + (int64_t)v * VEC, rv);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float sv = to_f32<DT>(xv[i]);
+      if constexpr (HAS_RES) sv += to_f32<DT>(rv[i]);
+      ssq += sv * sv / nf;
+    }
+  }
+  const float var = row_sum<256>(ssq, lds);
+  const float rrms = 1.0f / sqrtf(var + eps);
+  for (int v = threadIdx.x; v < nvec; v += 256) {
+    uint16_t xv[VEC], rv[VEC], wv[VEC], yv[VEC];
+    VecIO<VEC>::load(x + row * n + (int64_t)v * VEC, xv);
+    if constexpr (HAS_RES) VecIO<VEC>::load(r + row * n + (int64_t)v * VEC, rv);
+    VecIO<VEC>::load(w + (int64_t)v * VEC, wv);
+#pragma unroll
+    for (int i = 0; i < VEC; ++i) {
+      float sv = to_f32<DT>(xv[i]);
+      if constexpr (HAS_RES) {
+        sv += to_f32<DT>(rv[i]);
+        rv[i] = from_f32<DT>(sv);
+      }
+      yv[i] = mul_storage<DT>(from_f32<DT>(sv * rrms), wv[i]);
+    }
+    if constexpr (HAS_RES) VecIO<VEC>::store(r + row * n + (int64_t)v * VEC, rv);
+    VecIO<VEC>::store(y + row * n + (int64_t)v * VEC, yv);
+  }
+}
+
+template <int DT, bool HAS_RES>
+static int launch_skip_rmsnorm(uint16_t* y, const uint16_t* x, uint16_t* r, const uint16_t* w,
+                               int64_t rows, int n, float eps, hipStream_t st) {
+  const bool vec = (n % 8 == 0) && ll_aligned16(y) && ll_aligned16(x) && ll_aligned16(w) &&
+                   (!HAS_RES || ll_aligned16(r));
+  if (!vec) {
+    skip_rmsnorm_twopass<DT, 1, HAS_RES><<<dim3((unsigned)rows), 256, 0, st>>>(y, x, r, w, rows, n, eps);
+    return LL_LAUNCH_CHECK();
+  }
+  const int nv = n / 8;
+#define LL_NORM_CASE(TPR, VPT)                                                              \
+  skip_rmsnorm_cached<DT, TPR, VPT, HAS_RES>                                                \
+      <<<dim3((unsigned)((rows + (256 / TPR) - 1) / (256 / TPR))), 256, 0, st>>>(y, x, r, w, rows, n, eps)
+  if (nv <= 16) LL_NORM_CASE(16, 1);
+  else if (nv <= 32) LL_NORM_CASE(32, 1);
+  else if (nv <= 64) LL_NORM_CASE(64, 1);
+  else if (nv <= 256) LL_NORM_CASE(256, 1);
+  else if (nv <= 512) LL_NORM_CASE(256, 2);
+  else if (nv <= 1024) LL_NORM_CASE(256, 4);
+  else skip_rmsnorm_twopass<DT, 8, HAS_RES><<<dim3((unsigned)rows), 256, 0, st>>>(y, x, r, w, rows, n, eps);
+#undef LL_NORM_CASE
+  return LL_LAUNCH_CHECK();
+}
+
+extern "C" int ll_skip_rmsnorm(void* y, const void* x, void* residual, const void* weight,
+                               int64_t rows, int64_t n, float eps, int dtype, void* stream) {
+  if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (rows < 0 || n <= 0 || n > 65536) return LL_ERR_SHAPE;  // utils.py:48-54 (MAX_FUSED_SIZE)
+  if (rows == 0) return LL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  auto yy = (uint16_t*)y;
+  auto xx = (const uint16_t*)x;
+  auto rr = (uint16_t*)residual;
+  auto ww = (const uint16_t*)weight;
+  if (dtype == LL_F16)
+    return residual ? launch_skip_rmsnorm<LL_F16, true>(yy, xx, rr, ww, rows, (int)n, eps, st)
+                    : launch_skip_rmsnorm<LL_F16, false>(yy, xx, rr, ww, rows, (int)n, eps, st);
+  return residual ? launch_skip_rmsnorm<LL_BF16, true>(yy, xx, rr, ww, rows, (int)n, eps, st)
+                  : launch_skip_rmsnorm<LL_BF16, false>(yy, xx, rr, ww, rows, (int)n, eps, st);
+}
+
+// --------------------------------------------------------------------------- //
+// swiglu_forward -- reference lite_llama/kernels/swiglu.py:24-65
+// silu_and_mul   -- reference lite_llama/kernels/fused_moe.py:298-315
+// --------------------------------------------------------------------------- //
+__device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
+
+// MODE 0: c[row, col] = silu(a[row, col]) * b[row, col]
+// MODE 1: c[row, col] = silu(x[row, col]) * x[row, n + col]   (x has 2n columns)
+template <int DT, int VEC, int MODE>
+__global__ __launch_bounds__(256) void swiglu_kernel(uint16_t* __restrict__ c,
+                                                     const uint16_t* __restrict__ a,
+                                                     const uint16_t* __restrict__ b, int64_t rows,
+                                                     int64_t n) {
+  const int64_t nvec = n / VEC;
+  const int64_t total = rows * nvec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t row = i / nvec, col = (i % nvec) * VEC;
+    uint16_t av[VEC], bv[VEC], cv[VEC];
+    if constexpr (MODE == 0) {
+      VecIO<VEC>::load(a + row * n + col, av);
+      VecIO<VEC>::load(b + row * n + col, bv);
+    } else {
+      VecIO<VEC>::load(a + row * 2 * n + col, av);
+      VecIO<VEC>::load(a + row * 2 * n + n + col, bv);
+    }
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float g = to_f32<DT>(av[j]);
+      cv[j] = from_f32<DT>(g * sigmoidf(g) * to_f32<DT>(bv[j]));
+    }
+    VecIO<VEC>::store(c + row * n + col, cv);
+  }
+}
+
+template <int MODE>
+static int launch_swiglu(void* c, const void* a, const void* b, int64_t rows, int64_t n, int dtype,
+                         void* stream) {
+  if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (rows < 0 || n <= 0) return LL_ERR_SHAPE;
+  if (rows == 0) return LL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (n % 8 == 0) && ll_aligned16(c) && ll_aligned16(a) && (MODE == 1 || ll_aligned16(b));
+  const int64_t total = rows * (vec ? n / 8 : n);
+  const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  auto cc = (uint16_t*)c;
+  auto aa = (const uint16_t*)a;
+  auto bb = (const uint16_t*)b;
+#define LL_SW(DT, VEC) swiglu_kernel<DT, VEC, MODE><<<dim3(grid), 256, 0, st>>>(cc, aa, bb, rows, n)
+  if (dtype == LL_F16) {
+    if (vec) LL_SW(LL_F16, 8); else LL_SW(LL_F16, 1);
+  } else {
+    if (vec) LL_SW(LL_BF16, 8); else LL_SW(LL_BF16, 1);
+  }
+#undef LL_SW
+  return LL_LAUNCH_CHECK();
+}
+
+extern "C" int ll_swiglu(void* c, const void* a, const void* b, int64_t rows, int64_t n, int dtype,
+                         void* stream) {
+  return launch_swiglu<0>(c, a, b, rows, n, dtype, stream);
+}
+extern "C" int ll_silu_and_mul(void* out, const void* x, int64_t rows, int64_t n, int dtype,
+                               void* stream) {
+  return launch_swiglu<1>(out, x, nullptr, rows, n, dtype, stream);
+}
+
+// --------------------------------------------------------------------------- //
+// moe_sum -- reference lite_llama/kernels/fused_moe.py:318-335
+// --------------------------------------------------------------------------- //
+template <int DT, int VEC>
+__global__ __launch_bounds__(256) void moe_sum_kernel(uint16_t* __restrict__ out,
+                                                      const uint16_t* __restrict__ x,
+                                                      int64_t tokens, int top_k, int64_t n) {
+  const int64_t nvec = n / VEC;
+  const int64_t total = tokens * nvec;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < total; i += (int64_t)gridDim.x * 256) {
+    const int64_t t = i / nvec, col = (i % nvec) * VEC;
+    float acc[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) acc[j] = 0.f;
+    for (int kk = 0; kk < top_k; ++kk) {
+      uint16_t v[VEC];
+      VecIO<VEC>::load(x + (t * top_k + kk) * n + col, v);
+#pragma unroll
+      for (int j = 0; j < VEC; ++j) acc[j] += to_f32<DT>(v[j]);
+    }
+    uint16_t o[VEC];
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) o[j] = from_f32<DT>(acc[j]);
+    VecIO<VEC>::store(out + t * n + col, o);
+  }
+}
+
+extern "C" int ll_moe_sum(void* out, const void* x, int64_t tokens, int top_k, int64_t n, int dtype,
+                          void* stream) {
+  if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (tokens < 0 || n <= 0 || top_k <= 0) return LL_ERR_SHAPE;
+  if (tokens == 0) return LL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (n % 8 == 0) && ll_aligned16(out) && ll_aligned16(x);
+  const int64_t total = tokens * (vec ? n / 8 : n);
+  const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
+  auto oo = (uint16_t*)out;
+  auto xx = (const uint16_t*)x;
+#define LL_MS(DT, VEC) moe_sum_kernel<DT, VEC><<<dim3(grid), 256, 0, st>>>(oo, xx, tokens, top_k, n)
+  if (dtype == LL_F16) {
+    if (vec) LL_MS(LL_F16, 8); else LL_MS(LL_F16, 1);
+  } else {
+    if (vec) LL_MS(LL_BF16, 8); else LL_MS(LL_BF16, 1);
+  }
+#undef LL_MS
+  return LL_LAUNCH_CHECK();
+}
+
+// --------------------------------------------------------------------------- //
+// rope_emb_forward -- reference lite_llama/kernels/rope_emb.py:14-134
+// One block per token; every thread rotates 8-wide (or scalar) channel pairs.
+// cos/sin may be fp16/bf16/fp32; only [.., :hd/2] is read.
+// --------------------------------------------------------------------------- //
+template <int CS>
+__device__ __forceinline__ float load_cs(const void* p, int64_t i) {
+  if constexpr (CS == LL_F32) return ((const float*)p)[i];
+  else return to_f32<CS>(((const uint16_t*)p)[i]);
+}
+
+template <int DT, int CS, int VEC>
+__global__ __launch_bounds__(256) void rope_kernel(uint16_t* __restrict__ q, uint16_t* __restrict__ k,
+                                                   const void* __restrict__ cos_t,
+                                                   const void* __restrict__ sin_t, int n_qh, int n_kh,
+                                                   int hd, int64_t q_rs, int64_t k_rs, int64_t seq_len,
+                                                   int64_t cbs, int64_t css, int64_t sbs, int64_t sss) {
+  const int64_t tok = blockIdx.x;
+  const int64_t bi = tok / seq_len, si = tok % seq_len;
+  const int half = hd / 2;
+  const int vph = half / VEC;  // vectors per head-half
+  const int total = (n_qh + n_kh) * vph;
+  const int64_t cbase = bi * cbs + si * css;
+  const int64_t sbase = bi * sbs + si * sss;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int h = i / vph, j = (i % vph) * VEC;
+    uint16_t* base = (h < n_qh) ? (q + tok * q_rs + (int64_t)h * hd) : (k + tok * k_rs + (int64_t)(h - n_qh) * hd);
+    uint16_t x1[VEC], x2[VEC], o1[VEC], o2[VEC];
+    VecIO<VEC>::load(base + j, x1);
+    VecIO<VEC>::load(base + half + j, x2);
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float c = load_cs<CS>(cos_t, cbase + j + e);
+      const float s = load_cs<CS>(sin_t, sbase + j + e);
+      const float a = to_f32<DT>(x1[e]), b = to_f32<DT>(x2[e]);
+      o1[e] = from_f32<DT>(a * c - b * s);
+      o2[e] = from_f32<DT>(b * c + a * s);
+    }
+    VecIO<VEC>::store(base + j, o1);
+    VecIO<VEC>::store(base + half + j, o2);
+  }
+}
+
+extern "C" int ll_rope(void* q, void* k, const void* cos_t, const void* sin_t, int64_t tokens,
+                       int n_qh, int n_kh, int hd, int64_t q_row_stride, int64_t k_row_stride,
+                       int64_t seq_len, int64_t cos_b_stride, int64_t cos_s_stride,
+                       int64_t sin_b_stride, int64_t sin_s_stride, int qk_dtype, int cs_dtype,
+                       void* stream) {
+  if (qk_dtype != LL_F16 && qk_dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (cs_dtype != LL_F16 && cs_dtype != LL_BF16 && cs_dtype != LL_F32) return LL_ERR_DTYPE;
+  if (tokens < 0 || hd <= 0 || (hd & 1) || seq_len <= 0) return LL_ERR_SHAPE;
+  if (tokens == 0) return LL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (hd % 16 == 0) && ll_aligned16(q) && ll_aligned16(k) && (q_row_stride % 8 == 0) &&
+                   (k_row_stride % 8 == 0);
+  auto qq = (uint16_t*)q;
+  auto kk = (uint16_t*)k;
+#define LL_ROPE(DT, CS, VEC)                                                                      \
+  rope_kernel<DT, CS, VEC><<<dim3((unsigned)tokens), 256, 0, st>>>(                               \
+      qq, kk, cos_t, sin_t, n_qh, n_kh, hd, q_row_stride, k_row_stride, seq_len, cos_b_stride,    \
+      cos_s_stride, sin_b_stride, sin_s_stride)
+#define LL_ROPE_CS(DT, VEC)                                   \
+  if (cs_dtype == LL_F16) LL_ROPE(DT, LL_F16, VEC);           \
+  else if (cs_dtype == LL_BF16) LL_ROPE(DT, LL_BF16, VEC);    \
+  else LL_ROPE(DT, LL_F32, VEC)
+  if (qk_dtype == LL_F16) {
+    if (vec) { LL_ROPE_CS(LL_F16, 8); } else { LL_ROPE_CS(LL_F16, 1); }
+  } else {
+    if (vec) { LL_ROPE_CS(LL_BF16, 8); } else { LL_ROPE_CS(LL_BF16, 1); }
+  }
+#undef LL_ROPE_CS
+#undef LL_ROPE
+  return LL_LAUNCH_CHECK();
+}
+
+// --------------------------------------------------------------------------- //
+// greedy argmax -- reference lite_llama/engine/sampler.py:227-228,264
+// (torch.argmax: first index of the maximum).  One block per row.
+// --------------------------------------------------------------------------- //
+template <int DT>
+__device__ __forceinline__ float load_logit(const void* p, int64_t i) {
+  if constexpr (DT == LL_F32) return ((const float*)p)[i];
+  else return to_f32<DT>(((const uint16_t*)p)[i]);
+}
+
+template <int DT>
+__global__ __launch_bounds__(1024) void argmax_kernel(int64_t* __restrict__ out,
+                                                      const void* __restrict__ logits, int64_t n,
+                                                      int64_t stride_row) {
+  __shared__ float sv[16];
+  __shared__ int64_t si[16];
+  const int64_t row = blockIdx.x;
+  float best = -INFINITY;
+  int64_t bi = INT64_MAX;
+  for (int64_t i = threadIdx.x; i < n; i += 1024) {
+    const float v = load_logit<DT>(logits, row * stride_row + i);
+    if (bi == INT64_MAX || v > best) {  // per-thread indices ascend: strict > keeps the first max
+      best = v;
+      bi = i;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int64_t oi = __shfl_xor(bi, off, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sv[wid] = best;
+    si[wid] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 16; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
+        best = sv[w];
+        bi = si[w];
+      }
+    out[row] = bi;
+  }
+}
+
+extern "C" int ll_argmax(int64_t* out, const void* logits, int64_t rows, int64_t n, int64_t stride_row,
+                         int dtype, void* stream) {
+  if (rows < 0 || n <= 0) return LL_ERR_SHAPE;
+  if (rows == 0) return LL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LL_F16) argmax_kernel<LL_F16><<<dim3((unsigned)rows), 1024, 0, st>>>(out, logits, n, stride_row);
+  else if (dtype == LL_BF16) argmax_kernel<LL_BF16><<<dim3((unsigned)rows), 1024, 0, st>>>(out, logits, n, stride_row);
+  else if (dtype == LL_F32) argmax_kernel<LL_F32><<<dim3((unsigned)rows), 1024, 0, st>>>(out, logits, n, stride_row);
+  else return LL_ERR_DTYPE;
+  return LL_LAUNCH_CHECK();
+}

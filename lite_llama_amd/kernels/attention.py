@@ -1,0 +1,85 @@
+"""flash_decoding / flash_attention2_no_pad -- mirror of lite_llama/kernels/flashdecoding.py:316-380
+and flashattention2_nopad.py:175-231 over the HIP C-ABI."""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _lib as L
+
+
+@torch.no_grad()
+def flash_decoding(
+    q,
+    k_cache,
+    v_cache,
+    qk_scale,
+    b_req_tokens_table,
+    b_req_idx,
+    b_seq_len,
+    max_actual_seq_len,
+):
+    """Decode attention for one new token per batch row against the token-attention pool.
+
+    ``k_cache`` / ``v_cache`` may be strided views of ``[max_tokens, 2*Hkv, D]`` (last dim
+    contiguous); index tensors may be int32 or int64; the output is a fresh ``[B, Hq, D]``.
+    Scratch (``mid_o``, ``mid_o_logexpsum``) is allocated per call like the reference does
+    (flashdecoding.py:347-358) -- from torch's caching allocator, so it is graph-safe.
+    """
+    L.require_cuda(q, k_cache, v_cache, b_req_tokens_table, b_req_idx, b_seq_len)
+    assert q.shape[-1] == k_cache.shape[-1] == v_cache.shape[-1]
+    assert b_req_tokens_table.dtype == torch.int32
+    batchs, num_heads, head_dim = q.shape
+    if q.stride(-1) != 1:
+        q = q.contiguous()
+    assert k_cache.stride(-1) == 1 and v_cache.stride(-1) == 1
+    if b_req_tokens_table.stride(1) != 1:
+        b_req_tokens_table = b_req_tokens_table.contiguous()
+    max_len = int(max_actual_seq_len)
+    nparts = L.lib().ll_flash_decoding_num_partitions(max_len)
+    mid_o = torch.empty((batchs, num_heads, max(nparts, 1), head_dim), dtype=torch.float32, device=q.device)
+    mid_lse = torch.empty((batchs, num_heads, max(nparts, 1)), dtype=torch.float32, device=q.device)
+    out = torch.empty_like(q, memory_format=torch.contiguous_format)
+    L.check(
+        L.lib().ll_flash_decoding(
+            out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
+            b_req_tokens_table.data_ptr(), b_req_idx.data_ptr(), b_seq_len.data_ptr(),
+            mid_o.data_ptr(), mid_lse.data_ptr(), batchs, num_heads, k_cache.shape[1], head_dim,
+            max_len, float(qk_scale), q.stride(0), q.stride(1), k_cache.stride(0), k_cache.stride(1),
+            v_cache.stride(0), v_cache.stride(1), out.stride(0), out.stride(1),
+            b_req_tokens_table.stride(0), L.dtype_code(q.dtype), L.index_width(b_req_idx),
+            L.index_width(b_seq_len), L.stream_ptr(),
+        ),
+        "flash_decoding",
+    )
+    return out
+
+
+@torch.no_grad()
+def flash_attention2_no_pad(q, k, v, sm_scale, b_start_loc, b_seq_len, max_seq_len):
+    """Varlen causal prefill attention (``sm_scale`` must already include log2(e); the
+    kernel evaluates exp2).  fp32 inputs are cast to fp16 like the reference's
+    ``custom_fwd(cast_inputs=torch.float16)``."""
+    L.require_cuda(q, k, v, b_start_loc, b_seq_len)
+    if q.dtype == torch.float32:
+        q, k, v = q.half(), k.half(), v.half()
+    if q.stride(-1) != 1:
+        q = q.contiguous()
+    if k.stride(-1) != 1:
+        k = k.contiguous()
+    if v.stride(-1) != 1:
+        v = v.contiguous()
+    output = torch.empty_like(q, memory_format=torch.contiguous_format)
+    batchs = b_seq_len.shape[0]
+    n_heads, head_dim = q.shape[1], q.shape[2]
+    L.check(
+        L.lib().ll_flash_attention_nopad(
+            output.data_ptr(), q.data_ptr(), k.data_ptr(), v.data_ptr(), b_start_loc.data_ptr(),
+            b_seq_len.data_ptr(), batchs, n_heads, k.shape[1], head_dim, int(max_seq_len),
+            float(sm_scale), q.stride(0), q.stride(1), k.stride(0), k.stride(1), v.stride(0),
+            v.stride(1), output.stride(0), output.stride(1), L.dtype_code(q.dtype),
+            L.index_width(b_start_loc), L.index_width(b_seq_len), L.stream_ptr(),
+        ),
+        "flash_attention2_no_pad",
+    )
+    return output

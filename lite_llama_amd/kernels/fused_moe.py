@@ -1,0 +1,140 @@
+"""fused_moe / moe_align_block_size -- mirror of lite_llama/kernels/fused_moe.py:45-99,352-438
+over the HIP C-ABI.  Same vLLM data protocol: ``sorted_token_ids`` (slot ids sorted by expert,
+each expert's run padded to BLOCK_M with the sentinel ``num_slots``), ``expert_ids`` (expert
+per row block) and ``num_tokens_post_padded`` (device scalar; no host sync anywhere)."""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _lib as L
+
+
+def moe_align_block_size(
+    topk_ids: torch.Tensor, block_size: int, num_experts: int
+) -> tuple[torch.Tensor, torch.Tensor, torch.Tensor]:
+    """Returns ``(sorted_token_ids i32[max_padded], expert_ids i32[max_blocks],
+    num_tokens_post_padded i32[1])`` -- all shapes static (graph-capturable)."""
+    L.require_cuda(topk_ids)
+    device = topk_ids.device
+    flat = topk_ids.reshape(-1)
+    if not flat.is_contiguous():
+        flat = flat.contiguous()
+    num_slots = flat.numel()
+    max_padded = num_slots + num_experts * (block_size - 1)
+    max_blocks = (max_padded + block_size - 1) // block_size
+    sorted_ids = torch.empty((max_padded,), dtype=torch.int32, device=device)
+    expert_ids = torch.empty((max_blocks,), dtype=torch.int32, device=device)
+    num_post = torch.empty((1,), dtype=torch.int32, device=device)
+    L.check(
+        L.lib().ll_moe_align_block_size(
+            flat.data_ptr(), L.index_width(flat), num_slots, int(num_experts), int(block_size),
+            sorted_ids.data_ptr(), expert_ids.data_ptr(), num_post.data_ptr(), L.stream_ptr(),
+        ),
+        "moe_align_block_size",
+    )
+    return sorted_ids, expert_ids, num_post
+
+
+def _block_m(num_tokens: int) -> int:
+    # reference _launch_config (fused_moe.py:214-222): both GEMMs share one alignment
+    if num_tokens <= 16:
+        return 16
+    if num_tokens <= 64:
+        return 32
+    return 64
+
+
+def _wfmt(weight: torch.Tensor, scale) -> int:
+    if scale is None:
+        return L.LL_W_F16
+    if weight.dtype == torch.uint8:
+        return L.LL_W_FP8E4M3
+    if weight.dtype == torch.int8:
+        return L.LL_W_INT8
+    raise ValueError(f"quantised expert weights must be uint8 or int8, got {weight.dtype}")
+
+
+def _moe_gemm(a, w, c, w_scale, topk_w, sorted_ids, expert_ids, num_post, top_k, mul_w, wfmt,
+              group_n, group_k, block_m):
+    assert a.stride(-1) == 1 and w.stride(-1) == 1, "last dims must be contiguous"
+    n, k = w.shape[1], w.shape[2]
+    if w_scale is not None:
+        ss = w_scale.stride()
+        gk = min(group_k, k) if group_k else 1
+        gn = group_n or 1
+    else:
+        ss, gk, gn = (0, 0, 0), 1, 1
+    L.check(
+        L.lib().ll_moe_gemm(
+            c.data_ptr(), a.data_ptr(), w.data_ptr(), L.ptr(w_scale), topk_w.data_ptr(),
+            sorted_ids.data_ptr(), expert_ids.data_ptr(), num_post.data_ptr(), c.shape[0],
+            sorted_ids.numel(), block_m, n, k, top_k, int(mul_w), wfmt, gn, gk, a.stride(0),
+            w.stride(0), w.stride(1), ss[0], ss[1], ss[2], L.dtype_code(c.dtype), L.stream_ptr(),
+        ),
+        "fused_moe grouped GEMM",
+    )
+
+
+def fused_moe(
+    hidden_states: torch.Tensor,
+    w1: torch.Tensor,
+    w2: torch.Tensor,
+    topk_weights: torch.Tensor,
+    topk_ids: torch.Tensor,
+    *,
+    w1_scale: torch.Tensor | None = None,
+    w2_scale: torch.Tensor | None = None,
+    group_n: int = 0,
+    group_k: int = 0,
+) -> torch.Tensor:
+    """``sum_k w_k * (silu(x W1g^T) * (x W1u^T)) W2^T`` over each token's top-k experts.
+
+    Pipeline and intermediate dtypes as the reference: align -> GEMM1 (``[T*k, 2I]`` in x's
+    dtype) -> silu*up -> GEMM2 with the router weight folded in fp32 -> fp32 sum over top_k."""
+    num_tokens, hidden = hidden_states.shape
+    num_experts, two_inter, _ = w1.shape
+    intermediate = two_inter // 2
+    top_k = topk_ids.shape[1]
+    device = hidden_states.device
+    dtype = hidden_states.dtype
+
+    wfmt = _wfmt(w1, w1_scale)
+    if wfmt != _wfmt(w2, w2_scale):
+        raise ValueError("w1 and w2 must use the same quantisation format")
+    if wfmt and group_k % 128 != 0 and group_k < min(hidden, intermediate):
+        raise ValueError(f"group_k ({group_k}) must be a multiple of 128 unless it covers K")
+    L.require_cuda(hidden_states, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale)
+    if hidden_states.stride(-1) != 1:
+        hidden_states = hidden_states.contiguous()
+
+    topk_ids = topk_ids.to(torch.int32)
+    flat_weights = topk_weights.reshape(-1).to(dtype).contiguous()
+
+    block_m = _block_m(num_tokens)
+    sorted_ids, expert_ids, num_post = moe_align_block_size(topk_ids, block_m, num_experts)
+
+    gate_up = torch.empty((num_tokens * top_k, two_inter), device=device, dtype=dtype)
+    _moe_gemm(hidden_states, w1, gate_up, w1_scale, flat_weights, sorted_ids, expert_ids, num_post,
+              top_k, False, wfmt, group_n, group_k, block_m)
+
+    act = torch.empty((num_tokens * top_k, intermediate), device=device, dtype=dtype)
+    L.check(
+        L.lib().ll_silu_and_mul(act.data_ptr(), gate_up.data_ptr(), num_tokens * top_k, intermediate,
+                                L.dtype_code(dtype), L.stream_ptr()),
+        "silu_and_mul",
+    )
+
+    # GEMM2 gathers per-slot rows of ``act`` (top_k = 1 makes slot // top_k the identity,
+    # fused_moe.py:420-430) and folds the router weight in fp32.
+    expanded = torch.empty((num_tokens * top_k, hidden), device=device, dtype=dtype)
+    _moe_gemm(act, w2, expanded, w2_scale, flat_weights, sorted_ids, expert_ids, num_post,
+              1, True, wfmt, group_n, group_k, block_m)
+
+    out = torch.empty((num_tokens, hidden), device=device, dtype=dtype)
+    L.check(
+        L.lib().ll_moe_sum(out.data_ptr(), expanded.data_ptr(), num_tokens, top_k, hidden,
+                           L.dtype_code(dtype), L.stream_ptr()),
+        "moe_sum",
+    )
+    return out

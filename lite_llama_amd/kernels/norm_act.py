@@ -1,0 +1,93 @@
+"""skip_rmsnorm / swiglu_forward / rope_emb_forward -- Python mirror of the reference
+wrappers (lite_llama/kernels/skip_rmsnorm.py:192-234, swiglu.py:45-65, rope_emb.py:86-134)
+over the HIP C-ABI.  Same names, argument meaning, aliasing and error behaviour."""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _lib as L
+
+MAX_FUSED_SIZE = 65536  # reference kernels/utils.py:20
+
+
+def _check_row(n: int) -> None:
+    # reference calculate_settings (kernels/utils.py:48-54)
+    block = 1 << max(0, (n - 1).bit_length())
+    if block > MAX_FUSED_SIZE:
+        raise RuntimeError(
+            f"Cannot launch Triton kernel since n = {n} exceeds "
+            f"the recommended Triton blocksize = {MAX_FUSED_SIZE}."
+        )
+
+
+@torch.no_grad()
+def skip_rmsnorm(X, residual, weight, eps=1e-5):
+    """``(Y, residual)``: residual is updated IN PLACE with ``x + residual`` and returned
+    (same storage); ``residual=None`` -> plain RMSNorm, returns ``(Y, X)``."""
+    L.require_cuda(X, residual, weight)
+    orig_shape = X.shape
+    X = X.contiguous().view(-1, orig_shape[-1])
+    M, N = X.shape
+    _check_row(N)
+    Y = torch.empty_like(X)
+    if residual is not None:
+        residual = residual.contiguous().view(-1, N)
+    if weight.dtype != X.dtype:
+        weight = weight.to(X.dtype)
+    L.check(
+        L.lib().ll_skip_rmsnorm(
+            Y.data_ptr(), X.data_ptr(), L.ptr(residual), weight.contiguous().data_ptr(), M, N,
+            float(eps), L.dtype_code(X.dtype), L.stream_ptr(),
+        ),
+        "skip_rmsnorm",
+    )
+    if residual is not None:
+        return Y.view(orig_shape), residual.view(orig_shape)
+    return Y.view(orig_shape), X.view(orig_shape)
+
+
+def swiglu_forward(a, b):
+    """``silu(a.float()) * b`` in ``a``'s dtype and shape."""
+    L.require_cuda(a, b)
+    ori_shape = a.shape
+    n_cols = ori_shape[-1]
+    _check_row(n_cols)
+    a2 = a.view(-1, n_cols)
+    b2 = b.view(-1, n_cols)
+    if not a2.is_contiguous():
+        a2 = a2.contiguous()
+    if not b2.is_contiguous():
+        b2 = b2.contiguous()
+    c = torch.empty_like(a2)
+    L.check(
+        L.lib().ll_swiglu(c.data_ptr(), a2.data_ptr(), b2.data_ptr(), a2.shape[0], n_cols,
+                          L.dtype_code(a.dtype), L.stream_ptr()),
+        "swiglu_forward",
+    )
+    return c.view(*ori_shape)
+
+
+def rope_emb_forward(q, k, cos, sin, batch_size, seq_len):
+    """In-place half-split RoPE on ``q [N, Hq, D]`` and ``k [N, Hk, D]``; token ``i`` uses
+    ``cos[i // seq_len, i % seq_len, : D/2]``.  Returns ``(q, k)`` (the same tensors when
+    the inputs are contiguous, exactly like the reference's ``.contiguous()`` calls)."""
+    L.require_cuda(q, k, cos, sin)
+    N, n_qh, hd = q.shape
+    _, n_kh, _ = k.shape
+    assert batch_size * seq_len == N
+    q = q.contiguous()
+    k = k.contiguous()
+    cos = cos.contiguous()
+    sin = sin.contiguous()
+    if cos.dtype != sin.dtype:
+        sin = sin.to(cos.dtype)
+    L.check(
+        L.lib().ll_rope(
+            q.data_ptr(), k.data_ptr(), cos.data_ptr(), sin.data_ptr(), N, n_qh, n_kh, hd,
+            q.stride(0), k.stride(0), seq_len, cos.stride(0), cos.stride(1), sin.stride(0),
+            sin.stride(1), L.dtype_code(q.dtype), L.dtype_code(cos.dtype), L.stream_ptr(),
+        ),
+        "rope_emb_forward",
+    )
+    return q, k

@@ -1,0 +1,173 @@
+"""w4a16_matmul / w8a16_matmul / smoothquant_matmul -- mirror of
+lite_llama/kernels/quantization/{w4a16.py:152-207, w8a16.py:155-216, w8a8.py:151-217}
+over the HIP C-ABI.  Same signatures, same ValueErrors, same on-device weight formats
+(the reference's own: qweight [N, K/8] int32 LSB-first nibbles + fp32 scales/zeros [N, K/g];
+8-bit [N, K] uint8 (e4m3 bits) / int8 + fp32 scale grid)."""
+
+from __future__ import annotations
+
+import torch
+
+from .. import _lib as L
+
+
+def _flatten(x: torch.Tensor, k: int):
+    a = x.reshape(-1, k)
+    if a.stride(-1) != 1 or (a.stride(0) % 8) != 0 or (a.data_ptr() % 16) != 0:
+        a = a.contiguous()
+    return a
+
+
+def w4a16_matmul(
+    x: torch.Tensor,
+    qweight: torch.Tensor,
+    scales: torch.Tensor,
+    zeros: torch.Tensor,
+    *,
+    group_size: int = 128,
+    bias: torch.Tensor | None = None,
+) -> torch.Tensor:
+    """``x @ dequant(qweight).T (+ bias)``; ``W[n,k] = (nib(n,k) - zeros[n,k//g]) * scales[n,k//g]``."""
+    if x.dtype != torch.float16:
+        raise ValueError(f"w4a16 activations must be fp16, got {x.dtype}")
+    if qweight.dtype != torch.int32:
+        raise ValueError(f"qweight must be int32 (packed int4), got {qweight.dtype}")
+    n, k_packed = qweight.shape
+    k = k_packed * 8
+    if x.shape[-1] != k:
+        raise ValueError(f"x has {x.shape[-1]} cols but weight expects {k}")
+    if k % group_size != 0:
+        raise ValueError(f"K ({k}) must be a multiple of group_size ({group_size})")
+    L.require_cuda(x, qweight, scales, zeros, bias)
+    leading = x.shape[:-1]
+    a = _flatten(x, k)
+    m = a.shape[0]
+    if qweight.stride(1) != 1:
+        qweight = qweight.contiguous()
+    if scales.dtype != torch.float32 or scales.stride(1) != 1:
+        scales = scales.float().contiguous()
+    if zeros.dtype != torch.float32 or zeros.stride() != scales.stride():
+        zeros = zeros.float().contiguous()
+        scales = scales.contiguous()
+    if bias is not None and bias.dtype != torch.float16:
+        bias = bias.half()
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    ws, cnt = L.gemm_workspace(x.device, m, n, k)
+    L.check(
+        L.lib().ll_w4a16_matmul(
+            out.data_ptr(), a.data_ptr(), qweight.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+            L.ptr(bias), m, n, k, int(group_size), a.stride(0), qweight.stride(0), scales.stride(0),
+            ws.data_ptr(), cnt.data_ptr(), L.stream_ptr(),
+        ),
+        "w4a16_matmul",
+    )
+    return out.reshape(*leading, n)
+
+
+def w8a16_matmul(
+    x: torch.Tensor,
+    qweight: torch.Tensor,
+    scales: torch.Tensor,
+    *,
+    group_n: int,
+    group_k: int,
+    bias: torch.Tensor | None = None,
+) -> torch.Tensor:
+    """``x @ dequant(qweight).T (+ bias)`` with uint8 (fp8-e4m3 bits) or int8 weights and one
+    fp32 scale per ``(group_n, group_k)`` weight block."""
+    is_fp8 = qweight.dtype == torch.uint8
+    if not is_fp8 and qweight.dtype != torch.int8:
+        raise ValueError(f"qweight must be uint8 (fp8) or int8, got {qweight.dtype}")
+    if x.dtype != torch.float16:
+        raise ValueError(f"w8a16 activations must be fp16, got {x.dtype}")
+    if qweight.stride(-1) != 1:
+        raise ValueError("qweight last dimension must be contiguous")
+    n, k = qweight.shape
+    if x.shape[-1] != k:
+        raise ValueError(f"x has {x.shape[-1]} cols but weight expects {k}")
+    if group_k % 128 != 0 and group_k < k:
+        raise ValueError(f"group_k ({group_k}) must be a multiple of 128 unless it covers K")
+    L.require_cuda(x, qweight, scales, bias)
+    leading = x.shape[:-1]
+    a = _flatten(x, k)
+    m = a.shape[0]
+    if scales.dtype != torch.float32:
+        scales = scales.float()
+    if scales.dim() == 1:
+        scales = scales.unsqueeze(-1)
+    if bias is not None and bias.dtype != torch.float16:
+        bias = bias.half()
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    ws, cnt = L.gemm_workspace(x.device, m, n, k)
+    L.check(
+        L.lib().ll_w8a16_matmul(
+            out.data_ptr(), a.data_ptr(), qweight.data_ptr(), scales.data_ptr(), L.ptr(bias), m, n, k,
+            int(group_n), int(min(group_k, k)), L.LL_W_FP8E4M3 if is_fp8 else L.LL_W_INT8, a.stride(0),
+            qweight.stride(0), scales.stride(0), scales.stride(1), ws.data_ptr(), cnt.data_ptr(),
+            L.stream_ptr(),
+        ),
+        "w8a16_matmul",
+    )
+    return out.reshape(*leading, n)
+
+
+def quantize_activations_int8(a: torch.Tensor):
+    """Per-token dynamic int8 quantiser of smoothquant_matmul (w8a8.py:34-68):
+    ``scale = absmax/127`` (1.0 if 0), ``q = trunc(x/scale)``.  Returns ``(q int8, scale fp32)``."""
+    L.require_cuda(a)
+    m, k = a.shape
+    q = torch.empty((m, k), dtype=torch.int8, device=a.device)
+    s = torch.empty((m,), dtype=torch.float32, device=a.device)
+    L.check(
+        L.lib().ll_quantize_activations_int8(q.data_ptr(), s.data_ptr(), a.data_ptr(), m, k, a.stride(0),
+                                             L.stream_ptr()),
+        "quantize_activations_int8",
+    )
+    return q, s
+
+
+def smoothquant_matmul(
+    x: torch.Tensor,
+    qweight: torch.Tensor,
+    weight_scales: torch.Tensor,
+    *,
+    bias: torch.Tensor | None = None,
+    _return_int32: bool = False,
+) -> torch.Tensor:
+    """Dynamic per-token W8A8: int8 x int8 -> int32 (exact) -> ``* a_scale[m] * w_scale[n]``."""
+    if x.dtype != torch.float16:
+        raise ValueError(f"smoothquant activations must be fp16, got {x.dtype}")
+    if qweight.dtype != torch.int8:
+        raise ValueError(f"qweight must be int8, got {qweight.dtype}")
+    n, k = qweight.shape
+    if x.shape[-1] != k:
+        raise ValueError(f"x has {x.shape[-1]} cols but weight expects {k}")
+    L.require_cuda(x, qweight, weight_scales, bias)
+    leading = x.shape[:-1]
+    a = x.reshape(-1, k)
+    if a.stride(-1) != 1:
+        a = a.contiguous()
+    m = a.shape[0]
+    qa, a_scale = quantize_activations_int8(a)
+    if weight_scales.dim() > 1:
+        weight_scales = weight_scales.squeeze(-1)
+    weight_scales = weight_scales.float().contiguous()
+    if qweight.stride(1) != 1:
+        qweight = qweight.contiguous()
+    if bias is not None and bias.dtype != torch.float16:
+        bias = bias.half()
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    acc = torch.empty((m, n), dtype=torch.int32, device=x.device) if _return_int32 else None
+    ws, cnt = L.gemm_workspace(x.device, m, n, k)
+    L.check(
+        L.lib().ll_w8a8_matmul(
+            out.data_ptr(), qa.data_ptr(), a_scale.data_ptr(), qweight.data_ptr(),
+            weight_scales.data_ptr(), L.ptr(bias), m, n, k, qweight.stride(0), L.ptr(acc),
+            ws.data_ptr(), cnt.data_ptr(), L.stream_ptr(),
+        ),
+        "smoothquant_matmul",
+    )
+    out = out.reshape(*leading, n)
+    if _return_int32:
+        return out, acc, qa, a_scale
+    return out

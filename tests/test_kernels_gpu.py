@@ -1,0 +1,421 @@
+"""GPU parity tests (run with ``-m gpu`` on the MI355X box): the HIP path, called through
+the C ABI via the Python mirror, against (1) the committed golden vectors produced by the
+reference Triton kernels and (2) the CPU oracle on seeded inputs, with the reference's own
+test parametrisations (tests/kernels/*.py) and tolerances.
+
+Bit-exact: KV scatter / index writes, int8 activation codes, int32 accumulators, moe_align
+outputs, argmax.  Floating point: the reference's rtol = atol per kernel.
+"""
+
+import math
+
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+
+DEV = "cuda"
+
+
+def K():
+    import lite_llama_amd.kernels as k
+
+    return k
+
+
+def close(a, b, tol):
+    torch.testing.assert_close(a.float().cpu(), b.float().cpu(), rtol=tol, atol=tol)
+
+
+def dev(d):
+    return {k: (v.to(DEV) if isinstance(v, torch.Tensor) else v) for k, v in d.items()}
+
+
+# ------------------------------------------------------------------------------------- #
+# skip_rmsnorm / swiglu / rope (tol 2e-2)
+# ------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("name", G.names("skip_rmsnorm_"))
+def test_skip_rmsnorm_golden(name):
+    d = dev(G.load(name))
+    r = d["r_in"].clone() if d["has_res"] else None
+    x = d["x"].clone()
+    y, r_out = K().skip_rmsnorm(x, r, d["w"], d["eps"])
+    if d["y_valid"]:
+        close(y, d["y"], 2e-2)
+    else:
+        yo, _ = O.skip_rmsnorm(d["x"].cpu().clone(), d["r_in"].cpu().clone(), d["w"].cpu(), d["eps"])
+        close(y, yo, 2e-2)
+    if d["has_res"]:
+        close(r_out, d["r_out"], 1e-2 if r_out.dtype == torch.bfloat16 else 1e-3)
+        assert r_out.data_ptr() == r.data_ptr()  # in-place aliasing contract
+    else:
+        assert r_out.data_ptr() == x.data_ptr()
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 512), (2, 16, 1024), (1, 7, 896), (4, 1, 2048), (64, 1, 3584),
+                                   (3, 5, 300), (2, 1, 16384), (5, 28, 128)])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("with_res", [True, False])
+def test_skip_rmsnorm_oracle(shape, dtype, with_res):
+    x = torch.randn(shape, dtype=dtype)
+    r = torch.randn(shape, dtype=dtype) if with_res else None
+    w = torch.randn(shape[-1], dtype=dtype)
+    yo, ro = O.skip_rmsnorm(x.clone(), r.clone() if with_res else None, w, 1e-6)
+    rg = r.to(DEV) if with_res else None
+    y, r_out = K().skip_rmsnorm(x.to(DEV), rg, w.to(DEV), 1e-6)
+    close(y, yo, 2e-2)
+    if with_res:
+        close(r_out, ro, 1e-2 if dtype == torch.bfloat16 else 1e-3)
+        assert r_out.data_ptr() == rg.data_ptr()
+
+
+def test_skip_rmsnorm_unit_rms_and_post_add():
+    x = torch.randn(1, 32, 1024, device=DEV, dtype=torch.float16) * 5.0
+    w = torch.ones(1024, device=DEV, dtype=torch.float16)
+    out, _ = K().skip_rmsnorm(x, None, w)
+    rms = out.float().pow(2).mean(dim=-1).sqrt()
+    torch.testing.assert_close(rms, torch.ones_like(rms), rtol=5e-2, atol=5e-2)
+    x = torch.full((1, 4, 256), 2.0, device=DEV, dtype=torch.float16)
+    r = torch.full((1, 4, 256), 3.0, device=DEV, dtype=torch.float16)
+    _, nr = K().skip_rmsnorm(x, r, torch.ones(256, device=DEV, dtype=torch.float16))
+    assert torch.all(nr == 5.0) and torch.all(r == 5.0) and nr.data_ptr() == r.data_ptr()
+
+
+@pytest.mark.parametrize("name", G.names("swiglu_"))
+def test_swiglu_golden(name):
+    d = dev(G.load(name))
+    close(K().swiglu_forward(d["a"], d["b"]), d["c"], 2e-2)
+
+
+@pytest.mark.parametrize("shape", [(1, 1, 256), (2, 16, 4864), (1, 5, 300), (64, 1, 18944)])
+def test_swiglu_oracle(shape):
+    a, b = torch.randn(shape, dtype=torch.float16), torch.randn(shape, dtype=torch.float16)
+    out = K().swiglu_forward(a.to(DEV), b.to(DEV))
+    close(out, O.swiglu_forward(a, b), 2e-2)
+    assert out.shape == a.shape
+    z = K().swiglu_forward(torch.zeros(1, 4, 128, device=DEV, dtype=torch.float16),
+                           torch.randn(1, 4, 128, device=DEV, dtype=torch.float16))
+    assert torch.count_nonzero(z) == 0
+
+
+@pytest.mark.parametrize("name", G.names("rope_"))
+def test_rope_golden(name):
+    d = dev(G.load(name))
+    q, k = d["q"].clone(), d["k"].clone()
+    q2, k2 = K().rope_emb_forward(q, k, d["cos"], d["sin"], d["bs"], d["sl"])
+    close(q2, d["q_out"], 2e-2)
+    close(k2, d["k_out"], 2e-2)
+    assert q2.data_ptr() == q.data_ptr() and k2.data_ptr() == k.data_ptr()  # in place
+
+
+@pytest.mark.parametrize("bs,sl,hq,hk,hd", [(2, 8, 4, 4, 64), (1, 1, 8, 2, 128), (3, 5, 14, 2, 64),
+                                            (64, 1, 28, 4, 128), (2, 3, 4, 2, 24)])
+def test_rope_oracle(bs, sl, hq, hk, hd):
+    q, k = torch.randn(bs * sl, hq, hd, dtype=torch.float16), torch.randn(bs * sl, hk, hd, dtype=torch.float16)
+    pos = torch.randint(0, 4000, (bs, sl)).float()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, hd, 2).float() / hd))
+    emb = torch.cat([pos[..., None] * inv] * 2, dim=-1)
+    cos, sin = emb.cos().half(), emb.sin().half()
+    qo, ko = O.rope_emb_forward(q.clone(), k.clone(), cos, sin, bs, sl)
+    qg, kg = K().rope_emb_forward(q.to(DEV), k.to(DEV), cos.to(DEV), sin.to(DEV), bs, sl)
+    close(qg, qo, 2e-2)
+    close(kg, ko, 2e-2)
+    # zero angle is the identity
+    q0 = torch.randn(4, 2, 64, device=DEV, dtype=torch.float16)
+    k0 = torch.randn(4, 2, 64, device=DEV, dtype=torch.float16)
+    qq, kk = K().rope_emb_forward(q0.clone(), k0.clone(), torch.ones(1, 4, 64, device=DEV, dtype=torch.float16),
+                                  torch.zeros(1, 4, 64, device=DEV, dtype=torch.float16), 1, 4)
+    assert torch.equal(qq, q0) and torch.equal(kk, k0)
+
+
+# ------------------------------------------------------------------------------------- #
+# KV cache ops (bit-exact)
+# ------------------------------------------------------------------------------------- #
+def test_update_kv_buffer_golden():
+    d = dev(G.load("update_kv_buffer"))
+    buf = d["buf_in"].clone()
+    K().update_kv_buffer(d["vals"], d["idx"], buf)
+    assert torch.equal(buf, d["buf_out"])
+
+
+@pytest.mark.parametrize("tokens,heads,hd,idx_dtype", [(64, 8, 128, torch.int32), (5, 4, 64, torch.int64),
+                                                      (7, 3, 20, torch.int32)])
+def test_update_kv_buffer_exact(tokens, heads, hd, idx_dtype):
+    pool = torch.randn(300, heads, hd, dtype=torch.float16)
+    vals = torch.randn(tokens, heads, hd, dtype=torch.float16)
+    idx = torch.randperm(300)[:tokens].to(idx_dtype)
+    ref = pool.clone()
+    O.update_kv_buffer(vals, idx, ref)
+    g = pool.to(DEV)
+    K().update_kv_buffer(vals.to(DEV), idx.to(DEV), g)
+    assert torch.equal(g.cpu(), ref)  # scattered rows exact, every other row untouched
+
+
+def test_update_kv_index_golden():
+    d = dev(G.load("update_kv_index"))
+    t = d["table_in"].clone()
+    K().update_kv_index(t, d["req"], d["seq"], d["sel"])
+    assert torch.equal(t, d["table_out"])
+
+
+@pytest.mark.parametrize("dt", [torch.int32, torch.int64])
+def test_update_kv_index_exact(dt):
+    table = torch.zeros(8, 64, dtype=torch.int32)
+    req = torch.tensor([3, 0, 7, 5], dtype=dt)
+    seq = torch.tensor([1, 64, 17, 33], dtype=dt)
+    sel = torch.tensor([11, 22, 33, 44], dtype=torch.int32)
+    ref = table.clone()
+    O.update_kv_index(ref, req, seq, sel)
+    g = table.to(DEV)
+    K().update_kv_index(g, req.to(DEV), seq.to(DEV), sel.to(DEV))
+    assert torch.equal(g.cpu(), ref)
+
+
+# ------------------------------------------------------------------------------------- #
+# flash_decoding (tol 1e-2)
+# ------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("name", G.names("flash_decoding_"))
+def test_flash_decoding_golden(name):
+    d = dev(G.load(name))
+    out = K().flash_decoding(d["q"], d["k_cache"], d["v_cache"], d["scale"], d["table"], d["req_idx"],
+                             d["seq_len"], d["max_len"])
+    close(out, d["out"], 1e-2)
+
+
+_MAX_TOKENS = 2048
+
+
+def _decode_case(seq_lens, hq, hkv, d, *, scattered=False, req_idx=None, dtype=torch.float16,
+                 idx_dtype=torch.int32, fused_pool=False):
+    if fused_pool:  # the model's layout: one [tokens, 2*Hkv, D] pool, K heads then V heads
+        pool = torch.randn(_MAX_TOKENS, 2 * hkv, d, dtype=dtype)
+        kc, vc = pool[:, :hkv], pool[:, hkv:]
+    else:
+        kc = torch.randn(_MAX_TOKENS, hkv, d, dtype=dtype)
+        vc = torch.randn(_MAX_TOKENS, hkv, d, dtype=dtype)
+    q = (torch.randn(len(seq_lens) if req_idx is None else len(req_idx), hq, d) * 0.3).to(dtype)
+    width = max(seq_lens)
+    table = torch.zeros(len(seq_lens), width, dtype=torch.int32)
+    if scattered:
+        perm = torch.randperm(_MAX_TOKENS).to(torch.int32)
+        off = 0
+        for i, n in enumerate(seq_lens):
+            table[i, :n] = perm[off : off + n]
+            off += n
+    else:
+        for i, n in enumerate(seq_lens):
+            table[i, :n] = torch.arange(i * width, i * width + n, dtype=torch.int32)
+    ridx = torch.tensor(req_idx if req_idx is not None else list(range(len(seq_lens))), dtype=idx_dtype)
+    seq = torch.tensor([seq_lens[i] for i in ridx.tolist()], dtype=idx_dtype)
+    scale = 1.0 / math.sqrt(d)
+    ref = O.flash_decoding(q, kc, vc, scale, table, ridx, seq, int(seq.max()))
+    if fused_pool:
+        pg = pool.to(DEV)
+        kg, vg = pg[:, :hkv], pg[:, hkv:]
+    else:
+        kg, vg = kc.to(DEV), vc.to(DEV)
+    out = K().flash_decoding(q.to(DEV), kg, vg, scale, table.to(DEV), ridx.to(DEV), seq.to(DEV), int(seq.max()))
+    return out, ref
+
+
+@pytest.mark.parametrize("seq_lens", [[1], [15], [16], [17], [128], [129], [200], [256]])
+def test_flash_decoding_lengths(seq_lens):
+    out, ref = _decode_case(seq_lens, 4, 4, 64)
+    close(out, ref, 1e-2)
+
+
+@pytest.mark.parametrize("seq_lens", [[32, 32], [1, 200], [17, 129, 64, 3]])
+def test_flash_decoding_ragged(seq_lens):
+    out, ref = _decode_case(seq_lens, 4, 2, 64)
+    close(out, ref, 1e-2)
+
+
+@pytest.mark.parametrize("hq,hkv", [(4, 4), (8, 2), (14, 2), (8, 1), (32, 1), (28, 4)])
+def test_flash_decoding_gqa(hq, hkv):
+    out, ref = _decode_case([48, 130], hq, hkv, 64)
+    close(out, ref, 1e-2)
+
+
+@pytest.mark.parametrize("d", [32, 64, 128])
+def test_flash_decoding_head_dims(d):
+    out, ref = _decode_case([40, 150], 4, 2, d)
+    close(out, ref, 1e-2)
+
+
+@pytest.mark.parametrize("seq_lens", [[64], [33, 130]])
+def test_flash_decoding_scattered(seq_lens):
+    out, ref = _decode_case(seq_lens, 4, 2, 64, scattered=True)
+    close(out, ref, 1e-2)
+
+
+def test_flash_decoding_req_idx_and_shared_slot():
+    out, ref = _decode_case([40, 24, 61], 8, 8, 64, req_idx=[2, 1, 0])
+    close(out, ref, 1e-2)
+    out, ref = _decode_case([33, 33, 33], 4, 2, 64, req_idx=[0, 1, 1])
+    close(out, ref, 1e-2)
+
+
+def test_flash_decoding_int64_fused_pool_bf16():
+    out, ref = _decode_case([100, 7, 300], 28, 4, 128, idx_dtype=torch.int64, fused_pool=True, scattered=True)
+    close(out, ref, 1e-2)
+    out, ref = _decode_case([70, 129], 8, 2, 64, dtype=torch.bfloat16)
+    close(out, ref, 2e-2)
+
+
+def test_flash_decoding_long_finite_and_uniform_v():
+    out, _ = _decode_case([1000], 4, 2, 64)
+    assert torch.isfinite(out).all()
+    q = torch.randn(1, 4, 64, device=DEV, dtype=torch.float16) * 0.3
+    kc = torch.randn(_MAX_TOKENS, 4, 64, device=DEV, dtype=torch.float16)
+    vc = torch.full((_MAX_TOKENS, 4, 64), 0.25, device=DEV, dtype=torch.float16)
+    table = torch.arange(150, dtype=torch.int32, device=DEV).unsqueeze(0)
+    out = K().flash_decoding(q, kc, vc, 0.125, table, torch.zeros(1, dtype=torch.int32, device=DEV),
+                             torch.tensor([150], dtype=torch.int32, device=DEV), 150)
+    close(out, torch.full_like(out, 0.25), 1e-2)
+
+
+# ------------------------------------------------------------------------------------- #
+# w4a16 (tol 5e-2; nibble unpack bit-exact)
+# ------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("name", G.names("w4a16_"))
+def test_w4a16_golden(name):
+    d = dev(G.load(name))
+    y = K().w4a16_matmul(d["x"], d["qweight"], d["scales"], d["zeros"], group_size=d["group_size"],
+                         bias=d.get("bias"))
+    close(y, d["y"], 5e-2)
+    close(y, d["y"], 1e-2)  # in practice far tighter than the reference's own tolerance
+
+
+def test_w4a16_unpack_bit_exact():
+    """x = one-hot rows, scale 1, zero 0: the GEMM output IS the unpacked nibble matrix."""
+    n, k = 128, 256
+    qw = torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64).to(torch.int32)
+    x = torch.eye(k, dtype=torch.float16)[:64]  # rows pick k = 0..63
+    sc = torch.ones(n, k // 128)
+    zr = torch.zeros(n, k // 128)
+    y = K().w4a16_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), zr.to(DEV), group_size=128)
+    nib = O.unpack_int4(qw)[:, :64].T.float()
+    assert torch.equal(y.float().cpu(), nib)
+
+
+@pytest.mark.parametrize("M,N,K_", [(1, 256, 512), (8, 512, 1024), (64, 3584, 3584), (33, 130, 384),
+                                    (64, 1024, 3584), (100, 256, 512)])
+@pytest.mark.parametrize("gs", [32, 128])
+def test_w4a16_oracle(M, N, K_, gs):
+    x = torch.randn(M, K_, dtype=torch.float16) * 0.5
+    w = torch.randn(N, K_) * 0.05
+    qw, sc, zr = O.quantize_int4_groupwise(w, gs)
+    bias = (torch.randn(N) * 0.1).half()
+    ref = O.w4a16_matmul(x, qw, sc, zr, group_size=gs, bias=bias)
+    y = K().w4a16_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), zr.to(DEV), group_size=gs, bias=bias.to(DEV))
+    close(y, ref, 5e-2)
+    close(y, ref, 1e-2)
+
+
+def test_w4a16_float_zero_points_and_errors():
+    x = torch.randn(4, 256, dtype=torch.float16)
+    qw = torch.randint(0, 2**31 - 1, (64, 32), dtype=torch.int64).to(torch.int32)
+    sc = torch.rand(64, 2) * 0.02 + 0.01
+    zr = torch.rand(64, 2) * 15  # the format stores zeros as floats: non-integers must work
+    ref = O.w4a16_matmul(x, qw, sc, zr, group_size=128)
+    y = K().w4a16_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), zr.to(DEV), group_size=128)
+    close(y, ref, 5e-2)
+    with pytest.raises(ValueError):
+        K().w4a16_matmul(x.float().to(DEV), qw.to(DEV), sc.to(DEV), zr.to(DEV))
+    with pytest.raises(ValueError):
+        K().w4a16_matmul(x.to(DEV), qw.to(torch.int64).to(DEV), sc.to(DEV), zr.to(DEV))
+    with pytest.raises(ValueError):
+        K().w4a16_matmul(x[:, :128].to(DEV), qw.to(DEV), sc.to(DEV), zr.to(DEV))
+    with pytest.raises(ValueError):
+        K().w4a16_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), zr.to(DEV), group_size=96)
+
+
+# ------------------------------------------------------------------------------------- #
+# w8a16 (tol 1e-2; 8-bit widening exact)
+# ------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("name", G.names("w8a16_"))
+def test_w8a16_golden(name):
+    d = dev(G.load(name))
+    y = K().w8a16_matmul(d["x"], d["qweight"], d["scales"], group_n=d["group_n"], group_k=d["group_k"],
+                         bias=d.get("bias"))
+    close(y, d["y"], 1e-2)
+
+
+def test_w8a16_widening_bit_exact():
+    """One-hot activations, unit scales: output = the widened weight values, all 256 codes."""
+    n, k = 256, 128
+    codes = torch.arange(256, dtype=torch.uint8)
+    qw = codes[:, None].repeat(1, k).contiguous()  # row n holds code n in every column
+    x = torch.eye(k, dtype=torch.float16)[:4]
+    y = K().w8a16_matmul(x.to(DEV), qw.to(DEV), torch.ones(2, 1, device=DEV), group_n=128, group_k=128)
+    want = O.fp8e4m3_bits_to_fp16(codes).float() * 256.0  # includes the +-480 NaN encodings
+    assert torch.equal(y[0].float().cpu(), want)
+    qi = codes.view(torch.int8)[:, None].repeat(1, k).contiguous()
+    y = K().w8a16_matmul(x.to(DEV), qi.to(DEV), torch.ones(256, 1, device=DEV), group_n=1, group_k=k)
+    assert torch.equal(y[0].float().cpu(), codes.view(torch.int8).float())
+
+
+@pytest.mark.parametrize("M,N,K_", [(1, 512, 256), (8, 2048, 2048), (128, 768, 1024)])
+def test_w8a16_fp8_block_oracle(M, N, K_):
+    x = torch.randn(M, K_, dtype=torch.float16) * 0.5
+    w = torch.randn(N, K_) * 0.05
+    qw = w.to(torch.float8_e4m3fn).view(torch.uint8)
+    sc = torch.rand((N + 127) // 128, (K_ + 127) // 128) + 0.5
+    ref = O.w8a16_matmul(x, qw, sc, group_n=128, group_k=128)
+    y = K().w8a16_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), group_n=128, group_k=128)
+    close(y, ref, 1e-2)
+
+
+@pytest.mark.parametrize("M,N,K_", [(1, 512, 256), (8, 2048, 2048), (33, 130, 384)])
+def test_w8a16_int8_per_channel_oracle(M, N, K_):
+    x = torch.randn(M, K_, dtype=torch.float16) * 0.5
+    w = torch.randn(N, K_) * 0.05
+    qw, sc = O.quantize_int8_per_channel(w)
+    ref = O.w8a16_matmul(x, qw, sc, group_n=1, group_k=K_)
+    y = K().w8a16_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), group_n=1, group_k=K_)
+    close(y, ref, 1e-2)
+    with pytest.raises(ValueError):
+        K().w8a16_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), group_n=1, group_k=64)
+
+
+# ------------------------------------------------------------------------------------- #
+# smoothquant W8A8 (quantiser + int32 accumulators bit-exact; output tol 1e-1)
+# ------------------------------------------------------------------------------------- #
+def test_smoothquant_golden_bit_exact():
+    d = dev(G.load("smoothquant"))
+    y, acc, qa, a_scale = K().smoothquant_matmul(d["x"], d["qweight"], d["scales"], bias=d["bias"],
+                                                 _return_int32=True)
+    assert torch.equal(qa, d["qa"])
+    assert torch.equal(a_scale, d["a_scale"])
+    acc_ref, _, _ = O.smoothquant_int32_acc(d["x"].cpu(), d["qweight"].cpu())
+    assert torch.equal(acc.cpu(), acc_ref)
+    close(y, d["y"], 1e-1)
+    close(y, d["y"], 2e-3)
+
+
+@pytest.mark.parametrize("M,N,K_", [(1, 256, 512), (8, 512, 1024), (64, 2048, 2048), (32, 4096, 4096)])
+def test_smoothquant_oracle(M, N, K_):
+    x = torch.randn(M, K_, dtype=torch.float16) * 0.5
+    w = torch.randn(N, K_) * 0.05
+    qw, sc = O.quantize_int8_per_channel(w)
+    ref = O.smoothquant_matmul(x, qw, sc)
+    acc_ref, qa_ref, as_ref = O.smoothquant_int32_acc(x, qw)
+    y, acc, qa, a_scale = K().smoothquant_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), _return_int32=True)
+    assert torch.equal(qa.cpu(), qa_ref) and torch.equal(a_scale.cpu(), as_ref)
+    assert torch.equal(acc.cpu(), acc_ref)
+    close(y, ref, 2e-3)
+
+
+# ------------------------------------------------------------------------------------- #
+# greedy argmax (exact)
+# ------------------------------------------------------------------------------------- #
+def test_argmax_exact():
+    from lite_llama_amd.sampling import greedy_argmax
+
+    logits = torch.randn(64, 152064, dtype=torch.float16)
+    logits[3, 100] = logits[3, 70000] = 50.0  # tie -> first index
+    got = greedy_argmax(logits.to(DEV))
+    assert torch.equal(got.cpu(), torch.argmax(logits, dim=-1))
