@@ -1,12 +1,255 @@
-// placeholder, replaced below in this round
+// fused_moe pieces (a11) -- reference lite_llama/kernels/fused_moe.py:
+//   moe_align_block_size :45-99   (torch ops in the reference; one sync-free HIP kernel here)
+//   _fused_moe_kernel    :105-211 (grouped GEMM over expert-sorted, block-padded slots)
+// The vLLM data protocol is kept bit-exactly: sorted_token_ids (slot ids stably sorted by
+// expert, every expert's run padded to block_size with the sentinel num_slots), expert_ids
+// (expert per row block; searchsorted(right=True) clamped to E-1 for the unused tail) and
+// num_tokens_post_padded (device scalar; row blocks past it exit early -> no host sync).
+//
+// Grouped GEMM on MFMA 32x32x16: expert weights (fp16, or fp8-e4m3 / int8 with one scale per
+// group_n x group_k block) are the streamed "A" operand in fragment layout exactly as in
+// gemm_wq.hip; the gathered activation rows of one row block are staged through LDS.
 #include "common.h"
-extern "C" int ll_moe_align_block_size(const void*, int, int64_t, int, int, int32_t*, int32_t*, int32_t*,
-                                       void*) {
-  return LL_ERR_ARG;
+
+struct alignas(16) Q4 {
+  uint32_t x, y, z, w;
+};
+
+__device__ __forceinline__ int64_t moe_load_idx(const void* p, int64_t i, int w) {
+  return w == LL_I32 ? (int64_t)((const int32_t*)p)[i] : ((const int64_t*)p)[i];
 }
-extern "C" int ll_moe_gemm(void*, const void*, const void*, const float*, const void*, const int32_t*,
-                           const int32_t*, const int32_t*, int64_t, int64_t, int, int64_t, int64_t, int,
-                           int, int, int, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
-                           int, void*) {
-  return LL_ERR_ARG;
+
+// ---------------------------------------------------------------------------------- //
+// moe_align_block_size: one workgroup, no host sync.  Thread e owns expert e (loops when
+// E > 1024): count, padded prefix, then a stable in-order placement scan.
+// ---------------------------------------------------------------------------------- //
+__global__ __launch_bounds__(1024) void moe_align_kernel(const void* __restrict__ topk_ids, int ids_w,
+                                                         int num_slots, int num_experts, int block_size,
+                                                         int32_t* __restrict__ sorted_ids,
+                                                         int32_t* __restrict__ expert_ids,
+                                                         int32_t* __restrict__ num_post, int max_padded,
+                                                         int max_blocks) {
+  extern __shared__ int sm[];  // counts[E], starts[E], block_ends[E]
+  int* counts = sm;
+  int* starts = sm + num_experts;
+  int* bends = sm + 2 * num_experts;
+  const int tid = threadIdx.x;
+  for (int i = tid; i < max_padded; i += 1024) sorted_ids[i] = num_slots;  // sentinel
+  for (int e = tid; e < num_experts; e += 1024) counts[e] = 0;
+  __syncthreads();
+  for (int i = tid; i < num_slots; i += 1024) atomicAdd(&counts[(int)moe_load_idx(topk_ids, i, ids_w)], 1);
+  __syncthreads();
+  if (tid == 0) {
+    int pos = 0, blk = 0;
+    for (int e = 0; e < num_experts; ++e) {
+      const int padded = (counts[e] + block_size - 1) / block_size * block_size;
+      starts[e] = pos;
+      pos += padded;
+      blk += padded / block_size;
+      bends[e] = blk;
+    }
+    num_post[0] = pos;
+  }
+  __syncthreads();
+  // stable placement: expert e walks the slots in order (keeps token order inside each expert)
+  for (int e = tid; e < num_experts; e += 1024) {
+    if (counts[e] == 0) continue;
+    int dst = starts[e];
+    for (int i = 0; i < num_slots; ++i)
+      if ((int)moe_load_idx(topk_ids, i, ids_w) == e) sorted_ids[dst++] = i;
+  }
+  // expert_ids[b] = searchsorted(block_ends, b, right=True) clamped to E-1
+  for (int b = tid; b < max_blocks; b += 1024) {
+    int lo = 0, hi = num_experts;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (bends[mid] <= b) lo = mid + 1; else hi = mid;
+    }
+    expert_ids[b] = lo < num_experts - 1 ? lo : num_experts - 1;
+  }
+}
+
+extern "C" int ll_moe_align_block_size(const void* topk_ids, int ids_width, int64_t num_slots, int num_experts,
+                                       int block_size, int32_t* sorted_ids, int32_t* expert_ids,
+                                       int32_t* num_post, void* stream) {
+  if (ids_width != LL_I32 && ids_width != LL_I64) return LL_ERR_DTYPE;
+  if (num_slots < 0 || num_experts <= 0 || block_size <= 0 || num_experts > 8192) return LL_ERR_SHAPE;
+  const int max_padded = (int)num_slots + num_experts * (block_size - 1);
+  const int max_blocks = (max_padded + block_size - 1) / block_size;
+  moe_align_kernel<<<1, 1024, 3 * num_experts * sizeof(int), (hipStream_t)stream>>>(
+      topk_ids, ids_width, (int)num_slots, num_experts, block_size, sorted_ids, expert_ids, num_post, max_padded,
+      max_blocks);
+  return LL_LAUNCH_CHECK();
+}
+
+// ---------------------------------------------------------------------------------- //
+// grouped GEMM
+// ---------------------------------------------------------------------------------- //
+__device__ __forceinline__ uint32_t mpk_mul(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) * __builtin_bit_cast(f16x2, b));
+}
+__device__ __forceinline__ uint32_t mpk_add(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) + __builtin_bit_cast(f16x2, b));
+}
+__device__ __forceinline__ uint32_t mpk_bcast(float v) {
+  const uint32_t h = f32_to_f16_bits(v);
+  return h | (h << 16);
+}
+__device__ __forceinline__ void mdq_i8(uint32_t w, uint32_t s, uint32_t& o0, uint32_t& o1) {
+  const uint32_t u = w ^ 0x80808080u;
+  o0 = mpk_mul(mpk_add(__builtin_amdgcn_perm(0x64646464u, u, 0x04010400u), 0xE480E480u), s);
+  o1 = mpk_mul(mpk_add(__builtin_amdgcn_perm(0x64646464u, u, 0x04030402u), 0xE480E480u), s);
+}
+__device__ __forceinline__ void mdq_fp8(uint32_t w, uint32_t s256, uint32_t& o0, uint32_t& o1) {
+  uint32_t p0 = __builtin_amdgcn_perm(0u, w, 0x010C000Cu);
+  uint32_t p1 = __builtin_amdgcn_perm(0u, w, 0x030C020Cu);
+  p0 = (p0 & 0x80008000u) | ((p0 >> 1) & 0x3F803F80u);  // fused_moe.py:191-201 (same bit trick)
+  p1 = (p1 & 0x80008000u) | ((p1 >> 1) & 0x3F803F80u);
+  o0 = mpk_mul(p0, s256);
+  o1 = mpk_mul(p1, s256);
+}
+
+struct MoeParams {
+  uint16_t* c;            // [num_slots, N]
+  const uint16_t* a;      // [tokens or slots, K]
+  const void* w;          // [E, N, K] fp16 / uint8 / int8
+  const float* w_scale;   // [E, ceil(N/gn), ceil(K/gk)] or null
+  const uint16_t* topk_w; // [num_slots] in the activation dtype
+  const int32_t* sorted_ids;
+  const int32_t* expert_ids;
+  const int32_t* num_post;
+  int64_t num_slots, n, k;
+  int block_m, top_k, mul_w, group_n;
+  int64_t group_k;
+  int64_t a_stride, w_stride_e, w_stride_n, s_stride_e, s_stride_n, s_stride_k;
+};
+
+// grid = (ceil(N/128), EM / block_m), block = 256.  WFMT: LL_W_F16 / LL_W_FP8E4M3 / LL_W_INT8.
+// ADT: activation dtype (LL_F16 only on the MFMA f16 path; bf16 activations use the bf16 MFMA).
+template <int WFMT, int MT>
+__global__ __launch_bounds__(256) void moe_gemm_kernel(const MoeParams p) {
+  constexpr int A_ROW_BYTES = 256 + 16;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[MT * 32 * A_ROW_BYTES];
+  __shared__ int32_t row_slot[MT * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nl = lane & 31, h = lane >> 5;
+  const int pid_m = blockIdx.y;
+  if ((int64_t)pid_m * p.block_m >= p.num_post[0]) return;  // fused_moe.py:160-162
+  const int expert = p.expert_ids[pid_m];
+  if (tid < MT * 32) {
+    const int32_t s = tid < p.block_m ? p.sorted_ids[(int64_t)pid_m * p.block_m + tid] : (int32_t)p.num_slots;
+    row_slot[tid] = s;
+  }
+  __syncthreads();
+
+  const int64_t n0 = (int64_t)blockIdx.x * 128 + wv * 32;
+  int64_t nrow = n0 + nl;
+  if (nrow >= p.n) nrow = p.n - 1;
+  const int K = (int)p.k;
+  constexpr int EB = (WFMT == LL_W_F16) ? 2 : 1;  // bytes per weight element
+  const unsigned char* wrow = (const unsigned char*)p.w + ((int64_t)expert * p.w_stride_e + nrow * p.w_stride_n) * EB;
+  const float* srow = p.w_scale ? p.w_scale + (int64_t)expert * p.s_stride_e + (nrow / p.group_n) * p.s_stride_n : nullptr;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  // activation staging: thread (row = tid/8, seg = tid%8): 16 k = 32 B ... 32*MT rows x 128 k
+  const int chunks = (K + 127) / 128;
+  for (int c = 0; c < chunks; ++c) {
+    __syncthreads();
+    for (int i = tid; i < MT * 32 * 16; i += 256) {
+      const int row = i >> 4, q = i & 15;
+      const int kk = c * 128 + q * 8;
+      const int32_t slot = row_slot[row];
+      Q4 v = Q4{0, 0, 0, 0};
+      if (slot < p.num_slots && kk < K)
+        v = *reinterpret_cast<const Q4*>(p.a + (int64_t)(slot / p.top_k) * p.a_stride + kk);
+      *reinterpret_cast<Q4*>(lds + row * A_ROW_BYTES + q * 16) = v;
+    }
+    __syncthreads();
+    const int kbase = c * 128 + h * 64;
+    uint32_t sp = 0;
+    if constexpr (WFMT != LL_W_F16) {
+      const int kq = kbase < K ? kbase : K - 1;
+      const float sv = srow[(int64_t)(kq / p.group_k) * p.s_stride_k];
+      sp = mpk_bcast(WFMT == LL_W_FP8E4M3 ? sv * 256.0f : sv);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      const int kk = kbase + s * 8;
+      Q4 wf = Q4{0, 0, 0, 0};
+      if (kk < K) {
+        if constexpr (WFMT == LL_W_F16) {
+          wf = *reinterpret_cast<const Q4*>(wrow + (int64_t)kk * 2);
+        } else {
+          const uint2 raw = *reinterpret_cast<const uint2*>(wrow + kk);
+          if constexpr (WFMT == LL_W_FP8E4M3) {
+            mdq_fp8(raw.x, sp, wf.x, wf.y);
+            mdq_fp8(raw.y, sp, wf.z, wf.w);
+          } else {
+            mdq_i8(raw.x, sp, wf.x, wf.y);
+            mdq_i8(raw.y, sp, wf.z, wf.w);
+          }
+        }
+      }
+      const f16x8 wfrag = __builtin_bit_cast(f16x8, wf);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f16x8 afrag = *reinterpret_cast<const f16x8*>(lds + (mt * 32 + nl) * A_ROW_BYTES + h * 128 + s * 16);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, afrag, acc[mt], 0, 0, 0);
+      }
+    }
+  }
+
+  // epilogue: D[n][m]: lane = row-block column m (nl), rows n = 8g + 4h + e
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 32 + nl;
+    const int32_t slot = row_slot[m];
+    if (m >= p.block_m || slot >= p.num_slots) continue;
+    float rw = 1.f;
+    if (p.mul_w) rw = f16_bits_to_f32(p.topk_w[slot]);  // router weight multiplies in fp32 (:203-205)
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t nn = (int64_t)blockIdx.x * 128 + wv * 32 + 8 * g + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (nn + e < p.n) p.c[(int64_t)slot * p.n + nn + e] = f32_to_f16_bits(acc[mt][4 * g + e] * rw);
+    }
+  }
+}
+
+extern "C" int ll_moe_gemm(void* c, const void* a, const void* w, const float* w_scale, const void* topk_w,
+                           const int32_t* sorted_ids, const int32_t* expert_ids, const int32_t* num_post,
+                           int64_t num_slots, int64_t em, int block_m, int64_t n, int64_t k, int top_k,
+                           int mul_routed_weight, int wfmt, int group_n, int64_t group_k, int64_t a_stride_m,
+                           int64_t w_stride_e, int64_t w_stride_n, int64_t s_stride_e, int64_t s_stride_n,
+                           int64_t s_stride_k, int dtype, void* stream) {
+  if (dtype != LL_F16) return LL_ERR_DTYPE;  // the reference MoE path is fp16 end to end
+  if (wfmt != LL_W_F16 && wfmt != LL_W_FP8E4M3 && wfmt != LL_W_INT8) return LL_ERR_DTYPE;
+  if (block_m != 16 && block_m != 32 && block_m != 64) return LL_ERR_SHAPE;
+  if (n <= 0 || k <= 0 || top_k <= 0 || k % 8 != 0 || a_stride_m % 8 != 0) return LL_ERR_SHAPE;
+  if (wfmt != LL_W_F16 && (!w_scale || group_n <= 0 || group_k <= 0)) return LL_ERR_ARG;
+  if (wfmt == LL_W_F16 ? (w_stride_n % 8 != 0) : (w_stride_n % 8 != 0)) return LL_ERR_SHAPE;
+  if (num_slots == 0) return LL_OK;
+  MoeParams p{};
+  p.c = (uint16_t*)c; p.a = (const uint16_t*)a; p.w = w; p.w_scale = w_scale; p.topk_w = (const uint16_t*)topk_w;
+  p.sorted_ids = sorted_ids; p.expert_ids = expert_ids; p.num_post = num_post;
+  p.num_slots = num_slots; p.n = n; p.k = k; p.block_m = block_m; p.top_k = top_k; p.mul_w = mul_routed_weight;
+  p.group_n = group_n > 0 ? group_n : 1; p.group_k = group_k > 0 ? group_k : 1;
+  p.a_stride = a_stride_m; p.w_stride_e = w_stride_e; p.w_stride_n = w_stride_n;
+  p.s_stride_e = s_stride_e; p.s_stride_n = s_stride_n; p.s_stride_k = s_stride_k;
+  dim3 grid((unsigned)((n + 127) / 128), (unsigned)((em + block_m - 1) / block_m));
+  hipStream_t st = (hipStream_t)stream;
+#define LL_MOE(WF)                                                    \
+  if (block_m == 64) moe_gemm_kernel<WF, 2><<<grid, 256, 0, st>>>(p); \
+  else moe_gemm_kernel<WF, 1><<<grid, 256, 0, st>>>(p)
+  if (wfmt == LL_W_F16) { LL_MOE(LL_W_F16); }
+  else if (wfmt == LL_W_FP8E4M3) { LL_MOE(LL_W_FP8E4M3); }
+  else { LL_MOE(LL_W_INT8); }
+#undef LL_MOE
+  return LL_LAUNCH_CHECK();
 }

@@ -1,8 +1,208 @@
-// placeholder, replaced below in this round
+// flash_attention2_no_pad (a6) -- reference lite_llama/kernels/flashattention2_nopad.py:45-231.
+// Varlen causal prefill over the freshly projected q/k/v (not the cache): exp2 softmax
+// (sm_scale carries log2 e), masked score -1.0e8, P rounded to the storage dtype before PV,
+// fp32 accumulators, rows past b_seq_len are not written.
+//
+// Same MFMA formulation as the decode kernel: one wave owns 16 consecutive query rows of one
+// (sequence, head); S^T = K.Q^T puts keys in MFMA rows and queries in columns, so the online
+// softmax is lane-local per query, and the S^T accumulators are directly the P^T B-operand of
+// O^T = V^T.P^T.  K fragments come straight from global memory (L2-shared between the waves
+// of a head), V is staged per 32-key tile through LDS to be read key-major.
 #include "common.h"
-extern "C" int ll_flash_attention_nopad(void*, const void*, const void*, const void*, const void*,
-                                        const void*, int, int, int, int, int64_t, float, int64_t,
-                                        int64_t, int64_t, int64_t, int64_t, int64_t, int64_t, int64_t,
-                                        int, int, int, void*) {
-  return LL_ERR_ARG;
+
+typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
+
+struct alignas(16) Q4 {
+  uint32_t x, y, z, w;
+};
+
+template <int DT>
+__device__ __forceinline__ f32x4 mfma16(const Q4& a, const Q4& b, f32x4 c) {
+  if constexpr (DT == LL_F16)
+    return __builtin_amdgcn_mfma_f32_16x16x32_f16(__builtin_bit_cast(f16x8, a),
+                                                  __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_16x16x32_bf16(__builtin_bit_cast(bf16x8, a),
+                                                   __builtin_bit_cast(bf16x8, b), c, 0, 0, 0);
+}
+
+template <int DT>
+__device__ __forceinline__ uint32_t pack2(float lo, float hi) {
+  return (uint32_t)from_f32<DT>(lo) | ((uint32_t)from_f32<DT>(hi) << 16);
+}
+
+__device__ __forceinline__ int64_t pa_load_idx(const void* p, int64_t i, int w) {
+  return w == LL_I32 ? (int64_t)((const int32_t*)p)[i] : ((const int64_t*)p)[i];
+}
+
+// grid = (ceil(max_seq_len / 16), hq, batch), block = 64 (one wave)
+template <int DT, int D>
+__global__ __launch_bounds__(64) void fa_prefill(
+    uint16_t* __restrict__ out, const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+    const uint16_t* __restrict__ v, const void* __restrict__ b_start_loc, const void* __restrict__ b_seq_len,
+    int hq, int hkv, float sm_scale, int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh, int64_t v_st,
+    int64_t v_sh, int64_t o_st, int64_t o_sh, int start_w, int seq_w) {
+  constexpr int NS = D / 32, DQ = D / 4, NT = D / 16, VSTR = D + 8;
+  __shared__ __attribute__((aligned(16))) uint16_t lds_v[32 * VSTR];
+
+  const int lane = threadIdx.x;
+  const int t = lane & 15, c = lane >> 4;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int kvh = head / (hq / hkv);
+  const int64_t seq_len = pa_load_idx(b_seq_len, b, seq_w);
+  const int64_t start = pa_load_idx(b_start_loc, b, start_w);
+  const int64_t q0 = (int64_t)blockIdx.x * 16;
+  if (q0 >= seq_len) return;
+
+  // Q^T fragments: lane (query t, group c); rows past the sequence end read row seq_len-1
+  // (never stored)
+  const int64_t qrow = (q0 + t < seq_len) ? q0 + t : seq_len - 1;
+  Q4 qf[NS];
+#pragma unroll
+  for (int s = 0; s < NS; ++s)
+    qf[s] = *reinterpret_cast<const Q4*>(q + (start + qrow) * q_st + (int64_t)head * q_sh + c * DQ + s * 8);
+
+  float m_i = -INFINITY, d_i = 0.f;
+  f32x4 ot[NT];
+#pragma unroll
+  for (int i = 0; i < NT; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int64_t kend = (q0 + 16 < seq_len) ? q0 + 16 : seq_len;  // causal: keys < min(q0 + 16, seq_len)
+  for (int64_t p0 = 0; p0 < kend; p0 += 32) {
+    const int64_t ka_i = p0 + t, kb_i = p0 + 16 + t;
+    const bool okA = ka_i < kend, okB = kb_i < kend;
+    const int64_t ra = start + (okA ? ka_i : 0), rb = start + (okB ? kb_i : 0);
+    const uint16_t* kA = k + ra * k_st + (int64_t)kvh * k_sh + c * DQ;
+    const uint16_t* kB = k + rb * k_st + (int64_t)kvh * k_sh + c * DQ;
+    const uint16_t* vA = v + ra * v_st + (int64_t)kvh * v_sh + c * DQ;
+    const uint16_t* vB = v + rb * v_st + (int64_t)kvh * v_sh + c * DQ;
+    Q4 ka[NS], kb[NS], va[NS], vb[NS];
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      ka[s] = *reinterpret_cast<const Q4*>(kA + s * 8);
+      kb[s] = *reinterpret_cast<const Q4*>(kB + s * 8);
+      va[s] = *reinterpret_cast<const Q4*>(vA + s * 8);
+      vb[s] = *reinterpret_cast<const Q4*>(vB + s * 8);
+    }
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sa = mfma16<DT>(ka[s], qf[s], sa);
+#pragma unroll
+    for (int s = 0; s < NS; ++s) sb = mfma16<DT>(kb[s], qf[s], sb);
+
+    // rows = keys p0 + 4c + r (+16), col = query q0 + t
+    const int64_t qi = q0 + t;
+    float sc[8];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int64_t k0i = p0 + 4 * c + r, k1i = p0 + 16 + 4 * c + r;
+      // reference: where(causal, qk * sm_scale, -1.0e8); keys past the block end are causal-masked too
+      sc[r] = (k0i <= qi && k0i < kend) ? sa[r] * sm_scale : -1.0e8f;
+      sc[4 + r] = (k1i <= qi && k1i < kend) ? sb[r] * sm_scale : -1.0e8f;
+      mx = fmaxf(mx, fmaxf(sc[r], sc[4 + r]));
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
+    const float m_new = fmaxf(m_i, mx);
+    const float alpha = exp2f(m_i - m_new);
+    float p[8];
+    float ps = 0.f;
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      p[j] = exp2f(sc[j] - m_new);
+      ps += p[j];
+    }
+    ps += __shfl_xor(ps, 16, 64);
+    ps += __shfl_xor(ps, 32, 64);
+    d_i = d_i * alpha + ps;
+    m_i = m_new;
+    Q4 pf;
+    pf.x = pack2<DT>(p[0], p[1]);
+    pf.y = pack2<DT>(p[2], p[3]);
+    pf.z = pack2<DT>(p[4], p[5]);
+    pf.w = pack2<DT>(p[6], p[7]);
+
+    __syncthreads();
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      *reinterpret_cast<Q4*>(&lds_v[t * VSTR + c * DQ + s * 8]) = okA ? va[s] : Q4{0, 0, 0, 0};
+      *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + c * DQ + s * 8]) = okB ? vb[s] : Q4{0, 0, 0, 0};
+    }
+    __syncthreads();
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) {
+      uint32_t w[4];
+#pragma unroll
+      for (int jj = 0; jj < 4; ++jj) {
+        const int j0 = 2 * jj, j1 = 2 * jj + 1;
+        const int r0 = 16 * (j0 >> 2) + 4 * c + (j0 & 3);
+        const int r1 = 16 * (j1 >> 2) + 4 * c + (j1 & 3);
+        const uint32_t lo = lds_v[r0 * VSTR + dt * 16 + t];
+        const uint32_t hi = lds_v[r1 * VSTR + dt * 16 + t];
+        w[jj] = lo | (hi << 16);
+      }
+      const Q4 vf = {w[0], w[1], w[2], w[3]};
+      f32x4 acc = ot[dt];
+      acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
+      ot[dt] = mfma16<DT>(vf, pf, acc);
+    }
+  }
+
+  if (q0 + t < seq_len) {
+    const float inv = 1.0f / d_i;
+    uint16_t* o = out + (start + q0 + t) * o_st + (int64_t)head * o_sh;
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) {
+      uint2 pk;
+      pk.x = pack2<DT>(ot[dt][0] * inv, ot[dt][1] * inv);
+      pk.y = pack2<DT>(ot[dt][2] * inv, ot[dt][3] * inv);
+      *reinterpret_cast<uint2*>(o + dt * 16 + 4 * c) = pk;
+    }
+  }
+}
+
+template <int DT>
+static int launch_fa(void* out, const void* q, const void* k, const void* v, const void* start, const void* seq,
+                     int batch, int hq, int hkv, int d, int64_t max_seq_len, float sm_scale, int64_t q_st,
+                     int64_t q_sh, int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh, int64_t o_st,
+                     int64_t o_sh, int start_w, int seq_w, hipStream_t st) {
+  dim3 grid((unsigned)((max_seq_len + 15) / 16), (unsigned)hq, (unsigned)batch);
+#define LL_FA(DD)                                                                                        \
+  fa_prefill<DT, DD><<<grid, 64, 0, st>>>((uint16_t*)out, (const uint16_t*)q, (const uint16_t*)k,        \
+                                          (const uint16_t*)v, start, seq, hq, hkv, sm_scale, q_st, q_sh, \
+                                          k_st, k_sh, v_st, v_sh, o_st, o_sh, start_w, seq_w)
+  switch (d) {
+    case 32: LL_FA(32); break;
+    case 64: LL_FA(64); break;
+    case 128: LL_FA(128); break;
+    case 256: LL_FA(256); break;
+    default: return LL_ERR_SHAPE;
+  }
+#undef LL_FA
+  return LL_LAUNCH_CHECK();
+}
+
+extern "C" int ll_flash_attention_nopad(void* out, const void* q, const void* k, const void* v,
+                                        const void* b_start_loc, const void* b_seq_len, int batch, int hq,
+                                        int hkv, int d, int64_t max_seq_len, float sm_scale, int64_t q_stride_t,
+                                        int64_t q_stride_h, int64_t k_stride_t, int64_t k_stride_h,
+                                        int64_t v_stride_t, int64_t v_stride_h, int64_t o_stride_t,
+                                        int64_t o_stride_h, int dtype, int start_width, int seq_width,
+                                        void* stream) {
+  if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if ((start_width | seq_width) & ~1) return LL_ERR_DTYPE;
+  if (batch < 0 || hq <= 0 || hkv <= 0 || hq % hkv != 0 || max_seq_len < 0) return LL_ERR_SHAPE;
+  if (batch == 0 || max_seq_len == 0) return LL_OK;
+  if ((q_stride_t | q_stride_h | k_stride_t | k_stride_h | v_stride_t | v_stride_h | o_stride_t | o_stride_h) % 8 != 0 ||
+      !ll_aligned16(q) || !ll_aligned16(k) || !ll_aligned16(v) || !ll_aligned16(out))
+    return LL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LL_F16)
+    return launch_fa<LL_F16>(out, q, k, v, b_start_loc, b_seq_len, batch, hq, hkv, d, max_seq_len, sm_scale,
+                             q_stride_t, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_t,
+                             o_stride_h, start_width, seq_width, st);
+  return launch_fa<LL_BF16>(out, q, k, v, b_start_loc, b_seq_len, batch, hq, hkv, d, max_seq_len, sm_scale,
+                            q_stride_t, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_t,
+                            o_stride_h, start_width, seq_width, st);
 }

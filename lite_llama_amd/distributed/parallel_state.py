@@ -1,0 +1,120 @@
+"""Rank grid + the tensor-parallel collectives of the hot path -- mirror of
+lite_llama/distributed/parallel_state.py:44-230.
+
+One process per GPU; ``global_rank = dp_rank * tp_size + tp_rank`` (TP ranks contiguous); the
+only data-path collective is the in-place SUM all-reduce of the ``[tokens, hidden]`` partial
+sums after every row-parallel projection (2 per decoder layer).  Backend ``"nccl"`` IS RCCL on
+ROCm (ring/tree over xGMI); on a CPU-only host (tests) the same code runs on ``gloo``.
+"""
+
+from __future__ import annotations
+
+import os
+
+import torch
+import torch.distributed as dist
+
+_TP_RANK = 0
+_TP_WORLD_SIZE = 1
+_TP_GROUP = None
+_DP_RANK = 0
+_DP_WORLD_SIZE = 1
+_OWNS_PG = False
+
+
+def grid_coordinates(global_rank: int, tp_size: int, dp_size: int) -> tuple[int, int]:
+    """``global_rank -> (dp_rank, tp_rank)`` for the layout ``dp_rank * tp_size + tp_rank``."""
+    if tp_size < 1 or dp_size < 1:
+        raise ValueError(f"tp_size and dp_size must be >= 1, got {tp_size} and {dp_size}")
+    world = tp_size * dp_size
+    if not 0 <= global_rank < world:
+        raise ValueError(f"global_rank {global_rank} is outside a {dp_size}x{tp_size} grid of {world} ranks")
+    return global_rank // tp_size, global_rank % tp_size
+
+
+def _backend() -> str:
+    return "nccl" if torch.cuda.is_available() else "gloo"
+
+
+def init_parallel(global_rank: int = 0, tp_size: int = 1, dp_size: int = 1, master_port: int = 29500) -> None:
+    """Place this process in the ``dp_size x tp_size`` grid; creates one TP group per replica.
+    Blocks in the rendezvous until all ranks joined when ``tp_size > 1``."""
+    global _TP_RANK, _TP_WORLD_SIZE, _TP_GROUP, _DP_RANK, _DP_WORLD_SIZE, _OWNS_PG
+    _DP_RANK, _TP_RANK = grid_coordinates(global_rank, tp_size, dp_size)
+    _DP_WORLD_SIZE = dp_size
+    _TP_WORLD_SIZE = tp_size
+    if tp_size <= 1:
+        return
+    world = tp_size * dp_size
+    os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    os.environ.setdefault("MASTER_PORT", str(master_port))
+    if not dist.is_initialized():
+        kw = {}
+        if torch.cuda.is_available():
+            kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
+        dist.init_process_group(backend=_backend(), rank=global_rank, world_size=world, **kw)
+        _OWNS_PG = True
+    # every rank creates every group, in the same order (new_group is itself a collective)
+    for replica in range(dp_size):
+        members = list(range(replica * tp_size, (replica + 1) * tp_size))
+        group = dist.new_group(members, backend=_backend())
+        if replica == _DP_RANK:
+            _TP_GROUP = group
+
+
+def init_tensor_parallel(rank: int = 0, world_size: int = 1, master_port: int = 29500) -> None:
+    init_parallel(global_rank=rank, tp_size=world_size, dp_size=1, master_port=master_port)
+
+
+def destroy_parallel() -> None:
+    global _TP_RANK, _TP_WORLD_SIZE, _TP_GROUP, _DP_RANK, _DP_WORLD_SIZE, _OWNS_PG
+    if _TP_GROUP is not None and _OWNS_PG and dist.is_initialized():
+        dist.destroy_process_group()
+    _TP_RANK, _TP_WORLD_SIZE, _TP_GROUP, _DP_RANK, _DP_WORLD_SIZE, _OWNS_PG = 0, 1, None, 0, 1, False
+
+
+destroy_tensor_parallel = destroy_parallel
+
+
+def get_tp_rank() -> int:
+    return _TP_RANK
+
+
+def get_tp_world_size() -> int:
+    return _TP_WORLD_SIZE
+
+
+def get_dp_rank() -> int:
+    return _DP_RANK
+
+
+def get_dp_world_size() -> int:
+    return _DP_WORLD_SIZE
+
+
+def get_world_size() -> int:
+    return _DP_WORLD_SIZE * _TP_WORLD_SIZE
+
+
+def divide(a: int, b: int, what: str = "") -> int:
+    if a % b != 0:
+        raise ValueError(f"{what or 'value'} {a} does not divide across {b} tensor-parallel ranks")
+    return a // b
+
+
+def all_reduce_tp(tensor: torch.Tensor) -> torch.Tensor:
+    """In-place SUM over the TP group; identity when ``world_size == 1``."""
+    if _TP_WORLD_SIZE <= 1:
+        return tensor
+    dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=_TP_GROUP)
+    return tensor
+
+
+def all_reduce_min(value: int) -> int:
+    """Smallest ``value`` across the TP group (agreeing on a KV pool size, model_runner.py:84-89)."""
+    if _TP_WORLD_SIZE <= 1:
+        return value
+    device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
+    t = torch.tensor([value], dtype=torch.int64, device=device)
+    dist.all_reduce(t, op=dist.ReduceOp.MIN, group=_TP_GROUP)
+    return int(t.item())

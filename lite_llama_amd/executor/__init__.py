@@ -1,0 +1,222 @@
+"""Decode-step driver: per-step metadata, the token-attention KV pool and the hipGraph-captured
+decode step.  Counterpart of lite_llama/executor/{attention_metadata.py:19-44,
+kv_cache_manager.py:197-299, model_runner.py:153-218,310-330, cuda_graph.py:54-249} and of the
+one-shot decode loop engine/llm_engine.py:137-213 (greedy, no EOS stop, lockstep batch).
+
+MI355X-first differences from the reference (extensions, not parity changes):
+  * the WHOLE step -- forward, greedy argmax, KV-row bump, ``b_seq_len += 1``,
+    ``update_kv_index`` and feeding the sampled token back -- is captured in one hipGraph, so a
+    decode step is a single ``hipGraphLaunch`` with no host work in between (the reference
+    replays only the forward and does 5 host-issued copies + sampler + index update per step);
+  * the graph is also captured under tensor parallelism (RCCL all-reduces are capturable);
+    the reference disables graphs for TP>1 (model_runner.py:260-266).
+"""
+
+from __future__ import annotations
+
+from dataclasses import dataclass, field
+
+import torch
+
+from ..kernels import update_kv_index
+from ..sampling import greedy_argmax
+
+
+@dataclass
+class AttentionMetadata:
+    """The struct every attention kernel call reads (same field names as the reference)."""
+
+    kv_buffer: list = field(default_factory=list)        # per layer [max_tokens, 2*Hkv, D]
+    cur_select_index: torch.Tensor | None = None          # rows written this step (int32)
+    b_req_tokens_table: torch.Tensor | None = None        # [max_requests, max_seq_len] int32
+    b_start_loc: torch.Tensor | None = None               # prefill only
+    b_req_idx: torch.Tensor | None = None
+    b_seq_len: torch.Tensor | None = None
+    max_actual_seq_len: int = 0
+
+
+class KVPool:
+    """Token-granular KV pool: one ``[max_tokens, 2*Hkv, D]`` fp16 tensor per layer (K heads first),
+    with the reference's contiguous bump allocator (kv_cache_manager.py:197-216,286-292)."""
+
+    def __init__(self, num_layers: int, max_tokens: int, num_kv_heads: int, head_dim: int, device,
+                 dtype=torch.float16):
+        self.max_tokens = max_tokens
+        self.device = device
+        self.kv_buffer = [torch.zeros(max_tokens, 2 * num_kv_heads, head_dim, dtype=dtype, device=device)
+                          for _ in range(num_layers)]
+        self._next = 0
+
+    def alloc(self, n: int) -> torch.Tensor:
+        if self._next + n > self.max_tokens:
+            raise RuntimeError(f"KV pool exhausted: need {n} rows, {self.max_tokens - self._next} free")
+        idx = torch.arange(self._next, self._next + n, dtype=torch.int32, device=self.device)
+        self._next += n
+        return idx
+
+    def reset(self) -> None:
+        self._next = 0
+
+    @property
+    def used(self) -> int:
+        return self._next
+
+
+class DecodeEngine:
+    """One-shot batch generation: padded-grid prefill, then lockstep greedy decode.
+
+    ``prefill`` mirrors ModelRunner.prefill_alloc_kv_cache/_init_req_tokens_table
+    (model_runner.py:153-198): the ``[batch, max_prompt_len]`` grid is flattened row-major,
+    ``b_start_loc[i] = i * max_prompt_len``; ``decode`` mirrors decode_alloc_kv_cache (:200-218):
+    after every forward the next B rows are bump-allocated, ``b_seq_len += 1`` and the table is
+    updated, so at ``flash_decoding`` time ``b_seq_len`` already counts the token being fed.
+    """
+
+    def __init__(self, model, max_batch: int, max_seq_len: int, device="cuda", kv_dtype=torch.float16):
+        geo = model.geo
+        self.model = model
+        self.device = device
+        self.max_batch = max_batch
+        self.max_seq_len = max_seq_len
+        at0 = model.layers[0].self_attn
+        self.pool = KVPool(geo.num_layers, max_batch * max_seq_len, at0.num_kv_heads, geo.head_dim, device, kv_dtype)
+        self.info = AttentionMetadata(kv_buffer=self.pool.kv_buffer)
+        self.info.b_req_tokens_table = torch.zeros(max_batch, max_seq_len, dtype=torch.int32, device=device)
+        self._graph = None
+        self._graph_key = None
+
+    # ------------------------------------------------------------------ prefill ----- #
+    @torch.no_grad()
+    def prefill(self, prompt_ids: torch.Tensor, prompt_lens: torch.Tensor | None = None) -> torch.Tensor:
+        """``prompt_ids [B, Lp]`` (right-padded) -> greedy next token per row ``[B]``."""
+        b, lp = prompt_ids.shape
+        dev = self.device
+        self.pool.reset()
+        if prompt_lens is None:
+            prompt_lens = torch.full((b,), lp, dtype=torch.int32, device=dev)
+        info = self.info
+        info.b_req_idx = torch.arange(b, dtype=torch.int32, device=dev)
+        info.cur_select_index = self.pool.alloc(b * lp)
+        info.b_seq_len = prompt_lens.to(torch.int32).clone()
+        info.max_actual_seq_len = lp
+        info.b_start_loc = torch.arange(b, dtype=torch.int32, device=dev) * lp
+        # table[i, j] = row of token j of sequence i on the padded grid (pad rows included:
+        # they are overwritten by the sequence's own decode steps, slot_batch.py:104-110)
+        info.b_req_tokens_table[:b, :lp] = info.cur_select_index.view(b, lp)
+        position_ids = torch.arange(lp, device=dev).unsqueeze(0).expand(b, lp)
+        rows = torch.arange(b, device=dev) * lp + (prompt_lens.long() - 1)
+        last = self.model(prompt_ids, position_ids, info, logits_rows=rows)
+        self._positions = prompt_lens.long().clone().view(b, 1)
+        self._batch = b
+        return greedy_argmax(last)
+
+    @torch.no_grad()
+    def synthetic_context(self, batch: int, ctx_len: int, seed: int = 0) -> torch.Tensor:
+        """Benchmark helper: instead of running a prefill, fill the first ``ctx_len`` cache rows of
+        every sequence with seeded random K/V (synthetic data of the prefill's shape) and return
+        random first tokens.  Metadata ends up exactly as after ``prefill``."""
+        dev = self.device
+        self.pool.reset()
+        info = self.info
+        g = torch.Generator(device=dev)
+        g.manual_seed(seed)
+        info.b_req_idx = torch.arange(batch, dtype=torch.int32, device=dev)
+        rows = self.pool.alloc(batch * ctx_len)
+        info.b_req_tokens_table[:batch, :ctx_len] = rows.view(batch, ctx_len)
+        for kv in self.pool.kv_buffer:
+            kv[: batch * ctx_len].copy_(
+                (torch.randn(batch * ctx_len, kv.shape[1], kv.shape[2], generator=g, device=dev) * 0.5).to(kv.dtype))
+        info.b_seq_len = torch.full((batch,), ctx_len, dtype=torch.int32, device=dev)
+        info.max_actual_seq_len = ctx_len
+        self._positions = torch.full((batch, 1), ctx_len, dtype=torch.long, device=dev)
+        self._batch = batch
+        return torch.randint(0, self.model.geo.vocab_size, (batch,), generator=g, device=dev)
+
+    # ------------------------------------------------------------------ decode ------ #
+    def _begin_decode(self, first_tokens: torch.Tensor, max_new_tokens: int):
+        b, dev, info = self._batch, self.device, self.info
+        # decode_alloc_kv_cache for the first decode step
+        info.cur_select_index = self.pool.alloc(b)
+        info.b_seq_len = info.b_seq_len + 1
+        info.max_actual_seq_len += 1
+        update_kv_index(info.b_req_tokens_table, info.b_req_idx, info.b_seq_len, info.cur_select_index)
+        # reserve the rows of all remaining steps now: the bump allocator hands out the next B
+        # rows each step, which the graph reproduces on device as ``cur_select_index += B``
+        if max_new_tokens > 1:
+            self.pool.alloc(b * (max_new_tokens - 1))
+        self._input_ids = first_tokens.view(b, 1).clone()
+        self._out = torch.zeros(b, max_new_tokens, dtype=torch.long, device=dev)
+        self._step = torch.zeros(1, dtype=torch.long, device=dev)
+        self._row_base = torch.arange(b, device=dev) * max_new_tokens
+
+    def _step_body(self):
+        """forward -> greedy sample -> record -> advance metadata (all on device)."""
+        info, b = self.info, self._batch
+        logits = self.model(self._input_ids, self._positions, info)
+        nxt = greedy_argmax(logits[:, -1, :])
+        self._out.view(-1).scatter_(0, self._row_base + self._step, nxt)
+        self._step += 1
+        self._input_ids.copy_(nxt.view(b, 1))
+        self._positions += 1
+        info.cur_select_index += b
+        info.b_seq_len += 1
+        update_kv_index(info.b_req_tokens_table, info.b_req_idx, info.b_seq_len, info.cur_select_index)
+
+    @torch.no_grad()
+    def decode(self, first_tokens: torch.Tensor, max_new_tokens: int, use_graph: bool = True,
+               warmup_steps: int = 0, on_step=None) -> torch.Tensor:
+        """Generate ``max_new_tokens`` greedy tokens per row; returns ``[B, max_new_tokens]``.
+
+        With ``use_graph`` the step is captured once (``max_actual_seq_len`` baked as the final
+        context length rounded up to the attention partition size) and replayed per token.
+        ``warmup_steps`` of the total are run before ``on_step`` timing hooks fire (bench use).
+        """
+        self._begin_decode(first_tokens, max_new_tokens)
+        info = self.info
+        final_len = info.max_actual_seq_len + max_new_tokens
+        if final_len > self.max_seq_len:
+            raise RuntimeError(f"context {final_len} exceeds max_seq_len {self.max_seq_len}")
+        if use_graph:
+            info.max_actual_seq_len = (final_len + 127) // 128 * 128  # bucket, fixes the attention grid
+            # warm-up on a side stream (workspace growth, library init), fenced both ways
+            # (cuda_graph.py:110-115); state is restored afterwards
+            snap = self._snapshot()
+            s = torch.cuda.Stream()
+            s.wait_stream(torch.cuda.current_stream())
+            with torch.cuda.stream(s):
+                self._step_body()
+            torch.cuda.current_stream().wait_stream(s)
+            self._restore(snap)
+            graph = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(graph):
+                self._step_body()
+            self._restore(snap)  # capture does not execute, but keep the state explicit
+            self._graph = graph
+            for i in range(max_new_tokens):
+                if on_step is not None:
+                    on_step(i)
+                graph.replay()
+        else:
+            for i in range(max_new_tokens):
+                if on_step is not None:
+                    on_step(i)
+                info.max_actual_seq_len = int(info.max_actual_seq_len)  # eager: exact value
+                self._step_body()
+                info.max_actual_seq_len += 1
+        return self._out
+
+    def _snapshot(self):
+        info = self.info
+        return (self._input_ids.clone(), self._positions.clone(), info.cur_select_index.clone(),
+                info.b_seq_len.clone(), self._step.clone(), self._out.clone(),
+                info.b_req_tokens_table.clone())
+
+    def _restore(self, snap):
+        info = self.info
+        self._input_ids.copy_(snap[0])
+        self._positions.copy_(snap[1])
+        info.cur_select_index.copy_(snap[2])
+        info.b_seq_len.copy_(snap[3])
+        self._step.copy_(snap[4])
+        self._out.copy_(snap[5])
+        info.b_req_tokens_table.copy_(snap[6])

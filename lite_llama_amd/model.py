@@ -1,0 +1,400 @@
+"""The decode-step caller of the kernel boundary -- this build's counterpart of
+lite_llama/models/base.py:50-489 (PagedAttention / Attention / FusedMLP / DecoderLayer /
+CausalLM.forward), qwen3_moe.py:60-111 (sparse MoE block) and rotary_embedding.py:34-137.
+
+It fixes the per-layer call ORDER and wiring the reference uses, calling the 16-name kernel
+boundary unchanged:
+  norm -> q_proj, kv_proj -> split -> [qk-norm] -> rope -> cat(k, v) -> KV scatter ->
+  attention (prefill: flash_attention2_no_pad with scale*log2e; decode: flash_decoding) ->
+  o_proj (+TP all-reduce) -> norm (residual threaded in place) -> gate, up -> swiglu ->
+  down (+all-reduce) | router -> fused_moe (+all-reduce);  final norm -> fp16 lm_head.
+Checkpoint loading / HF config parsing are out of scope: geometry comes
+from the static table below and weights are synthetic (seeded).
+"""
+
+from __future__ import annotations
+
+import math
+from dataclasses import dataclass, field
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from .distributed.parallel_state import all_reduce_tp, divide, get_tp_rank, get_tp_world_size
+from .kernels import (
+    flash_attention2_no_pad,
+    flash_decoding,
+    rope_emb_forward,
+    skip_rmsnorm,
+    swiglu_forward,
+    update_kv_buffer,
+)
+from .linear import ColumnParallelLinear, LinearBase, RowParallelLinear
+from .quantization import QuantConfig, get_moe_method
+
+_LOG2E = 1.4426950408889634  # prefill kernel evaluates exp2 (base.py:45-47)
+
+
+@dataclass(frozen=True)
+class ModelGeometry:
+    """Static geometry (public HF configs)."""
+
+    name: str
+    hidden_size: int
+    num_layers: int
+    num_heads: int
+    num_kv_heads: int
+    head_dim: int
+    intermediate_size: int
+    vocab_size: int
+    rms_norm_eps: float = 1e-6
+    rope_theta: float = 1e6
+    qkv_bias: bool = False
+    use_qk_norm: bool = False
+    tie_word_embeddings: bool = False
+    rope_type: str = "default"
+    rope_scaling: dict = field(default_factory=dict)
+    # MoE (0 experts = dense MLP)
+    num_experts: int = 0
+    num_experts_per_tok: int = 0
+    moe_intermediate_size: int = 0
+    norm_topk_prob: bool = True
+
+    @property
+    def q_size(self) -> int:
+        return self.num_heads * self.head_dim
+
+    @property
+    def kv_size(self) -> int:
+        return self.num_kv_heads * self.head_dim
+
+
+GEOMETRY = {
+    "qwen2.5-0.5b": ModelGeometry("qwen2.5-0.5b", 896, 24, 14, 2, 64, 4864, 151936, qkv_bias=True,
+                                  tie_word_embeddings=True),
+    "qwen2.5-1.5b": ModelGeometry("qwen2.5-1.5b", 1536, 28, 12, 2, 128, 8960, 151936, qkv_bias=True,
+                                  tie_word_embeddings=True),
+    "qwen2.5-7b": ModelGeometry("qwen2.5-7b", 3584, 28, 28, 4, 128, 18944, 152064, qkv_bias=True),
+    "llama-3-8b": ModelGeometry("llama-3-8b", 4096, 32, 32, 8, 128, 14336, 128256, rms_norm_eps=1e-5,
+                                rope_theta=5e5),
+    "qwen3-30b-a3b": ModelGeometry("qwen3-30b-a3b", 2048, 48, 32, 4, 128, 6144, 151936, use_qk_norm=True,
+                                   num_experts=128, num_experts_per_tok=8, moe_intermediate_size=768),
+}
+
+
+def tiny_geometry(**kw) -> ModelGeometry:
+    """A small Qwen2-shaped geometry for tests / smoke."""
+    base = dict(name="tiny", hidden_size=256, num_layers=2, num_heads=4, num_kv_heads=2, head_dim=64,
+                intermediate_size=512, vocab_size=1024, qkv_bias=True)
+    base.update(kw)
+    return ModelGeometry(**base)
+
+
+# ------------------------------------------------------------------------------------- #
+# rotary tables (rotary_embedding.py:34-137): fp32 math, cos/sin in the activation dtype,
+# halves duplicated across the full head dim
+# ------------------------------------------------------------------------------------- #
+class RotaryEmbedding(nn.Module):
+    def __init__(self, geo: ModelGeometry):
+        super().__init__()
+        dim = geo.head_dim
+        inv_freq = 1.0 / (geo.rope_theta ** (torch.arange(0, dim, 2, dtype=torch.float32) / dim))
+        if geo.rope_type in ("llama3", "yarn"):
+            sc = geo.rope_scaling
+            factor, lo, hi = sc["factor"], sc["low_freq_factor"], sc["high_freq_factor"]
+            orig = sc["original_max_position_embeddings"]
+            wavelen = 2 * math.pi / inv_freq
+            scaled = torch.where(wavelen > orig / lo, inv_freq / factor, inv_freq)
+            smooth = (orig / wavelen - lo) / (hi - lo)
+            smoothed = (1 - smooth) * scaled / factor + smooth * scaled
+            mid = (wavelen <= orig / lo) & (wavelen >= orig / hi)
+            inv_freq = torch.where(mid, smoothed, scaled)
+        self.register_buffer("inv_freq", inv_freq, persistent=False)
+
+    @torch.no_grad()
+    def forward(self, x: torch.Tensor, position_ids: torch.Tensor):
+        """``(cos, sin)`` shaped ``[batch, seq, head_dim]`` in ``x.dtype``."""
+        freqs = position_ids.to(torch.float32)[:, :, None] * self.inv_freq.to(x.device)[None, None, :]
+        emb = torch.cat((freqs, freqs), dim=-1)
+        return emb.cos().to(x.dtype), emb.sin().to(x.dtype)
+
+
+# ------------------------------------------------------------------------------------- #
+# attention
+# ------------------------------------------------------------------------------------- #
+class PagedAttention(nn.Module):
+    """KV scatter + phase kernel over the token-attention pool ``[max_tokens, 2*Hkv, D]``
+    (K heads first, then V heads) -- base.py:50-142."""
+
+    def __init__(self, num_kv_heads: int, head_dim: int):
+        super().__init__()
+        self.num_kv_heads = num_kv_heads
+        self.head_dim = head_dim
+        self.scale = 1.0 / math.sqrt(head_dim)
+
+    def forward(self, xq, xk, xv, atten_info, layer_index: int, is_prefill: bool):
+        update_kv_buffer(torch.cat([xk, xv], dim=-2), atten_info.cur_select_index,
+                         atten_info.kv_buffer[layer_index])
+        if is_prefill:
+            return flash_attention2_no_pad(xq, xk, xv, self.scale * _LOG2E, atten_info.b_start_loc,
+                                           atten_info.b_seq_len, atten_info.max_actual_seq_len)
+        kv = atten_info.kv_buffer[layer_index]
+        return flash_decoding(xq, kv[:, : self.num_kv_heads, :], kv[:, self.num_kv_heads :, :], self.scale,
+                              atten_info.b_req_tokens_table, atten_info.b_req_idx, atten_info.b_seq_len,
+                              atten_info.max_actual_seq_len)
+
+
+class Attention(nn.Module):
+    """q/kv column-parallel, o row-parallel (one all-reduce) -- base.py:145-245."""
+
+    def __init__(self, geo: ModelGeometry, quant: QuantConfig | None):
+        super().__init__()
+        tp = get_tp_world_size()
+        self.num_heads = divide(geo.num_heads, tp, "attention heads")
+        self.num_kv_heads = divide(geo.num_kv_heads, tp, "key/value heads")
+        self.head_dim = geo.head_dim
+        self.hidden_size = geo.hidden_size
+        self.q_size = self.num_heads * self.head_dim
+        self.kv_size = self.num_kv_heads * self.head_dim
+        self.eps = geo.rms_norm_eps
+        self.use_qk_norm = geo.use_qk_norm
+        self.q_proj = ColumnParallelLinear(geo.hidden_size, geo.q_size, bias=geo.qkv_bias, quant=quant,
+                                           what="query features")
+        self.kv_proj = ColumnParallelLinear(geo.hidden_size, 2 * geo.kv_size, bias=geo.qkv_bias, quant=quant,
+                                            what="key/value features")
+        self.o_proj = RowParallelLinear(geo.q_size, geo.hidden_size, quant=quant, what="query features")
+        if self.use_qk_norm:
+            self.q_norm_weight = nn.Parameter(torch.ones(self.head_dim, dtype=torch.float16), requires_grad=False)
+            self.k_norm_weight = nn.Parameter(torch.ones(self.head_dim, dtype=torch.float16), requires_grad=False)
+        self.attn = PagedAttention(self.num_kv_heads, self.head_dim)
+
+    def forward(self, x, atten_info, layer_index, position_embeddings):
+        batch, seq_len, _ = x.shape
+        x2 = x.view(-1, self.hidden_size)
+        xq = self.q_proj(x2)
+        xkv = self.kv_proj(x2)
+        xk, xv = torch.split(xkv, self.kv_size, dim=-1)
+        n = batch * seq_len
+        xq = xq.view(n, self.num_heads, self.head_dim)
+        xk = xk.view(n, self.num_kv_heads, self.head_dim)
+        xv = xv.view(n, self.num_kv_heads, self.head_dim)
+        if self.use_qk_norm:
+            xq, _ = skip_rmsnorm(xq, None, self.q_norm_weight, self.eps)
+            xk, _ = skip_rmsnorm(xk, None, self.k_norm_weight, self.eps)
+        cos, sin = position_embeddings
+        xq, xk = rope_emb_forward(xq, xk, cos, sin, batch, seq_len)
+        out = self.attn(xq, xk, xv, atten_info, layer_index, is_prefill=seq_len > 1)
+        return self.o_proj(out.view(batch, seq_len, self.q_size))
+
+
+class FusedMLP(nn.Module):
+    """down(silu(gate(x)) * up(x)) -- base.py:248-264."""
+
+    def __init__(self, geo: ModelGeometry, quant: QuantConfig | None):
+        super().__init__()
+        h, i = geo.hidden_size, geo.intermediate_size
+        self.gate_proj = ColumnParallelLinear(h, i, quant=quant, what="MLP intermediate")
+        self.up_proj = ColumnParallelLinear(h, i, quant=quant, what="MLP intermediate")
+        self.down_proj = RowParallelLinear(i, h, quant=quant, what="MLP intermediate")
+
+    def forward(self, x):
+        return self.down_proj(swiglu_forward(self.gate_proj(x), self.up_proj(x)))
+
+
+class SparseMoeBlock(nn.Module):
+    """Top-k routed experts, TP-sharded on the expert intermediate dim -- qwen3_moe.py:60-111.
+    Router: fp16 linear -> fp32 softmax over ALL experts -> top-k -> renormalise."""
+
+    def __init__(self, geo: ModelGeometry, quant: QuantConfig | None):
+        super().__init__()
+        tp = get_tp_world_size()
+        self.hidden_size = geo.hidden_size
+        self.num_experts = geo.num_experts
+        self.top_k = geo.num_experts_per_tok
+        self.norm_topk_prob = geo.norm_topk_prob
+        self.moe_intermediate_size = divide(geo.moe_intermediate_size, tp, "MoE intermediate")
+        if quant is not None and not quant.shard_is_aligned(self.moe_intermediate_size):
+            raise ValueError(
+                f"tensor-parallel shard of MoE intermediate is {self.moe_intermediate_size} channels, which is not "
+                f"a multiple of the {quant.format} scale block ({quant.group_n}x{quant.group_k}); "
+                "use a smaller tensor_parallel_size"
+            )
+        self.quant = quant
+        self.quant_method = get_moe_method(quant)
+        self.gate_weight = nn.Parameter(torch.empty(self.num_experts, self.hidden_size, dtype=torch.float16),
+                                        requires_grad=False)
+        self.experts = nn.ParameterDict(self.quant_method.create_weights(self))
+
+    def _route(self, x):
+        logits = F.linear(x, self.gate_weight)
+        probs = torch.softmax(logits, dim=-1, dtype=torch.float32)
+        w, ids = torch.topk(probs, self.top_k, dim=-1)
+        if self.norm_topk_prob:
+            w = w / w.sum(dim=-1, keepdim=True)
+        return w, ids
+
+    def forward(self, x):
+        shape = x.shape
+        x2 = x.reshape(-1, self.hidden_size)
+        w, ids = self._route(x2)
+        out = self.quant_method.apply(self, x2, w, ids)
+        return all_reduce_tp(out).view(shape)
+
+    @torch.no_grad()
+    def quantize_experts_(self, quant: QuantConfig) -> None:
+        if self.quant is not None:
+            return
+        method = get_moe_method(quant)
+        method.convert_from_fp16(self, quant)
+        self.quant, self.quant_method = quant, method
+
+
+class DecoderLayer(nn.Module):
+    """Pre-norm block with the fused add-and-normalise threading ``residual`` -- base.py:267-319."""
+
+    def __init__(self, geo: ModelGeometry, quant: QuantConfig | None):
+        super().__init__()
+        self.eps = geo.rms_norm_eps
+        self.input_layernorm_weight = nn.Parameter(torch.ones(geo.hidden_size, dtype=torch.float16), requires_grad=False)
+        self.post_attention_layernorm_weight = nn.Parameter(torch.ones(geo.hidden_size, dtype=torch.float16),
+                                                            requires_grad=False)
+        self.self_attn = Attention(geo, quant)
+        self.mlp = SparseMoeBlock(geo, quant) if geo.num_experts else FusedMLP(geo, quant)
+
+    def forward(self, hidden_states, atten_info, layer_index, position_embeddings, residual=None):
+        hidden_states, residual = skip_rmsnorm(hidden_states, residual, self.input_layernorm_weight, self.eps)
+        hidden_states = self.self_attn(hidden_states, atten_info, layer_index, position_embeddings)
+        hidden_states, residual = skip_rmsnorm(hidden_states, residual, self.post_attention_layernorm_weight, self.eps)
+        hidden_states = self.mlp(hidden_states)
+        return hidden_states, residual
+
+
+class CausalLM(nn.Module):
+    """token ids -> logits (base.py:322-489).  Embedding, final norm and ``lm_head`` are fp16 and
+    replicated under TP (every rank computes full logits and the same argmax)."""
+
+    def __init__(self, geo: ModelGeometry, quant: QuantConfig | None = None):
+        super().__init__()
+        self.geo = geo
+        self.quant = quant
+        self.embed_tokens = nn.Embedding(geo.vocab_size, geo.hidden_size, dtype=torch.float16)
+        self.embed_tokens.weight.requires_grad_(False)
+        self.layers = nn.ModuleList(DecoderLayer(geo, quant) for _ in range(geo.num_layers))
+        self.norm_weight = nn.Parameter(torch.ones(geo.hidden_size, dtype=torch.float16), requires_grad=False)
+        if geo.tie_word_embeddings:
+            self.lm_head_weight = self.embed_tokens.weight
+        else:
+            self.lm_head_weight = nn.Parameter(torch.empty(geo.vocab_size, geo.hidden_size, dtype=torch.float16),
+                                               requires_grad=False)
+        self.rotary_emb = RotaryEmbedding(geo)
+        self.eps = geo.rms_norm_eps
+
+    @torch.no_grad()
+    def forward(self, input_ids, position_ids, atten_info, logits_rows=None):
+        """``[batch, seq]`` ids -> ``[batch, seq, vocab]`` fp16 logits.  ``logits_rows`` (extension:
+        flat token indices) restricts the lm_head to those rows -- prefill only needs the last
+        prompt position of every sequence, not ``batch*seq*vocab`` logits."""
+        hidden_states = self.embed_tokens(input_ids)
+        position_embeddings = self.rotary_emb(hidden_states, position_ids)
+        residual = None
+        for i, layer in enumerate(self.layers):
+            hidden_states, residual = layer(hidden_states, atten_info, i, position_embeddings, residual)
+        hidden_states, _ = skip_rmsnorm(hidden_states, residual, self.norm_weight, self.eps)
+        if logits_rows is not None:
+            hidden_states = hidden_states.view(-1, hidden_states.shape[-1])[logits_rows]
+        return F.linear(hidden_states, self.lm_head_weight)
+
+    @torch.no_grad()
+    def quantize_(self, quant: QuantConfig) -> None:
+        """Convert every fp16 projection to ``quant`` in place (the ``--quantization`` path)."""
+        for m in self.modules():
+            if isinstance(m, LinearBase):
+                m.quantize_(quant)
+            elif hasattr(m, "quantize_experts_"):
+                m.quantize_experts_(quant)
+        self.quant = quant
+
+    # --------------------------------------------------------------------------------- #
+    # synthetic weights (no checkpoints exist offline): seeded, reference quantiser semantics
+    # --------------------------------------------------------------------------------- #
+    @torch.no_grad()
+    def init_synthetic(self, seed: int = 0, quant: QuantConfig | None = None, device="cuda") -> "CausalLM":
+        """fp16 masters ``randn * 0.02`` per projection (each TP rank draws the FULL matrix from the
+        same seed and keeps its shard, so all ranks hold consistent weights), norms ``1 + 0.1 randn``,
+        biases ``0.01 randn``; then quantised layer by layer with the reference quantisers."""
+        g = torch.Generator(device=device)
+        g.manual_seed(seed)
+        tp, rank = get_tp_world_size(), get_tp_rank()
+
+        def randn(*shape, std=0.02):
+            return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std).to(torch.float16)
+
+        def shard(full, dim):
+            return full if tp == 1 else full.chunk(tp, dim=dim)[rank].contiguous()
+
+        def fill_linear(lin: LinearBase, full_out: int, full_in: int, shard_dim: int | None):
+            w = randn(full_out, full_in)
+            w = w if shard_dim is None else shard(w, shard_dim)
+            lin.weight = nn.Parameter(w, requires_grad=False)
+            if lin.bias is not None:
+                b = randn(full_out, std=0.01)
+                lin.bias = nn.Parameter(b if shard_dim != 0 else shard(b, 0), requires_grad=False)
+            lin.quant, lin.quant_method = None, get_linear_method_for(None)
+            if quant is not None:
+                lin.quantize_(quant)
+
+        geo = self.geo
+        self.to(device)
+        self.embed_tokens.weight.copy_(randn(geo.vocab_size, geo.hidden_size))
+        if not geo.tie_word_embeddings:
+            self.lm_head_weight.copy_(randn(geo.vocab_size, geo.hidden_size))
+        self.norm_weight.copy_((1 + 0.1 * torch.randn(geo.hidden_size, generator=g, device=device)).half())
+        for layer in self.layers:
+            layer.input_layernorm_weight.copy_((1 + 0.1 * torch.randn(geo.hidden_size, generator=g, device=device)).half())
+            layer.post_attention_layernorm_weight.copy_(
+                (1 + 0.1 * torch.randn(geo.hidden_size, generator=g, device=device)).half())
+            at = layer.self_attn
+            fill_linear(at.q_proj, geo.q_size, geo.hidden_size, 0)
+            # fused kv: each rank takes its slice of k_proj and of v_proj and fuses locally
+            # (weights.py:99,166-169): rank r's rows are [K_r ; V_r]
+            kw, vw = randn(geo.kv_size, geo.hidden_size), randn(geo.kv_size, geo.hidden_size)
+            kv = torch.cat([shard(kw, 0), shard(vw, 0)], dim=0)
+            at.kv_proj.weight = nn.Parameter(kv, requires_grad=False)
+            if at.kv_proj.bias is not None:
+                kb, vb = randn(geo.kv_size, std=0.01), randn(geo.kv_size, std=0.01)
+                at.kv_proj.bias = nn.Parameter(torch.cat([shard(kb, 0), shard(vb, 0)]), requires_grad=False)
+            at.kv_proj.quant, at.kv_proj.quant_method = None, get_linear_method_for(None)
+            if quant is not None:
+                at.kv_proj.quantize_(quant)
+            fill_linear(at.o_proj, geo.hidden_size, geo.q_size, 1)
+            if geo.use_qk_norm:
+                at.q_norm_weight.copy_((1 + 0.1 * torch.randn(geo.head_dim, generator=g, device=device)).half())
+                at.k_norm_weight.copy_((1 + 0.1 * torch.randn(geo.head_dim, generator=g, device=device)).half())
+            if geo.num_experts:
+                blk = layer.mlp
+                blk.gate_weight.copy_(randn(geo.num_experts, geo.hidden_size))
+                e, i_full = geo.num_experts, geo.moe_intermediate_size
+                gate = shard(randn(e, i_full, geo.hidden_size, std=1.0 / math.sqrt(geo.hidden_size)), 1)
+                up = shard(randn(e, i_full, geo.hidden_size, std=1.0 / math.sqrt(geo.hidden_size)), 1)
+                down = shard(randn(e, geo.hidden_size, i_full, std=1.0 / math.sqrt(i_full)), 2)
+                blk.quant, blk.quant_method = None, get_moe_method(None)
+                blk.experts = nn.ParameterDict({
+                    "gate_up_proj": nn.Parameter(torch.cat([gate, up], dim=1), requires_grad=False),
+                    "down_proj": nn.Parameter(down, requires_grad=False),
+                })
+                if quant is not None:
+                    blk.quantize_experts_(quant)
+            else:
+                mlp = layer.mlp
+                fill_linear(mlp.gate_proj, geo.intermediate_size, geo.hidden_size, 0)
+                fill_linear(mlp.up_proj, geo.intermediate_size, geo.hidden_size, 0)
+                fill_linear(mlp.down_proj, geo.hidden_size, geo.intermediate_size, 1)
+        self.quant = quant
+        return self
+
+
+def get_linear_method_for(quant):
+    from .quantization import get_linear_method
+
+    return get_linear_method(quant)

@@ -1,0 +1,197 @@
+"""Quant-method strategies -- mirror of lite_llama/models/quantization/methods/*.py
+(``LinearQuantMethod`` / ``MoeQuantMethod`` contract, base.py:23-74; registries
+``_LINEAR_METHODS`` / ``_MOE_METHODS``, __init__.py:21-63).  ``apply`` dispatches the
+layer's parameters to the HIP kernels; parameter names/dtypes are the reference's
+(``weight`` + ``weight_scale``/``weight_zeros`` | ``weight_scale_inv``; experts
+``gate_up_proj``/``down_proj`` + ``*_scale_inv``)."""
+
+from __future__ import annotations
+
+from abc import ABC, abstractmethod
+
+import torch
+import torch.nn as nn
+import torch.nn.functional as F
+
+from ..kernels import fused_moe, smoothquant_matmul, w4a16_matmul, w8a16_matmul
+from .config import FP8, INT4, INT8, SMOOTHQUANT, QuantConfig
+from .params import (
+    quantize_fp8_per_channel,
+    quantize_int4_groupwise,
+    quantize_int8_groupwise,
+    quantize_int8_per_channel,
+)
+
+
+def RawParameter(t: torch.Tensor) -> nn.Parameter:
+    """Non-trainable parameter holding raw (integer / scale) storage (parameter.py:16-20)."""
+    return nn.Parameter(t, requires_grad=False)
+
+
+class LinearQuantMethod(ABC):
+    @abstractmethod
+    def create_weights(self, layer: nn.Module, input_size: int, output_size: int) -> None: ...
+
+    @abstractmethod
+    def apply(self, layer: nn.Module, x: torch.Tensor) -> torch.Tensor: ...
+
+    def convert_from_fp16(self, layer: nn.Module, quant: QuantConfig) -> None:
+        raise NotImplementedError(f"{type(self).__name__} cannot be computed from fp16 weights at load time")
+
+
+class MoeQuantMethod(ABC):
+    @abstractmethod
+    def create_weights(self, block: nn.Module) -> dict: ...
+
+    @abstractmethod
+    def apply(self, block, x, topk_weights, topk_ids) -> torch.Tensor: ...
+
+    def convert_from_fp16(self, block: nn.Module, quant: QuantConfig) -> None:
+        raise NotImplementedError(f"{type(self).__name__} cannot be computed from fp16 weights at load time")
+
+
+class UnquantizedLinearMethod(LinearQuantMethod):
+    """fp16 weight through the library GEMM (hipBLASLt via ``F.linear``), unquantized.py:21-22."""
+
+    def create_weights(self, layer, input_size, output_size):
+        layer.weight = nn.Parameter(torch.empty(output_size, input_size, dtype=torch.float16), requires_grad=False)
+
+    def apply(self, layer, x):
+        return F.linear(x, layer.weight, layer.bias)
+
+
+class W4A16LinearMethod(LinearQuantMethod):
+    """methods/w4a16.py:18-43."""
+
+    def create_weights(self, layer, input_size, output_size):
+        q = layer.quant
+        layer.weight = RawParameter(torch.empty(output_size, (input_size + 7) // 8, dtype=torch.int32))
+        layer.weight_scale = RawParameter(torch.empty(*q.scale_shape(output_size, input_size), dtype=torch.float32))
+        layer.weight_zeros = RawParameter(torch.empty(*q.scale_shape(output_size, input_size), dtype=torch.float32))
+
+    def apply(self, layer, x):
+        return w4a16_matmul(x, layer.weight, layer.weight_scale, layer.weight_zeros,
+                            group_size=layer.quant.group_k, bias=layer.bias)
+
+    def convert_from_fp16(self, layer, quant):
+        qw, sc, zr = quantize_int4_groupwise(layer.weight.data, quant.group_k)
+        layer.weight = RawParameter(qw)
+        layer.weight_scale = RawParameter(sc)
+        layer.weight_zeros = RawParameter(zr)
+
+
+def _quantize_8bit(weight, quant: QuantConfig, in_size: int):
+    if quant.format == FP8:
+        return quantize_fp8_per_channel(weight)
+    if quant.group_k < in_size:
+        return quantize_int8_groupwise(weight, quant.group_k)
+    return quantize_int8_per_channel(weight)
+
+
+class W8A16LinearMethod(LinearQuantMethod):
+    """methods/w8a16.py:39-63."""
+
+    def create_weights(self, layer, input_size, output_size):
+        q = layer.quant
+        layer.weight = RawParameter(torch.empty(output_size, input_size, dtype=q.storage_dtype))
+        layer.weight_scale_inv = RawParameter(torch.empty(*q.scale_shape(output_size, input_size), dtype=torch.float32))
+
+    def apply(self, layer, x):
+        q = layer.quant
+        return w8a16_matmul(x, layer.weight, layer.weight_scale_inv, group_n=q.group_n,
+                            group_k=min(q.group_k, layer.input_size), bias=layer.bias)
+
+    def convert_from_fp16(self, layer, quant):
+        qw, sc = _quantize_8bit(layer.weight.data, quant, layer.input_size)
+        layer.weight = RawParameter(qw)
+        layer.weight_scale_inv = RawParameter(sc)
+
+
+class SmoothQuantLinearMethod(LinearQuantMethod):
+    """methods/w8a8.py:16-38 (dynamic per-token int8 activations x per-channel int8 weights)."""
+
+    def create_weights(self, layer, input_size, output_size):
+        q = layer.quant
+        layer.weight = RawParameter(torch.empty(output_size, input_size, dtype=q.storage_dtype))
+        layer.weight_scale_inv = RawParameter(torch.empty(*q.scale_shape(output_size, input_size), dtype=torch.float32))
+
+    def apply(self, layer, x):
+        return smoothquant_matmul(x, layer.weight, layer.weight_scale_inv, bias=layer.bias)
+
+    def convert_from_fp16(self, layer, quant):
+        qw, sc = quantize_int8_per_channel(layer.weight.data)
+        layer.weight = RawParameter(qw)
+        layer.weight_scale_inv = RawParameter(sc)
+
+
+class UnquantizedMoeMethod(MoeQuantMethod):
+    """methods/unquantized.py:25-57."""
+
+    def create_weights(self, block):
+        return {
+            "gate_up_proj": nn.Parameter(torch.empty(block.num_experts, 2 * block.moe_intermediate_size,
+                                                     block.hidden_size, dtype=torch.float16), requires_grad=False),
+            "down_proj": nn.Parameter(torch.empty(block.num_experts, block.hidden_size,
+                                                  block.moe_intermediate_size, dtype=torch.float16), requires_grad=False),
+        }
+
+    def apply(self, block, x, topk_weights, topk_ids):
+        return fused_moe(x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids)
+
+
+class W8A16MoeMethod(MoeQuantMethod):
+    """methods/w8a16.py:66-112."""
+
+    def create_weights(self, block):
+        q = block.quant
+        gu_n, gu_k = 2 * block.moe_intermediate_size, block.hidden_size
+        d_n, d_k = block.hidden_size, block.moe_intermediate_size
+        e = block.num_experts
+        return {
+            "gate_up_proj": RawParameter(torch.empty(e, gu_n, gu_k, dtype=q.storage_dtype)),
+            "gate_up_proj_scale_inv": RawParameter(torch.empty(e, *q.scale_shape(gu_n, gu_k), dtype=torch.float32)),
+            "down_proj": RawParameter(torch.empty(e, d_n, d_k, dtype=q.storage_dtype)),
+            "down_proj_scale_inv": RawParameter(torch.empty(e, *q.scale_shape(d_n, d_k), dtype=torch.float32)),
+        }
+
+    def apply(self, block, x, topk_weights, topk_ids):
+        q = block.quant
+        return fused_moe(
+            x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids,
+            w1_scale=block.experts["gate_up_proj_scale_inv"], w2_scale=block.experts["down_proj_scale_inv"],
+            group_n=q.group_n, group_k=min(q.group_k, block.hidden_size),
+        )
+
+    def convert_from_fp16(self, block, quant):
+        for name in ("gate_up_proj", "down_proj"):
+            qw, sc = _quantize_8bit(block.experts[name].data, quant, block.hidden_size)
+            block.experts[name] = RawParameter(qw)
+            block.experts[f"{name}_scale_inv"] = RawParameter(sc)
+
+
+_LINEAR_METHODS = {FP8: W8A16LinearMethod, INT8: W8A16LinearMethod, SMOOTHQUANT: SmoothQuantLinearMethod,
+                   INT4: W4A16LinearMethod}
+# smoothquant experts are weight-only int8 (grouped GEMM keeps fp16 activations); int4 experts are
+# rejected -- there is no grouped int4 GEMM (methods/__init__.py:28-36)
+_MOE_METHODS = {FP8: W8A16MoeMethod, INT8: W8A16MoeMethod, SMOOTHQUANT: W8A16MoeMethod}
+
+
+def get_linear_method(quant: QuantConfig | None) -> LinearQuantMethod:
+    if quant is None:
+        return UnquantizedLinearMethod()
+    cls = _LINEAR_METHODS.get(quant.format)
+    if cls is None:
+        raise ValueError(f"no linear quant method for format {quant.format!r}")
+    return cls()
+
+
+def get_moe_method(quant: QuantConfig | None) -> MoeQuantMethod:
+    if quant is None:
+        return UnquantizedMoeMethod()
+    cls = _MOE_METHODS.get(quant.format)
+    if cls is None:
+        raise ValueError(
+            f"format {quant.format!r} is not supported for MoE experts; "
+            "add the layer to modules_to_not_convert or use an 8-bit scheme"
+        )
+    return cls()

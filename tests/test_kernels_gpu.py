@@ -419,3 +419,123 @@ def test_argmax_exact():
     logits[3, 100] = logits[3, 70000] = 50.0  # tie -> first index
     got = greedy_argmax(logits.to(DEV))
     assert torch.equal(got.cpu(), torch.argmax(logits, dim=-1))
+
+
+# ------------------------------------------------------------------------------------- #
+# flash_attention2_no_pad (tol 2e-2)
+# ------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("name", G.names("fa2_nopad_"))
+def test_fa2_nopad_golden(name):
+    d = dev(G.load(name))
+    out = K().flash_attention2_no_pad(d["q"], d["k"], d["v"], d["sm_scale"], d["b_start_loc"], d["b_seq_len"],
+                                      d["max_seq_len"])
+    valid = d["valid"]
+    close(out[valid], d["out"][valid], 2e-2)
+
+
+@pytest.mark.parametrize("lens,hq,hkv,d", [([64], 4, 4, 64), ([1], 4, 2, 64), ([70, 33, 128], 8, 2, 64),
+                                            ([200, 17], 14, 2, 128), ([40, 5], 4, 1, 32)])
+def test_fa2_nopad_oracle(lens, hq, hkv, d):
+    lp, bsz = max(lens), len(lens)
+    q = (torch.randn(bsz * lp, hq, d) * 0.5).half()
+    k = (torch.randn(bsz * lp, hkv, d) * 0.5).half()
+    v = torch.randn(bsz * lp, hkv, d).half()
+    start = torch.arange(bsz, dtype=torch.int32) * lp
+    seq = torch.tensor(lens, dtype=torch.int32)
+    scale = 1.4426950408889634 / math.sqrt(d)
+    ref = O.flash_attention2_no_pad(q, k, v, scale, start, seq, lp)
+    out = K().flash_attention2_no_pad(q.to(DEV), k.to(DEV), v.to(DEV), scale, start.to(DEV), seq.to(DEV), lp)
+    valid = torch.zeros(bsz * lp, dtype=torch.bool)
+    for i, n in enumerate(lens):
+        valid[i * lp : i * lp + n] = True
+    close(out.cpu()[valid], ref[valid], 2e-2)
+    # first token attends only itself: output == v row
+    close(out.cpu()[0], v[0].repeat_interleave(hq // hkv, dim=0), 2e-2)
+
+
+def test_fa2_nopad_no_cross_sequence_leak():
+    """Changing sequence 1's K/V must not change sequence 0's output."""
+    lens, hq, hkv, d = [20, 30], 4, 2, 64
+    lp = 30
+    q = torch.randn(2 * lp, hq, d, device=DEV, dtype=torch.float16)
+    k = torch.randn(2 * lp, hkv, d, device=DEV, dtype=torch.float16)
+    v = torch.randn(2 * lp, hkv, d, device=DEV, dtype=torch.float16)
+    start = torch.tensor([0, lp], dtype=torch.int32, device=DEV)
+    seq = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    a = K().flash_attention2_no_pad(q, k, v, 0.18, start, seq, lp)
+    k2, v2 = k.clone(), v.clone()
+    k2[lp:] += 1.0
+    v2[lp:] -= 2.0
+    b = K().flash_attention2_no_pad(q, k2, v2, 0.18, start, seq, lp)
+    assert torch.equal(a[:20], b[:20])
+
+
+# ------------------------------------------------------------------------------------- #
+# fused_moe (align outputs bit-exact; output tol 2e-2)
+# ------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("name", G.names("moe_align_"))
+def test_moe_align_golden(name):
+    d = dev(G.load(name))
+    s, e, n = K().moe_align_block_size(d["topk_ids"], d["block_size"], d["num_experts"])
+    assert torch.equal(s, d["sorted_ids"]) and torch.equal(e, d["expert_ids"]) and torch.equal(n, d["num_post"])
+
+
+def test_moe_align_protocol():
+    ids = torch.tensor([[2, 0], [1, 2]], device=DEV, dtype=torch.int32)
+    s, e, n = K().moe_align_block_size(ids, 4, 3)
+    assert int(n.item()) == 12
+    valid = s[:12].tolist()
+    assert [v for v in valid if v != 4] == [1, 2, 0, 3]
+    assert e[:3].tolist() == [0, 1, 2]
+    assert (s[1:4] == 4).all()
+    ids = torch.full((4, 2), 5, device=DEV, dtype=torch.int64)
+    s, e, n = K().moe_align_block_size(ids, 4, 8)
+    assert int(n.item()) == 8 and s[:8].max() < 8 and e[:2].tolist() == [5, 5]
+    for t, topk, ne, bm in [(37, 2, 8, 32), (128, 8, 128, 64), (1, 8, 128, 16), (300, 4, 16, 64)]:
+        ids = torch.randint(0, ne, (t, topk), dtype=torch.int32)
+        so, eo, no = O.moe_align_block_size(ids, bm, ne)
+        s, e, n = K().moe_align_block_size(ids.to(DEV), bm, ne)
+        assert torch.equal(s.cpu(), so) and torch.equal(e.cpu(), eo) and torch.equal(n.cpu(), no)
+
+
+@pytest.mark.parametrize("name", G.names("fused_moe_"))
+def test_fused_moe_golden(name):
+    d = dev(G.load(name))
+    kw = {k: d[k] for k in ("w1_scale", "w2_scale", "group_n", "group_k") if k in d}
+    out = K().fused_moe(d["x"], d["w1"], d["w2"], d["topk_weights"], d["topk_ids"], **kw)
+    close(out, d["out"], 2e-2)
+
+
+@pytest.mark.parametrize("num_tokens", [1, 3, 37, 128])
+@pytest.mark.parametrize("num_experts,top_k", [(8, 2), (128, 8)])
+def test_fused_moe_oracle(num_tokens, num_experts, top_k):
+    hidden, inter = 256, 128
+    x = (torch.randn(num_tokens, hidden) / hidden**0.5).half()
+    w1 = (torch.randn(num_experts, 2 * inter, hidden) / hidden**0.5).half()
+    w2 = (torch.randn(num_experts, hidden, inter) / inter**0.5).half()
+    ids = torch.randint(0, num_experts, (num_tokens, top_k))
+    wts = torch.softmax(torch.randn(num_tokens, top_k), dim=-1).half()
+    ref = O.fused_moe(x, w1, w2, wts, ids)
+    out = K().fused_moe(x.to(DEV), w1.to(DEV), w2.to(DEV), wts.to(DEV), ids.to(DEV))
+    close(out, ref, 2e-2)
+
+
+def test_fused_moe_routing_weight_and_quant():
+    hidden, inter, ne, top_k = 128, 128, 4, 2
+    x = torch.randn(5, hidden).half()
+    w1 = (torch.randn(ne, 2 * inter, hidden) / hidden**0.5)
+    w2 = (torch.randn(ne, hidden, inter) / inter**0.5)
+    ids = torch.randint(0, ne, (5, top_k))
+    wts = torch.rand(5, top_k).half()
+    wts[:, 1] = 0
+    ref = O.fused_moe(x, w1.half(), w2.half(), wts, ids)
+    out = K().fused_moe(x.to(DEV), w1.half().to(DEV), w2.half().to(DEV), wts.to(DEV), ids.to(DEV))
+    close(out, ref, 2e-2)
+    q1, s1 = O.quantize_int8_per_channel(w1)
+    q2, s2 = O.quantize_int8_per_channel(w2)
+    ref = O.fused_moe(x, q1, q2, wts, ids, w1_scale=s1, w2_scale=s2, group_n=1, group_k=hidden)
+    out = K().fused_moe(x.to(DEV), q1.to(DEV), q2.to(DEV), wts.to(DEV), ids.to(DEV), w1_scale=s1.to(DEV),
+                        w2_scale=s2.to(DEV), group_n=1, group_k=hidden)
+    close(out, ref, 2e-2)
+    with pytest.raises(ValueError):
+        K().fused_moe(x.to(DEV), q1.to(DEV), w2.half().to(DEV), wts.to(DEV), ids.to(DEV), w1_scale=s1.to(DEV))

@@ -1,0 +1,147 @@
+"""Whole decode-step parity: call ORDER, KV-pool / table side effects and logits of the model-step
+caller against the golden captured from the reference's own model code.
+
+CPU tier: the oracle model vs the golden.  GPU tier: the HIP-backed model vs the golden + oracle.
+"""
+
+import types
+
+import numpy as np
+import pytest
+import torch
+
+from tests import _golden as G
+
+
+def _load():
+    d = np.load(G.GOLDEN_DIR + "/model_step_qwen2_tiny.npz")
+    params = {k[len("param."):]: torch.from_numpy(d[k].copy()) for k in d.files if k.startswith("param.")}
+    return d, params
+
+
+def _info(kv, table, sel, seq, start, max_len, dev="cpu"):
+    return types.SimpleNamespace(kv_buffer=kv, cur_select_index=sel.to(dev), b_req_tokens_table=table,
+                                 b_start_loc=start.to(dev) if start is not None else None,
+                                 b_req_idx=torch.arange(len(seq), dtype=torch.int32, device=dev),
+                                 b_seq_len=seq.to(dev), max_actual_seq_len=max_len)
+
+
+def _run_steps(make_model, dev, quant=None):
+    """prefill (fp16 always) + decode with ``quant``; returns (last prefill logits, decode logits, kv, table)."""
+    d, params = _load()
+    H, I, L, HQ, HKV, D, V = [int(x) for x in d["geometry"]]
+    lens = d["lens"].tolist()
+    B, LP = len(lens), max(lens)
+    kv = [torch.zeros(64, 2 * HKV, D, dtype=torch.float16, device=dev) for _ in range(L)]
+    table = torch.zeros(B, 16, dtype=torch.int32, device=dev)
+    sel = torch.arange(B * LP, dtype=torch.int32)
+    for i, n in enumerate(lens):
+        table[i, :n] = sel[i * LP : i * LP + n].to(dev)
+    info = _info(kv, table, sel, torch.tensor(lens, dtype=torch.int32), torch.arange(B, dtype=torch.int32) * LP, LP, dev)
+    m16 = make_model(params, None)
+    ids = torch.from_numpy(d["prompt_ids"]).to(dev)
+    pos = torch.arange(LP, device=dev).unsqueeze(0).expand(B, LP).contiguous()
+    logits = m16.forward(ids, pos, info)
+    last = torch.stack([logits[i, n - 1] for i, n in enumerate(lens)])
+    kv_prefill = [k.clone() for k in kv]
+    # decode_alloc_kv_cache
+    info.cur_select_index = torch.arange(B * LP, B * LP + B, dtype=torch.int32, device=dev)
+    info.b_seq_len = info.b_seq_len + 1
+    info.max_actual_seq_len += 1
+    for i in range(B):
+        table[i, int(info.b_seq_len[i]) - 1] = info.cur_select_index[i]
+    tok = torch.from_numpy(d["first_tokens"]).to(dev)
+    mq = make_model(params, quant) if quant else m16
+    dl = mq.forward(tok.view(B, 1), torch.from_numpy(d["decode_positions"]).to(dev), info)
+    return d, last, dl, kv_prefill, kv, table
+
+
+def _oracle_model(params, quant):
+    from oracle.model import OracleModel
+
+    d = np.load(G.GOLDEN_DIR + "/model_step_qwen2_tiny.npz")
+    H, I, L, HQ, HKV, D, V = [int(x) for x in d["geometry"]]
+    return OracleModel({k: v.clone() for k, v in params.items()}, H, I, L, HQ, HKV, D, V, quant=quant)
+
+
+@pytest.mark.parametrize("quant", [None, "int4", "int8", "smoothquant", "fp8"])
+def test_oracle_model_matches_reference_step(quant):
+    d, last, dl, kvp, kvd, table = _run_steps(_oracle_model, "cpu", quant)
+    lens = d["lens"].tolist()
+    LP = max(lens)
+    torch.testing.assert_close(last.float(), torch.from_numpy(d["logits_prefill_last"]).float(), rtol=2e-2, atol=2e-2)
+    assert torch.equal(torch.argmax(last, -1), torch.from_numpy(d["first_tokens"]))
+    # KV pool: rows of the valid prompt tokens and of the decode token (pad rows hold junk by design)
+    valid = [i * LP + j for i, n in enumerate(lens) for j in range(n)]
+    for li in range(len(kvp)):
+        torch.testing.assert_close(kvp[li][valid].float(), torch.from_numpy(d[f"kv_prefill.{li}"])[valid].float(),
+                                   rtol=2e-2, atol=2e-2)
+    assert torch.equal(table, torch.from_numpy(d["table_after"]))
+    key = "fp16" if quant is None else quant
+    ref = torch.from_numpy(d[f"logits_decode.{key}"]).float()
+    tol = 1e-1 if quant == "smoothquant" else 3e-2
+    torch.testing.assert_close(dl.float(), ref, rtol=tol, atol=tol)
+    if quant is None:
+        dec_rows = [len(lens) * LP + i for i in range(len(lens))]
+        for li in range(len(kvd)):
+            torch.testing.assert_close(kvd[li][dec_rows].float(), torch.from_numpy(d[f"kv_decode.{li}"])[dec_rows].float(),
+                                       rtol=2e-2, atol=2e-2)
+        assert torch.equal(torch.argmax(dl[:, -1], -1), torch.argmax(ref[:, -1], -1))
+
+
+def _hip_model(params, quant):
+    from lite_llama_amd.model import CausalLM, tiny_geometry
+    from lite_llama_amd.quantization import QuantConfig
+
+    d = np.load(G.GOLDEN_DIR + "/model_step_qwen2_tiny.npz")
+    H, I, L, HQ, HKV, D, V = [int(x) for x in d["geometry"]]
+    geo = tiny_geometry(hidden_size=H, intermediate_size=I, num_layers=L, num_heads=HQ, num_kv_heads=HKV,
+                        head_dim=D, vocab_size=V, rope_theta=10000.0, qkv_bias=True)
+    m = CausalLM(geo)
+    m.load_state_dict({k: v for k, v in params.items()}, strict=True)
+    m = m.to("cuda")
+    if quant:
+        cfg = {"int4": QuantConfig.int4_groupwise(128), "int8": QuantConfig.int8_per_channel(),
+               "smoothquant": QuantConfig.smoothquant_per_channel(), "fp8": QuantConfig.fp8_per_channel()}[quant]
+        m.quantize_(cfg)
+    return m
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("quant", [None, "int4", "int8", "smoothquant", "fp8"])
+def test_hip_model_matches_reference_step(quant):
+    d, last, dl, kvp, kvd, table = _run_steps(_hip_model, "cuda", quant)
+    lens = d["lens"].tolist()
+    LP = max(lens)
+    torch.testing.assert_close(last.float().cpu(), torch.from_numpy(d["logits_prefill_last"]).float(), rtol=3e-2, atol=3e-2)
+    assert torch.equal(torch.argmax(last, -1).cpu(), torch.from_numpy(d["first_tokens"]))
+    valid = [i * LP + j for i, n in enumerate(lens) for j in range(n)]
+    for li in range(len(kvp)):
+        torch.testing.assert_close(kvp[li][valid].float().cpu(), torch.from_numpy(d[f"kv_prefill.{li}"])[valid].float(),
+                                   rtol=2e-2, atol=2e-2)
+    assert torch.equal(table.cpu(), torch.from_numpy(d["table_after"]))
+    key = "fp16" if quant is None else quant
+    ref = torch.from_numpy(d[f"logits_decode.{key}"]).float()
+    tol = 1e-1 if quant == "smoothquant" else 3e-2
+    torch.testing.assert_close(dl.float().cpu(), ref, rtol=tol, atol=tol)
+    if quant is None:
+        assert torch.equal(torch.argmax(dl[:, -1], -1).cpu(), torch.argmax(ref[:, -1], -1))
+
+
+@pytest.mark.gpu
+def test_engine_graph_equals_eager_and_oracle():
+    """hipGraph-captured decode == eager decode (byte-identical greedy tokens, like the reference's
+    tests/compile/test_cuda_graph.py:50-70), and both follow the oracle model's greedy path."""
+    from lite_llama_amd.executor import DecodeEngine
+
+    d, params = _load()
+    m = _hip_model(params, None)
+    ids = torch.from_numpy(d["prompt_ids"]).cuda()
+    lens = torch.from_numpy(d["lens"]).int().cuda()
+    outs = []
+    for use_graph in (False, True):
+        eng = DecodeEngine(m, max_batch=2, max_seq_len=64)
+        first = eng.prefill(ids, lens)
+        assert torch.equal(first.cpu(), torch.from_numpy(d["first_tokens"]))
+        outs.append(eng.decode(first, 12, use_graph=use_graph).cpu())
+    assert torch.equal(outs[0], outs[1])
