@@ -1,0 +1,280 @@
+"""Headline benchmark: decode throughput of Qwen2.5-7B W4A16 (group 128) at batch 64 on MI355X.
+
+    python bench.py [--gpus N --steps K --warmup W]
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
+        --master-port P bench.py --gpus N --steps K --warmup W
+
+A "step" is ONE decode step of the whole batch (one new token per sequence) through the HIP hot
+path, replayed from a hipGraph: embedding -> 28 x [skip_rmsnorm, w4a16 q/kv, rope, KV scatter,
+flash_decoding, w4a16 o (+TP all-reduce), skip_rmsnorm, w4a16 gate/up, swiglu, w4a16 down
+(+all-reduce)] -> norm -> fp16 lm_head -> greedy argmax -> on-device metadata advance.
+Synthetic data (no checkpoints offline): seeded random fp16 weights quantised with the reference's
+int4 quantiser semantics, seeded random K/V for a 512-token context per sequence, random first
+tokens; greedy, no EOS stop, lockstep batch -- the reference's measurement protocol
+(benchmarks/common.py:101-137).  Inputs are resident in HBM when the timed region starts.
+
+Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
+  roofline     -- dominant kernel (wgemm_kernel = W4A16 dequant-GEMM): algorithmic weight bytes per
+                  launch / average launch duration measured live with HIP events, vs 8 TB/s HBM peak
+  cpu_baseline -- the CPU oracle (oracle/model.py, a "port") timed on the host cores on a bounded
+                  sample of the same workload (N = 1 only)
+"""
+
+from __future__ import annotations
+
+import argparse
+import json
+import os
+import sys
+import time
+
+import torch
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+sys.path.insert(0, ROOT)
+
+PEAK_HBM = 8.0e12  # B/s, MI355X HBM3E peak (MI355X_MICROARCH.md)
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=64)
+    ap.add_argument("--warmup", type=int, default=8)
+    ap.add_argument("--model", default="qwen2.5-7b")
+    ap.add_argument("--batch", type=int, default=64)
+    ap.add_argument("--ctx", type=int, default=512, help="context tokens per sequence when decoding starts")
+    ap.add_argument("--quant", default="int4", choices=["int4", "int8", "smoothquant", "fp8", "none"])
+    ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--cpu-layers", type=int, default=2, help="decoder layers in the CPU oracle sample")
+    return ap.parse_args()
+
+
+def algorithmic_bytes(geo, quant, batch, ctx, tp):
+    """weight bytes (reference storage format) + fp16 lm_head + K/V bytes, per step, per rank."""
+    per_w = {"int4": 0.5 + 8.0 / 128, "int8": 1.0, "smoothquant": 1.0, "fp8": 1.0, "none": 2.0}[quant]
+    lin = geo.num_layers * (geo.hidden_size * geo.q_size * 2 + geo.hidden_size * 2 * geo.kv_size +
+                            3 * geo.hidden_size * geo.intermediate_size)
+    w_lin = lin * per_w / tp
+    w_head = geo.vocab_size * geo.hidden_size * 2
+    kv_tok = geo.num_layers * 2 * geo.kv_size * 2 / tp
+    return w_lin, w_head, batch * ctx * kv_tok
+
+
+def gemm_roofline(model, batch, quant, iters=6):
+    """Average launch duration of the dominant kernel (the weight-streaming dequant-GEMM) over every
+    projection of the model with its real weights, by HIP events on the launch stream."""
+    from lite_llama_amd.linear import LinearBase
+
+    lins = [m for m in model.modules() if isinstance(m, LinearBase) and m.quant is not None]
+    if not lins:
+        return None
+    dev = next(model.parameters()).device
+    xs = {}
+    for lin in lins:
+        if lin.input_size not in xs:
+            xs[lin.input_size] = torch.randn(batch, lin.input_size, device=dev, dtype=torch.float16) * 0.5
+    per_w = {"int4": 0.5 + 8.0 / 128, "int8": 1.0, "smoothquant": 1.0, "fp8": 1.0}[quant]
+    nbytes = sum(lin.input_size * lin.output_size * per_w for lin in lins)
+    stream = torch.cuda.current_stream()
+    for lin in lins:  # warm
+        lin.apply_linear(xs[lin.input_size])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record(stream)
+    for _ in range(iters):
+        for lin in lins:
+            lin.apply_linear(xs[lin.input_size])
+    e1.record(stream)
+    torch.cuda.synchronize()
+    launches = iters * len(lins) * (2 if quant == "smoothquant" else 1)
+    avg_s = e0.elapsed_time(e1) * 1e-3 / (iters * len(lins))
+    bytes_per_launch = nbytes / len(lins)
+    achieved = bytes_per_launch / avg_s
+    traffic = None
+    tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
+    if os.path.exists(tpath):
+        try:
+            traffic = json.load(open(tpath)).get("wgemm_bytes_per_launch")
+        except Exception:
+            traffic = None
+    return {
+        "bound": "hbm", "kernel": "wgemm_kernel (w4a16 dequant-GEMM)" if quant == "int4" else "wgemm_kernel",
+        "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+        "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic,
+        "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
+        "launches_timed": launches,
+    }
+
+
+def cpu_baseline(geo, batch, ctx, layers, quant):
+    """The CPU oracle (a port of the reference algorithm, oracle/model.py) on a bounded sample:
+    ``layers`` decoder layers + final norm + lm_head of the same decode step (same batch / context
+    / geometry / int4 format), extrapolated to the full depth."""
+    from oracle import oracle as O
+    from oracle.model import OracleModel
+    import types
+
+    torch.manual_seed(0)
+    H, I, HQ, HKV, D, V = geo.hidden_size, geo.intermediate_size, geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.vocab_size
+    p = {"embed_tokens.weight": (torch.randn(V, H) * 0.02).half(), "lm_head_weight": (torch.randn(V, H) * 0.02).half(),
+         "norm_weight": torch.ones(H).half()}
+    for li in range(layers):
+        pre = f"layers.{li}."
+        p[pre + "input_layernorm_weight"] = torch.ones(H).half()
+        p[pre + "post_attention_layernorm_weight"] = torch.ones(H).half()
+        for name, (n, k) in {"self_attn.q_proj": (HQ * D, H), "self_attn.kv_proj": (2 * HKV * D, H),
+                             "self_attn.o_proj": (H, HQ * D), "mlp.gate_proj": (I, H), "mlp.up_proj": (I, H),
+                             "mlp.down_proj": (H, I)}.items():
+            p[pre + name + ".weight"] = (torch.randn(n, k) * 0.02).half()
+        p[pre + "self_attn.q_proj.bias"] = torch.zeros(HQ * D).half()
+        p[pre + "self_attn.kv_proj.bias"] = torch.zeros(2 * HKV * D).half()
+    om = OracleModel(p, H, I, layers, HQ, HKV, D, V, eps=geo.rms_norm_eps, rope_theta=geo.rope_theta,
+                     quant=None if quant == "none" else quant)
+    # quantise outside the timed region
+    for li in range(layers):
+        for name in ("self_attn.q_proj", "self_attn.kv_proj", "self_attn.o_proj", "mlp.gate_proj", "mlp.up_proj",
+                     "mlp.down_proj"):
+            key = f"layers.{li}.{name}.weight"
+            om._linear(torch.zeros(1, p[key].shape[1]).half(), key)
+    rows = batch * (ctx + 1)
+    kv = [(torch.randn(rows, 2 * HKV, D) * 0.5).half() for _ in range(layers)]
+    table = torch.arange(rows, dtype=torch.int32).view(batch, ctx + 1)
+    info = types.SimpleNamespace(kv_buffer=kv, cur_select_index=table[:, ctx].contiguous(), b_req_tokens_table=table,
+                                 b_start_loc=None, b_req_idx=torch.arange(batch, dtype=torch.int32),
+                                 b_seq_len=torch.full((batch,), ctx + 1, dtype=torch.int32), max_actual_seq_len=ctx + 1)
+    ids = torch.randint(0, V, (batch, 1))
+    pos = torch.full((batch, 1), ctx)
+    t0 = time.perf_counter()
+    logits = om.forward(ids, pos, info)
+    O.greedy_argmax(logits[:, -1])
+    t_all = time.perf_counter() - t0
+    # time the non-layer part (embedding + final norm + lm_head + argmax) to extrapolate honestly
+    om0 = OracleModel(p, H, I, 0, HQ, HKV, D, V, eps=geo.rms_norm_eps, rope_theta=geo.rope_theta)
+    t0 = time.perf_counter()
+    O.greedy_argmax(om0.forward(ids, pos, info)[:, -1])
+    t_head = time.perf_counter() - t0
+    per_layer = max(t_all - t_head, 1e-9) / layers
+    step_s = per_layer * geo.num_layers + t_head
+    return {"value": round(batch / step_s, 2), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"oracle decode step, batch {batch}, ctx {ctx}: {layers} of {geo.num_layers} layers timed "
+                      f"({per_layer:.2f} s/layer) + lm_head/argmax ({t_head:.2f} s), extrapolated to full depth",
+            "sample_seconds": round(t_all + t_head, 1)}
+
+
+def main():
+    args = parse()
+    rank = int(os.environ.get("RANK", 0))
+    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    world = int(os.environ.get("WORLD_SIZE", 1))
+    if world != args.gpus and world > 1:
+        raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
+    if args.gpus > 1 and world == 1:
+        raise SystemExit("launch multi-GPU runs with torch.distributed.run (see module docstring)")
+    torch.cuda.set_device(local_rank)
+    dev = torch.device("cuda", local_rank)
+
+    from lite_llama_amd.distributed import parallel_state as ps
+    from lite_llama_amd.executor import DecodeEngine
+    from lite_llama_amd.model import GEOMETRY, CausalLM
+    from lite_llama_amd.quantization import QuantConfig
+
+    geo = GEOMETRY[args.model]
+    # TP degree: the largest divisor of the GPU count that the reference's sharding rules allow
+    # (tp | Hq, tp | Hkv, shard sizes multiples of the int4 group); remaining GPUs are data-parallel
+    # replicas (no collective between them).
+    tp = 1
+    for cand in (8, 4, 2, 1):
+        if world % cand == 0 and geo.num_heads % cand == 0 and geo.num_kv_heads % cand == 0 and \
+                (geo.intermediate_size // cand) % 128 == 0 and (geo.q_size // cand) % 128 == 0:
+            tp = cand
+            break
+    dp = world // tp
+    ps.init_parallel(rank, tp_size=tp, dp_size=dp, master_port=int(os.environ.get("MASTER_PORT", 29500)))
+    if world > 1 and not torch.distributed.is_initialized():  # pure DP: still need the timing barrier
+        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+
+    quant = None if args.quant == "none" else QuantConfig.for_runtime_scheme(args.quant)
+    t_build = time.perf_counter()
+    with torch.device(dev):
+        model = CausalLM(geo, quant)
+    model.init_synthetic(seed=0, quant=quant, device=dev)
+    torch.cuda.synchronize()
+    t_build = time.perf_counter() - t_build
+
+    total = args.warmup + args.steps
+    engine = DecodeEngine(model, max_batch=args.batch, max_seq_len=args.ctx + total + 8, device=dev)
+    first = engine.synthetic_context(args.batch, args.ctx, seed=1 + ps.get_dp_rank())
+
+    marks = {}
+
+    def barrier():
+        torch.cuda.synchronize()
+        if world > 1:
+            torch.distributed.barrier()
+        torch.cuda.synchronize()
+
+    def on_step(i):
+        if i == args.warmup:
+            barrier()
+            marks["t0"] = time.perf_counter()
+
+    use_graph = not args.no_graph
+    graph_note = "hipGraph"
+    try:
+        out = engine.decode(first, total, use_graph=use_graph, on_step=on_step)
+    except Exception as exc:  # graph capture refused (e.g. collective not capturable): measured eagerly
+        if not use_graph:
+            raise
+        graph_note = f"eager (graph capture failed: {type(exc).__name__})"
+        engine = DecodeEngine(model, max_batch=args.batch, max_seq_len=args.ctx + total + 8, device=dev)
+        first = engine.synthetic_context(args.batch, args.ctx, seed=1 + ps.get_dp_rank())
+        out = engine.decode(first, total, use_graph=False, on_step=on_step)
+    barrier()
+    elapsed = time.perf_counter() - marks["t0"]
+    if world > 1:
+        t = torch.tensor([elapsed], device=dev, dtype=torch.float64)
+        torch.distributed.all_reduce(t, op=torch.distributed.ReduceOp.MAX)
+        elapsed = float(t.item())
+    assert out.shape == (args.batch, total)
+
+    global_batch = args.batch * dp
+    tokens = global_batch * args.steps
+    ms_per_step = elapsed / args.steps * 1e3
+    ctx_mid = args.ctx + args.warmup + args.steps / 2
+    w_lin, w_head, kv_bytes = algorithmic_bytes(geo, args.quant, args.batch, ctx_mid, tp)
+    step_bytes = w_lin + w_head + kv_bytes
+
+    result = {
+        "metric": "decode tokens/s (Qwen2.5-7B W4A16 g128, batch 64, greedy, ctx 512+)" if args.model == "qwen2.5-7b"
+        else f"decode tokens/s ({args.model} {args.quant}, batch {args.batch})",
+        "value": round(tokens / elapsed, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
+        "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
+        "scaling": "strong" if dp == 1 else "weak", "vs_baseline": None, "dtype": "f16 (int4 weights, fp32 accumulate)",
+        "data": "synthetic",
+        "config": {"workload": f"{args.model} {args.quant} decode, batch {args.batch}/replica, ctx {args.ctx}->"
+                               f"{args.ctx + total}, {graph_note}", "global_batch": global_batch,
+                   "parallelism": f"dp{dp}xtp{tp}", "build_seconds": round(t_build, 1)},
+        "step_roofline": {"algorithmic_bytes_per_step_per_gpu": int(step_bytes),
+                          "achieved_GBps_per_gpu": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
+                          "frac_of_8TBps": round(step_bytes / (elapsed / args.steps) / PEAK_HBM, 4)},
+    }
+    if rank == 0:
+        rf = gemm_roofline(model, args.batch, args.quant) if quant is not None else None
+        result["roofline"] = rf
+        if world == 1 and not args.no_cpu_baseline:
+            try:
+                result["cpu_baseline"] = cpu_baseline(geo, args.batch, args.ctx, args.cpu_layers, args.quant)
+            except Exception as exc:  # never lose the GPU line to a host-side hiccup
+                result["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+        print(json.dumps(result), flush=True)
+    if world > 1:
+        torch.distributed.barrier()
+        ps.destroy_parallel()
+        if torch.distributed.is_initialized():
+            torch.distributed.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

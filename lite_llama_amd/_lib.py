@@ -122,7 +122,9 @@ _gemm_ws_keepalive: list = []  # captured hipGraphs may still point at outgrown 
 def gemm_workspace(device: torch.device, m: int, n: int, k: int):
     floats, ints = c_int64(0), c_int64(0)
     lib().ll_gemm_workspace(m, n, k, ctypes.byref(floats), ctypes.byref(ints))
-    key = (device.type, device.index, torch.cuda.current_stream().cuda_stream)
+    # one scratch per device: the decode path is single-stream (a side-stream warm-up and the
+    # capture that follows are ordered by stream fences), so concurrent use never happens
+    key = (device.type, device.index)
     ws = _gemm_ws.get(key)
     if ws is None or ws[0].numel() < floats.value or ws[1].numel() < ints.value:
         if torch.cuda.is_current_stream_capturing():

@@ -94,43 +94,41 @@ def flash_decoding(q, k_cache, v_cache, qk_scale, table, b_req_idx, b_seq_len, m
     hkv = k_cache.shape[1]
     groups = hq // hkv
     out = torch.empty_like(q)
-    neg_inf = float("-inf")
-    for b in range(bsz):
+    for b in range(bsz):  # all heads of a row advance together (vectorised over the head axis)
         length = int(b_seq_len[b])
         rows = table[int(b_req_idx[b]), :length].long()
         nparts = (length + PARTITION_SIZE - 1) // PARTITION_SIZE
-        for h in range(hq):
-            kvh = h // groups
-            qv = q[b, h].float()
-            kk = k_cache[rows, kvh].float()  # [L, D]
-            vv = v_cache[rows, kvh].float()
-            part_o, part_lse = [], []
-            for p in range(nparts):
-                lo, hi = p * PARTITION_SIZE, min(length, (p + 1) * PARTITION_SIZE)
-                m_i, d_i = neg_inf, 0.0
-                acc = torch.zeros(d, dtype=torch.float32)
-                for c0 in range(lo, hi, DECODE_BLOCK_N):
-                    c1 = min(hi, c0 + DECODE_BLOCK_N)
-                    s = (kk[c0:c1] * qv).sum(dim=1) * qk_scale
-                    m_ij = max(m_i, float(s.max()))
-                    pr = torch.exp(s - m_ij)
-                    alpha = math.exp(m_i - m_ij) if m_i != neg_inf else 0.0
-                    d_i = alpha * d_i + float(pr.sum())
-                    acc = alpha * acc + (pr[:, None] * vv[c0:c1]).sum(dim=0)
-                    m_i = m_ij
-                part_o.append(acc / d_i)
-                part_lse.append(m_i + math.log(d_i))
-            m_i, d_i = neg_inf, 0.0
-            acc = torch.zeros(d, dtype=torch.float32)
-            for p in range(nparts):
-                m_ij = max(part_lse[p], m_i)
-                alpha = math.exp(m_i - m_ij) if m_i != neg_inf else 0.0
-                w = math.exp(part_lse[p] - m_ij)
-                acc = alpha * acc + w * part_o[p]
-                d_i = alpha * d_i + w
+        qv = q[b].float()  # [Hq, D]
+        kk = k_cache[rows].float().repeat_interleave(groups, dim=1).transpose(0, 1)  # [Hq, L, D]
+        vv = v_cache[rows].float().repeat_interleave(groups, dim=1).transpose(0, 1)
+        part_o, part_lse = [], []
+        for p in range(nparts):
+            lo, hi = p * PARTITION_SIZE, min(length, (p + 1) * PARTITION_SIZE)
+            m_i = torch.full((hq,), float("-inf"))
+            d_i = torch.zeros(hq)
+            acc = torch.zeros(hq, d)
+            for c0 in range(lo, hi, DECODE_BLOCK_N):
+                c1 = min(hi, c0 + DECODE_BLOCK_N)
+                s = (kk[:, c0:c1] * qv[:, None, :]).sum(dim=2) * qk_scale  # [Hq, n]
+                m_ij = torch.maximum(m_i, s.max(dim=1).values)
+                pr = torch.exp(s - m_ij[:, None])
+                alpha = torch.exp(m_i - m_ij)
+                d_i = alpha * d_i + pr.sum(dim=1)
+                acc = alpha[:, None] * acc + (pr[:, :, None] * vv[:, c0:c1]).sum(dim=1)
                 m_i = m_ij
-            res = acc / d_i if d_i != 0.0 else torch.full((d,), float("nan"))
-            out[b, h] = res.to(out.dtype)
+            part_o.append(acc / d_i[:, None])
+            part_lse.append(m_i + torch.log(d_i))
+        m_i = torch.full((hq,), float("-inf"))
+        d_i = torch.zeros(hq)
+        acc = torch.zeros(hq, d)
+        for p in range(nparts):
+            m_ij = torch.maximum(part_lse[p], m_i)
+            alpha = torch.exp(m_i - m_ij)
+            w = torch.exp(part_lse[p] - m_ij)
+            acc = alpha[:, None] * acc + w[:, None] * part_o[p]
+            d_i = alpha * d_i + w
+            m_i = m_ij
+        out[b] = (acc / d_i[:, None]).to(out.dtype)  # zero-length row: 0/0 -> NaN like the reference
     return out
 
 
