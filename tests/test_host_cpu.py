@@ -1,0 +1,114 @@
+"""CPU tier: the C-ABI library loads and exports every symbol include/lite_llama_amd.h declares
+(no compute calls without a GPU), plus the host-side mirror of the reference's operator interface
+(names, quant-method registry, parameter layout, error behaviour, engine metadata arithmetic)."""
+
+import os
+import re
+
+import pytest
+import torch
+
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def test_abi_exports_match_header():
+    from lite_llama_amd import _lib, build
+
+    build.build(verbose=False)
+    lib = _lib.lib()
+    header = open(os.path.join(ROOT, "include", "lite_llama_amd.h")).read()
+    declared = set(re.findall(r"^int\s+(ll_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    assert declared, "no declarations parsed"
+    assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
+    for name in declared:
+        assert hasattr(lib, name), name
+    assert lib.ll_abi_version() == _lib.ABI_VERSION
+    assert lib.ll_flash_decoding_num_partitions(129) == 2
+
+
+def test_kernel_names_match_reference_surface():
+    import lite_llama_amd.kernels as k
+
+    assert sorted(k.__all__) == sorted([
+        "flash_attention2_no_pad", "flash_decoding", "fused_moe", "gelu", "leaky_relu", "moe_align_block_size",
+        "relu", "rope_emb_forward", "skip_rmsnorm", "swiglu_forward", "tanh", "update_kv_buffer",
+        "update_kv_index", "w4a16_matmul", "w8a16_matmul", "smoothquant_matmul"])
+
+
+def test_no_cpu_fallback():
+    """The product path fails loudly on CPU tensors instead of routing anywhere else."""
+    import lite_llama_amd.kernels as k
+
+    x = torch.randn(2, 64, dtype=torch.float16)
+    with pytest.raises(RuntimeError, match="GPU only"):
+        k.skip_rmsnorm(x, None, torch.ones(64, dtype=torch.float16))
+    with pytest.raises(RuntimeError, match="GPU only"):
+        k.swiglu_forward(x, x)
+
+
+def test_validation_errors_precede_launch():
+    import lite_llama_amd.kernels as k
+
+    x = torch.randn(2, 256, dtype=torch.float16)
+    qw = torch.zeros(8, 32, dtype=torch.int32)
+    with pytest.raises(ValueError, match="must be fp16"):
+        k.w4a16_matmul(x.float(), qw, torch.ones(8, 2), torch.zeros(8, 2))
+    with pytest.raises(ValueError, match="int32"):
+        k.w4a16_matmul(x, qw.long(), torch.ones(8, 2), torch.zeros(8, 2))
+    with pytest.raises(ValueError, match="multiple of group_size"):
+        k.w4a16_matmul(x, qw, torch.ones(8, 2), torch.zeros(8, 2), group_size=96)
+    with pytest.raises(ValueError, match="uint8"):
+        k.w8a16_matmul(x, torch.zeros(8, 256, dtype=torch.int16), torch.ones(8, 1), group_n=1, group_k=256)
+    with pytest.raises(ValueError, match="group_k"):
+        k.w8a16_matmul(x, torch.zeros(8, 256, dtype=torch.int8), torch.ones(8, 4), group_n=1, group_k=64)
+    with pytest.raises(ValueError, match="int8"):
+        k.smoothquant_matmul(x, torch.zeros(8, 256, dtype=torch.uint8), torch.ones(8))
+
+
+def test_quant_registry_and_layout():
+    from lite_llama_amd.quantization import (QuantConfig, SmoothQuantLinearMethod, W4A16LinearMethod,
+                                             W8A16LinearMethod, W8A16MoeMethod, get_linear_method, get_moe_method)
+    from lite_llama_amd.linear import LinearBase
+
+    assert isinstance(get_linear_method(QuantConfig.int4_groupwise()), W4A16LinearMethod)
+    assert isinstance(get_linear_method(QuantConfig.fp8_block()), W8A16LinearMethod)
+    assert isinstance(get_linear_method(QuantConfig.smoothquant_per_channel()), SmoothQuantLinearMethod)
+    assert isinstance(get_moe_method(QuantConfig.smoothquant_per_channel()), W8A16MoeMethod)
+    with pytest.raises(ValueError, match="not supported for MoE"):
+        get_moe_method(QuantConfig.int4_groupwise())
+    lin = LinearBase(512, 256, bias=True, quant=QuantConfig.int4_groupwise(128))
+    assert lin.weight.shape == (256, 64) and lin.weight.dtype == torch.int32
+    assert lin.weight_scale.shape == (256, 4) and lin.weight_zeros.dtype == torch.float32
+    lin8 = LinearBase(512, 256, quant=QuantConfig.fp8_block())
+    assert lin8.weight.dtype == torch.uint8 and lin8.weight_scale_inv.shape == (2, 4)
+    q = QuantConfig.for_runtime_scheme("int8-blockwise")
+    assert q.group_k == 128 and q.storage_dtype == torch.int8
+    with pytest.raises(ValueError):
+        QuantConfig.for_runtime_scheme("int3")
+
+
+def test_quantisers_match_oracle_bit_exactly():
+    from lite_llama_amd.quantization import (quantize_fp8_per_channel, quantize_int4_groupwise,
+                                             quantize_int8_groupwise, quantize_int8_per_channel)
+    from oracle import oracle as O
+
+    w = torch.randn(16, 256) * 0.05
+    for mine, ref in [(quantize_int4_groupwise(w, 128), O.quantize_int4_groupwise(w, 128)),
+                      (quantize_int8_per_channel(w), O.quantize_int8_per_channel(w)),
+                      (quantize_int8_groupwise(w, 128), O.quantize_int8_groupwise(w, 128)),
+                      (quantize_fp8_per_channel(w), O.quantize_fp8_per_channel(w))]:
+        for a, b in zip(mine, ref):
+            assert torch.equal(a, b)
+
+
+def test_model_skeleton_and_tp_rules():
+    from lite_llama_amd.model import GEOMETRY, CausalLM, tiny_geometry
+    from lite_llama_amd.quantization import QuantConfig
+
+    m = CausalLM(tiny_geometry(), QuantConfig.int4_groupwise(128))
+    names = dict(m.named_parameters())
+    assert "layers.0.self_attn.kv_proj.weight_zeros" in names and "layers.1.mlp.down_proj.weight_scale" in names
+    g = GEOMETRY["qwen2.5-7b"]
+    assert (g.q_size, g.kv_size, g.intermediate_size) == (3584, 512, 18944)
+    moe = CausalLM(tiny_geometry(num_experts=4, num_experts_per_tok=2, moe_intermediate_size=128))
+    assert moe.layers[0].mlp.experts["gate_up_proj"].shape == (4, 256, 256)
