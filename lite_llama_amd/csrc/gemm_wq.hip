@@ -641,12 +641,22 @@ static Plan make_plan(int64_t m, int64_t n, int64_t k) {
   return pl;
 }
 
+// second-generation W4A16 engine (gemm_w4_v2.hip)
+extern "C" int ll_w4a16_v2_workspace(int64_t m, int64_t n, int64_t k, int64_t* floats, int64_t* ints);
+extern "C" int ll_w4a16_v2_supported(int64_t m, int64_t n, int64_t k, int group_size);
+extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweight, const float* scales,
+                                  const float* zeros, const void* bias, int64_t m, int64_t n, int64_t k,
+                                  int group_size, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
+                                  float* workspace, int32_t* counters, void* stream);
+
 extern "C" int ll_gemm_workspace(int64_t m, int64_t n, int64_t k, int64_t* workspace_floats,
                                  int64_t* counter_ints) {
   const Plan pl = make_plan(m, n, k);
   const int64_t tiles = (int64_t)pl.mblocks * pl.nblocks;
-  if (workspace_floats) *workspace_floats = tiles * pl.slots * GEMM_SLAB;
-  if (counter_ints) *counter_ints = tiles * 4;
+  int64_t f = tiles * pl.slots * GEMM_SLAB, c = tiles * 4, f2 = 0, c2 = 0;
+  ll_w4a16_v2_workspace(m, n, k, &f2, &c2);  // the scratch must fit whichever engine is dispatched
+  if (workspace_floats) *workspace_floats = f > f2 ? f : f2;
+  if (counter_ints) *counter_ints = c > c2 ? c : c2;
   return LL_OK;
 }
 
@@ -687,6 +697,9 @@ extern "C" int ll_w4a16_matmul(void* out, const void* x, const int32_t* qweight,
   p.m = m; p.n = n; p.k = k; p.x_stride = x_stride_m; p.w_stride = qw_stride_n;
   p.s_stride_n = s_stride_n; p.s_stride_k = 1; p.group_n = 1; p.group_k = group_size;
   hipStream_t st = (hipStream_t)stream;
+  if (workspace && counters && ll_w4a16_v2_supported(m, n, k, group_size))
+    return ll_w4a16_v2_launch(out, x, qweight, scales, zeros, bias, m, n, k, group_size, x_stride_m,
+                              qw_stride_n, s_stride_n, workspace, counters, stream);
   if (group_size % 64 == 0) return launch_wgemm<FMT_W4, 1>(p, st);
   if (group_size == 32) return launch_wgemm<FMT_W4, 2>(p, st);
   if (group_size == 16) return launch_wgemm<FMT_W4, 4>(p, st);
