@@ -7,6 +7,8 @@ import lite_llama_amd.kernels as K
 dev = "cuda"
 M = int(os.environ.get("M", 64))
 shapes = [("q/o", 3584, 3584), ("kv", 1024, 3584), ("gate/up", 18944, 3584), ("down", 3584, 18944)]
+if os.environ.get("SHAPES"):
+    shapes = [(f"s{i}", *map(int, t.split("x"))) for i, t in enumerate(os.environ["SHAPES"].split(","))]
 for name, n, k in shapes:
     wbytes = n * k // 2 + 2 * n * (k // 128) * 4
     copies = max(2, int(700e6 // wbytes))

@@ -21,6 +21,7 @@ LIBDIR = os.path.join(HERE, "lib")
 LIBNAME = "liblite_llama_amd.so"
 ARCH = "gfx950"
 FLAGS = ["-O3", "-std=c++17", "-fPIC", f"--offload-arch={ARCH}", "-ffp-contract=off"]
+FLAGS += os.environ.get("LL_EXTRA_HIPCC_FLAGS", "").split()  # debug builds (e.g. -DV2_DEBUG_ABLATE)
 
 
 def _hipcc() -> str:

@@ -1,18 +1,27 @@
-// W4A16 dequant-GEMM, second-generation engine (group_size % 128 == 0: the AWQ/GPTQ g128 case).
+// W4A16 dequant-GEMM, decode engine (M <= 64, group_size % 128 == 0: the AWQ/GPTQ g128 case).
 // Reference semantics: lite_llama/kernels/quantization/w4a16.py:28-207 (see gemm_wq.hip for the
-// generic engine that also serves the other group sizes and the 8-bit formats).
+// generic engine that serves every other shape / group size and the 8-bit formats).
 //
-// What round-1 measurements (benchmarks/gemm_trace.py, probes/stream_probe.hip) said
-// about the first engine, and what this one does about it:
+// What the round-1 measurements (benchmarks/gemm_shapes.py + ablations) said, and what
+// this engine does about it:
 //   * lane-per-row weight loads stream at 3.7 TB/s, 64-B-per-row coalesced loads at 4.3+ TB/s
 //     -> dedicated LOADER waves fetch the [128 rows x 64 B] unit tile with 4 lanes per row and stage
 //        it (XOR-swizzled, conflict-free) in an LDS ring; scale/zero pairs ride along;
-//   * one consumer wave per SIMD is issue-bound (~4 cycles/instruction) -> 8 consumer waves
-//     (2 per SIMD): 4 row groups x 2 k-halves of every unit, each doing 4 MFMA steps;
-//     the two k-halves are summed through LDS once per tile;
-//   * per-workgroup fixed costs dominated (cold prologue, many-contributor tile merges)
-//     -> ONE persistent 12-wave workgroup per CU, one HBM round trip in the prologue,
-//        <= 3 contributors per tile.
+//   * one consumer wave per SIMD is issue-bound -> 8 consumer waves (2 per SIMD): 4 row groups x
+//     2 k-halves of every unit, each doing 4 MFMA steps; the k-halves are summed through LDS once
+//     per tile segment;
+//   * every role is a single instruction stream (~5 cycles per instruction): the per-unit cost of
+//     the WHOLE workgroup is the longest role's instruction count, so loaders/producers carry no
+//     address arithmetic in the loop (fixed per-lane VGPR offsets + one scalar base per unit) and
+//     the unit sequence is advanced with branch-free scalar selects.  No control flow ever
+//     surrounds a global load (hipcc's waitcnt pass drains vmcnt(0) otherwise);
+//   * tile merges: a release fence or a returning ticket atomic in the middle of the stream stalls
+//     the workgroup for microseconds -> STATIC ownership.  Each workgroup runs its range
+//     tail-segment FIRST and head-segment LAST: the tail (first chunks of a tile finished by the
+//     next workgroup) is parked in a slab with write-through stores and flagged one unit later
+//     (fire and forget); the head (last chunks of a tile) is finished at the very end by its
+//     owner, which finds the earlier contributors' flags already set, adds their slabs and writes
+//     the output.  Waits only ever point at lower-numbered workgroups (dispatched earlier).
 // Roles (wave id): 0-7 consumers (ng = w & 3, kh = w >> 2), 8-9 weight loaders (64 rows each),
 // 10-11 activation producers (32 rows each).  One s_barrier per unit for everybody.
 #include <stdlib.h>
@@ -24,10 +33,9 @@
 #define V2_CK 128
 #define V2_THREADS 768
 #define V2_SLAB (V2_BN * V2_BM)
-#define V2_MAX_SLOTS 6
-#define V2_WPF 6  // weight units in flight (registers) per loader wave
-#define V2_RW 4   // LDS weight ring depth (units)
-#define V2_D 2    // a unit is staged in LDS this many iterations before it is consumed
+#define V2_MAX_SLOTS 12
+#define V2_RW 4  // LDS weight ring depth (units)
+#define V2_D 2   // a unit is staged in LDS this many iterations before it is consumed
 
 struct alignas(16) Q4 {
   uint32_t x, y, z, w;
@@ -47,8 +55,6 @@ struct V2Params {
   int nblocks, chunks, total_units, upw, slots;
   int gshift;  // log2(group_size / 128) when a power of two, else -1
   int gdiv;    // group_size / 128
-  unsigned long long* dbg;  // optional phase stamps (LL_GEMM_TRACE)
-  int ablate;               // LL_GEMM2_ABLATE: 1 no x loads, 2 no weight loads, 4 no compute (debug)
 };
 
 __device__ __forceinline__ uint32_t v2_pk_add(uint32_t a, uint32_t b) {
@@ -89,87 +95,103 @@ __device__ __forceinline__ Q4 v2_dequant(uint32_t w, uint32_t s, uint32_t nzs, u
 
 // LDS map (bytes)
 #define V2_A_ROW 272
-#define V2_A_TILE (V2_BM * V2_A_ROW)              // 17408
-#define V2_XR 4                                   // LDS activation ring depth (units)
-#define V2_OFF_A 0                                // V2_XR x-tiles
-#define V2_OFF_W (V2_XR * V2_A_TILE)              // RW weight tiles of 8192 B
-#define V2_OFF_S (V2_OFF_W + V2_RW * 8192)        // RW scale tiles: 128 rows x (s, -z*s) as fp16 pairs x2 = 8 B
-#define V2_OFF_R (V2_OFF_S + V2_RW * 1024)        // reduce buffer: 4 row groups x 8 KB
-#define V2_LDS_BYTES (V2_OFF_R + 4 * 8192)
+#define V2_A_TILE (V2_BM * V2_A_ROW)        // 17408
+#define V2_XR 4                             // LDS activation ring depth (units)
+#define V2_OFF_A 0                          // V2_XR x-tiles
+#define V2_OFF_W (V2_XR * V2_A_TILE)        // RW weight tiles of 8192 B
+#define V2_OFF_S (V2_OFF_W + V2_RW * 8192)  // RW scale tiles: 128 rows x (s, -z*s) fp16 pairs x2 = 8 B
+#define V2_OFF_R (V2_OFF_S + V2_RW * 1024)  // reduce buffer: 4 row groups x 8 KB
+#define V2_OFF_T (V2_OFF_R + 4 * 8192)      // unit table: 16 B per unit of the workgroup
+#define V2_MAX_UNITS 1024
+#define V2_LDS_BYTES (V2_OFF_T + V2_MAX_UNITS * 16)
 
 // swizzled byte offset of 16-B piece p (0..3) of row r (0..127) inside an 8-KB weight tile
 __device__ __forceinline__ int v2_wslot(int r, int p) { return (r * 4 + (p ^ ((r >> 2) & 3))) * 16; }
 
-#define V2_TBAR()                                                  \
-  {                                                                \
-    const unsigned long long b0_ = dbgp ? __builtin_amdgcn_s_memtime() : 0; \
-    __syncthreads();                                               \
-    if (dbgp) bwait += __builtin_amdgcn_s_memtime() - b0_;          \
-  }
+// The unit sequence of one workgroup (all scalar).  Global unit g = tile * chunks + chunk; the
+// workgroup owns [ub, ue).  Order: tail segment (first chunks of the last tile), full tiles, head
+// segment (last chunks of the first tile).  LT / NF / LH = units in each part.
 
-template <int MT>
+// ABL (debug builds only, -DV2_DEBUG_ABLATE): 1 no x loads, 2 no weight loads, 4 no compute, 8 no flush
+template <int MT, int ABL>
 __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgemm2_kernel(const V2Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
-  const int lane = tid & 63, wv = tid >> 6;
-  const int K = (int)p.k;
+  const int lane = tid & 63;
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chunks = p.chunks;
   const int ub = blockIdx.x * p.upw;
   int ue = ub + p.upw;
   if (ue > p.total_units) ue = p.total_units;
   if (ub >= ue) return;
+  const int cnt = ue - ub;
+  const int tA = ub / chunks, cA = ub - tA * chunks;
+  const int tZ = (ue - 1) / chunks, cZ = (ue - 1) - tZ * chunks;
+  int LT = 0, LH = cnt;  // a range inside one tile runs as a single "head" segment
+  if (tA != tZ) {
+    LT = (cZ != chunks - 1) ? cZ + 1 : 0;
+    LH = (cA != 0) ? chunks - cA : 0;
+  }
+  const int NF = cnt - LT - LH;
+  const int tF = tA + ((LH > 0 && tA != tZ) ? 1 : 0);
 
-  // every role walks the same (tile, chunk) sequence, so the seg_end barriers always match
-  const int tile0 = ub / chunks, chunk0 = ub - tile0 * chunks;
-  // debug stamps: role slots 0 (consumer wave 0), 1 (loader wave 8), 2 (producer wave 10)
-  const int drole = wv == 0 ? 0 : wv == 8 ? 1 : wv == 10 ? 2 : -1;
-  unsigned long long* dbgp = (p.dbg && lane == 0 && drole >= 0) ? p.dbg + ((size_t)blockIdx.x * 3 + drole) * 4 : nullptr;
-  unsigned long long bwait = 0;
-  const unsigned long long tstart = dbgp ? __builtin_amdgcn_s_memtime() : 0;
-  auto group_of = [&](int c) -> int { return p.gshift >= 0 ? (c >> p.gshift) : (c / p.gdiv); };
+  // The unit table: one 16-B entry per unit of this workgroup, in execution order, built once by
+  // all threads.  Every role then gets the offsets of "its" unit with one broadcast ds_read_b128
+  // instead of carrying the (tile, chunk) arithmetic in its instruction stream.
+  //   .x weight byte offset of (tile row 0, chunk)   .y scale byte offset of (tile row 0, group)
+  //   .z activation byte offset of the chunk          .w seg_end | chunk << 1 | tile << 13
+  i32x4* tab = reinterpret_cast<i32x4*>(lds + V2_OFF_T);
+  for (int v = tid; v < cnt; v += V2_THREADS) {
+    int t, c;
+    if (v < LT) {
+      t = tZ;
+      c = v;
+    } else if (v < LT + NF) {
+      const int q = v - LT;
+      const int dq = q / chunks;
+      t = tF + dq;
+      c = q - dq * chunks;
+    } else {
+      t = tA;
+      c = cA + (v - LT - NF);
+    }
+    const int se = (c == chunks - 1) | (v == LT - 1) | (v == cnt - 1);
+    i32x4 e;
+    e.x = (int)((uint32_t)t * (uint32_t)(V2_BN * 4) * (uint32_t)p.w_stride + (uint32_t)c * 64u);
+    e.y = (int)((uint32_t)t * (uint32_t)(V2_BN * 4) * (uint32_t)p.s_stride + (uint32_t)(c >> p.gshift) * 4u);
+    e.z = c * (V2_CK * 2);
+    e.w = se | (c << 1) | (t << 13);
+    tab[v] = e;
+  }
+  __syncthreads();
+  const int last = cnt - 1;
+#define V2_ENTRY(V) tab[(V) < last ? (V) : last]  // sticks on the last unit past the end
 
   if (wv >= 10) {
     // =============================== activation producers =============================== //
-    const int half = wv - 10;  // rows half*32 .. +31
+    // rows half*32 .. +31 of the [64 x 128] fp16 x-tile; lane = (row sub 0..3, 16-B column 0..15)
+    const int half = wv - 10;
     const int xcol = lane & 15, xrsub = lane >> 4;
-    int pu = ub, ptile = tile0, pchunk = chunk0;
-    int64_t pm0 = (int64_t)(ptile / p.nblocks) * V2_BM;
     uint32_t roff[8];
-    auto set_rows = [&]() {
 #pragma unroll
-      for (int j = 0; j < 8; ++j) {
-        const int64_t row = pm0 + half * 32 + j * 4 + xrsub;
-        const int64_t rc = row < p.m ? row : p.m - 1;  // rows >= M feed only unstored outputs
-        roff[j] = (uint32_t)(rc * p.x_stride * 2);
-      }
-    };
-    set_rows();
-    auto advance = [&]() {
-      if (pu + 1 < ue) {
-        ++pu;
-        if (++pchunk == chunks) {
-          pchunk = 0;
-          ++ptile;
-          const int64_t nm0 = (int64_t)(ptile / p.nblocks) * V2_BM;
-          if (nm0 != pm0) {
-            pm0 = nm0;
-            set_rows();
-          }
-        }
-      }
-    };
+    for (int j = 0; j < 8; ++j) {
+      const int64_t row = half * 32 + j * 4 + xrsub;
+      const int64_t rc = row < p.m ? row : p.m - 1;  // rows >= M feed only unstored outputs
+      roff[j] = (uint32_t)(rc * p.x_stride * 2 + xcol * 16);
+    }
     const unsigned char* xbase = (const unsigned char*)p.x;
     const uint32_t lds_lane = (uint32_t)((half * 32 + xrsub) * V2_A_ROW + xcol * 16);
+    int lv = 0;  // load position
+    int xo = V2_ENTRY(0).z;
 #define V2_DECL_X(P) i32x4 P##0, P##1, P##2, P##3, P##4, P##5, P##6, P##7
-#define V2_LOAD_X1(P, J) P##J = *reinterpret_cast<const i32x4*>(xbase + (roff[J] + kc_));
-#define V2_LOAD_X(P)                                                                        \
-  if (!(p.ablate & 1)) {                                                                    \
-    const int kk_ = pchunk * V2_CK + xcol * 8;                                              \
-    const uint32_t kc_ = (uint32_t)(kk_ < K ? kk_ : K - 8) * 2; /* k tail: weights zeroed */ \
-    V2_LOAD_X1(P, 0) V2_LOAD_X1(P, 1) V2_LOAD_X1(P, 2) V2_LOAD_X1(P, 3)                     \
-    V2_LOAD_X1(P, 4) V2_LOAD_X1(P, 5) V2_LOAD_X1(P, 6) V2_LOAD_X1(P, 7)                     \
-    advance();                                                                              \
-  } else { advance(); }
+#define V2_LOAD_X1(P, J) if constexpr (!(ABL & 1)) P##J = *reinterpret_cast<const i32x4*>(xbase + (roff[J] + (uint32_t)xo));
+#define V2_LOAD_X(P)                                                    \
+  {                                                                     \
+    V2_LOAD_X1(P, 0) V2_LOAD_X1(P, 1) V2_LOAD_X1(P, 2) V2_LOAD_X1(P, 3) \
+    V2_LOAD_X1(P, 4) V2_LOAD_X1(P, 5) V2_LOAD_X1(P, 6) V2_LOAD_X1(P, 7) \
+    ++lv;                                                               \
+    xo = V2_ENTRY(lv).z;                                                \
+  }
 // [h0..h7] -> (h0,h4) (h1,h5) (h2,h6) (h3,h7): the nibble pairing of the dequant
 #define V2_STORE_X1(P, J, DST)                                                       \
   {                                                                                  \
@@ -187,108 +209,93 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     V2_STORE_X1(P, 0, dst_) V2_STORE_X1(P, 1, dst_) V2_STORE_X1(P, 2, dst_) V2_STORE_X1(P, 3, dst_) \
     V2_STORE_X1(P, 4, dst_) V2_STORE_X1(P, 5, dst_) V2_STORE_X1(P, 6, dst_) V2_STORE_X1(P, 7, dst_) \
   }
-    // Three rotating register sets: a tile is loaded THREE units before it is stored (the x
-    // loads queue behind the HBM weight stream in the CU's memory pipeline, so their latency
-    // is HBM-like even though x is L2-resident), and stored two units before it is consumed.
+    // Three rotating register sets: a tile is loaded three units before it is stored and stored
+    // two units before it is consumed (the x loads queue behind the HBM weight stream in the
+    // CU's memory pipeline, so their latency is HBM-like even though x is L2-resident).
     V2_DECL_X(xa);
     V2_DECL_X(xb);
     V2_DECL_X(xc);
-    V2_LOAD_X(xa)  // unit ub
-    V2_LOAD_X(xb)  // unit ub + 1
-    V2_LOAD_X(xc)  // unit ub + 2
+    V2_LOAD_X(xa)  // unit 0
+    V2_LOAD_X(xb)  // unit 1
+    V2_LOAD_X(xc)  // unit 2
     V2_STORE_X(xa, 0)
     V2_STORE_X(xb, 1)
-    V2_LOAD_X(xa)  // unit ub + 3
-    V2_LOAD_X(xb)  // unit ub + 4
+    V2_LOAD_X(xa)  // unit 3
+    V2_LOAD_X(xb)  // unit 4
     __syncthreads();
-    const unsigned long long tpro = dbgp ? __builtin_amdgcn_s_memtime() : 0;
     int wbuf = 2;
-    int tile = tile0, chunk = chunk0;
-    int u = ub;
-#define V2_PRODUCER_STEP(P)                                 \
-  V2_STORE_X(P, wbuf) /* unit u + 2 */                      \
-  V2_LOAD_X(P)        /* unit u + 5 */                      \
-  wbuf = wbuf == V2_XR - 1 ? 0 : wbuf + 1;                  \
-  V2_TBAR()                                                 \
-  if (chunk == chunks - 1 || u + 1 >= ue) {                 \
-    __syncthreads(); /* the consumers' k-half reduction */  \
-    chunk = 0;                                              \
-    ++tile;                                                 \
-  } else {                                                  \
-    ++chunk;                                                \
-  }                                                         \
-  ++u;                                                      \
-  if (u >= ue) break;
-    for (;;) {
+    int cv = 0;  // the unit the consumers are on (barrier schedule)
+#define V2_PRODUCER_STEP(P)                                                   \
+  {                                                                           \
+    const int fl_ = __builtin_amdgcn_readfirstlane(tab[cv].w);                \
+    V2_STORE_X(P, wbuf) /* unit v + 2 */                                      \
+    V2_LOAD_X(P)        /* unit v + 5 */                                      \
+    wbuf = wbuf == V2_XR - 1 ? 0 : wbuf + 1;                                  \
+    __syncthreads();                                                          \
+    if (fl_ & 1) __syncthreads(); /* the consumers' k-half reduction */       \
+    ++cv;                                                                     \
+  }
+    // full rotations in a single-exit loop (a break between steps made hipcc drain vmcnt(0)),
+    // then the 0-2 leftover steps
+    for (int it = cnt / 3; it > 0; --it) {
       V2_PRODUCER_STEP(xc)
       V2_PRODUCER_STEP(xa)
       V2_PRODUCER_STEP(xb)
     }
+    if (cv < cnt) V2_PRODUCER_STEP(xc)
+    if (cv < cnt) V2_PRODUCER_STEP(xa)
 #undef V2_PRODUCER_STEP
-    if (dbgp) { dbgp[0] = tpro - tstart; dbgp[1] = __builtin_amdgcn_s_memtime() - tpro; dbgp[2] = bwait; dbgp[3] = ue - ub; }
     return;
   }
 
   if (wv >= 8) {
     // ================================== weight loaders ================================== //
-    const int half = wv - 8;                    // rows half*64 .. +63
+    const int half = wv - 8;                       // rows half*64 .. +63
     const int piece = lane & 3, rsub = lane >> 2;  // 4 lanes x 16 B = the unit's 64-B row slice
-    int lu = ub, ltile = tile0, lchunk = chunk0;
-    const unsigned char* wrow[4];
-    int64_t srow;  // scale row of this lane (row half*64 + lane)
-    auto set_tile = [&](int t) {
-      const int nb = t % p.nblocks;
+    uint32_t woff[4];                              // byte offsets relative to (tile row 0, chunk 0)
+    int st_off[4];
 #pragma unroll
-      for (int q = 0; q < 4; ++q) {
-        int64_t r = (int64_t)nb * V2_BN + half * 64 + q * 16 + rsub;
-        if (r >= p.n) r = p.n - 1;
-        wrow[q] = (const unsigned char*)p.w + r * p.w_stride * 4 + piece * 16;
-      }
-      srow = (int64_t)nb * V2_BN + half * 64 + lane;
-      if (srow >= p.n) srow = p.n - 1;
-    };
-    set_tile(ltile);
-    auto advance = [&]() {
-      if (lu + 1 < ue) {
-        ++lu;
-        if (++lchunk == chunks) {
-          lchunk = 0;
-          ++ltile;
-          set_tile(ltile);
-        }
-      }
-    };
+    for (int q = 0; q < 4; ++q) {
+      const int r = half * 64 + q * 16 + rsub;
+      woff[q] = (uint32_t)((int64_t)r * p.w_stride * 4 + piece * 16);
+      st_off[q] = v2_wslot(r, piece);
+    }
+    const uint32_t soff = (uint32_t)((int64_t)(half * 64 + lane) * p.s_stride * 4);
+    const unsigned char* wbase = (const unsigned char*)p.w;
+    const unsigned char* sbase = (const unsigned char*)p.scales;
+    const unsigned char* zbase = (const unsigned char*)p.zeros;
+    int lv = 0;  // load position
+    i32x4 le = V2_ENTRY(0);
     // NOTE: plain scalars + macros on purpose -- structs/arrays passed through lambdas ended up
     // in scratch memory (hipcc did not promote them to registers).
 #define V2_DECL_W(P) i32x4 P##0, P##1, P##2, P##3; float P##s, P##z
-#define V2_LOAD_W(P)                                                        \
-  if (!(p.ablate & 2)) {                                                    \
-    const int kb_ = lchunk * 64; /* byte offset of the unit in the row */   \
-    P##0 = *reinterpret_cast<const i32x4*>(wrow[0] + kb_);                     \
-    P##1 = *reinterpret_cast<const i32x4*>(wrow[1] + kb_);                     \
-    P##2 = *reinterpret_cast<const i32x4*>(wrow[2] + kb_);                     \
-    P##3 = *reinterpret_cast<const i32x4*>(wrow[3] + kb_);                     \
-    const int gi_ = group_of(lchunk);                                       \
-    P##s = p.scales[srow * p.s_stride + gi_];                               \
-    P##z = p.zeros[srow * p.s_stride + gi_];                                \
-    advance();                                                              \
-  } else { advance(); }
+#define V2_LOAD_W(P)                                                                     \
+  {                                                                                      \
+    const uint32_t wo_ = (uint32_t)le.x, so_ = (uint32_t)le.y + soff;                    \
+    if constexpr (!(ABL & 2)) {                                                          \
+    P##0 = *reinterpret_cast<const i32x4*>(wbase + (wo_ + woff[0]));                     \
+    P##1 = *reinterpret_cast<const i32x4*>(wbase + (wo_ + woff[1]));                     \
+    P##2 = *reinterpret_cast<const i32x4*>(wbase + (wo_ + woff[2]));                     \
+    P##3 = *reinterpret_cast<const i32x4*>(wbase + (wo_ + woff[3]));                     \
+    P##s = *reinterpret_cast<const float*>(sbase + so_);                                 \
+    P##z = *reinterpret_cast<const float*>(zbase + so_);                                 \
+    }                                                                                    \
+    ++lv;                                                                                \
+    le = V2_ENTRY(lv);                                                                   \
+  }
 #define V2_STORE_W(P, SLOT)                                                               \
   {                                                                                       \
     unsigned char* wt_ = lds + V2_OFF_W + (SLOT) * 8192;                                  \
-    *reinterpret_cast<i32x4*>(wt_ + st_off[0]) = P##0;                                       \
-    *reinterpret_cast<i32x4*>(wt_ + st_off[1]) = P##1;                                       \
-    *reinterpret_cast<i32x4*>(wt_ + st_off[2]) = P##2;                                       \
-    *reinterpret_cast<i32x4*>(wt_ + st_off[3]) = P##3;                                       \
+    *reinterpret_cast<i32x4*>(wt_ + st_off[0]) = P##0;                                    \
+    *reinterpret_cast<i32x4*>(wt_ + st_off[1]) = P##1;                                    \
+    *reinterpret_cast<i32x4*>(wt_ + st_off[2]) = P##2;                                    \
+    *reinterpret_cast<i32x4*>(wt_ + st_off[3]) = P##3;                                    \
     uint2 sz_; /* (s, -z*s) as packed fp16 pairs: one fp32 product, one rounding */       \
     sz_.x = v2_bcast(P##s);                                                               \
     sz_.y = v2_bcast(-P##z * P##s);                                                       \
     *reinterpret_cast<uint2*>(lds + V2_OFF_S + (SLOT) * 1024 + (half * 64 + lane) * 8) = sz_; \
   }
-    int st_off[4];
-#pragma unroll
-    for (int q = 0; q < 4; ++q) st_off[q] = v2_wslot(half * 64 + q * 16 + rsub, piece);
-    // prologue: units ub .. ub+D+PF-1 in one round trip
+    // prologue: units 0 .. D+PF-1 in one round trip
     V2_DECL_W(t0);
     V2_DECL_W(t1);
     V2_DECL_W(w0);
@@ -308,25 +315,19 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     V2_STORE_W(t0, 0)
     V2_STORE_W(t1, 1)
     __syncthreads();
-    const unsigned long long tpro = dbgp ? __builtin_amdgcn_s_memtime() : 0;
     int wslot = V2_D % V2_RW;
-    int tile = tile0, chunk = chunk0;
-    int u = ub;
-#define V2_LOADER_STEP(P)                                   \
-  V2_STORE_W(P, wslot) /* unit u + D */                     \
-  V2_LOAD_W(P)         /* unit u + D + PF */                \
-  wslot = wslot == V2_RW - 1 ? 0 : wslot + 1;               \
-  V2_TBAR()                                                 \
-  if (chunk == chunks - 1 || u + 1 >= ue) {                 \
-    __syncthreads();                                        \
-    chunk = 0;                                              \
-    ++tile;                                                 \
-  } else {                                                  \
-    ++chunk;                                                \
-  }                                                         \
-  ++u;                                                      \
-  if (u >= ue) break;
-    for (;;) {
+    int cv = 0;
+#define V2_LOADER_STEP(P)                                                     \
+  {                                                                           \
+    const int fl_ = __builtin_amdgcn_readfirstlane(tab[cv].w);                \
+    V2_STORE_W(P, wslot) /* unit v + D */                                     \
+    V2_LOAD_W(P)         /* unit v + D + PF */                                \
+    wslot = wslot == V2_RW - 1 ? 0 : wslot + 1;                               \
+    __syncthreads();                                                          \
+    if (fl_ & 1) __syncthreads();                                             \
+    ++cv;                                                                     \
+  }
+    for (int it = cnt / 6; it > 0; --it) {
       V2_LOADER_STEP(w0)
       V2_LOADER_STEP(w1)
       V2_LOADER_STEP(w2)
@@ -334,7 +335,11 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       V2_LOADER_STEP(w4)
       V2_LOADER_STEP(w5)
     }
-    if (dbgp) { dbgp[0] = tpro - tstart; dbgp[1] = __builtin_amdgcn_s_memtime() - tpro; dbgp[2] = bwait; dbgp[3] = ue - ub; }
+    if (cv < cnt) V2_LOADER_STEP(w0)
+    if (cv < cnt) V2_LOADER_STEP(w1)
+    if (cv < cnt) V2_LOADER_STEP(w2)
+    if (cv < cnt) V2_LOADER_STEP(w3)
+    if (cv < cnt) V2_LOADER_STEP(w4)
 #undef V2_LOADER_STEP
 #undef V2_STORE_W
 #undef V2_LOAD_W
@@ -364,13 +369,20 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   const int soff = wrow_l * 8;
   const int aoff = nl * V2_A_ROW + kh * 128 + h * 64;
 
+  // contribution flag of a parked partial, posted once its write-through stores have landed
+  int32_t* pend_ctr = nullptr;
+  int pend_val = 0;
+  auto post_pending = [&]() {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    if (lane == 0) __hip_atomic_fetch_add(pend_ctr, pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pend_ctr = nullptr;
+  };
+
   auto flush = [&](int t, int c_lo, int c_hi) {
-    const int mblk = t / p.nblocks, nb = t - mblk * p.nblocks;
-    const int64_t m0 = (int64_t)mblk * V2_BM;
-    const bool full = (c_lo == 0 && c_hi == chunks - 1);
-    if (!full) {
-      const int w0 = (int)(((int64_t)t * chunks) / p.upw);
-      const int slot = (int)blockIdx.x - w0;
+    const int w0 = (int)(((int64_t)t * chunks) / p.upw);  // first contributor of the tile
+    const int slot = (int)blockIdx.x - w0;
+    if (c_hi != chunks - 1) {
+      // contributor: park the partial in this workgroup's slab (flag follows, see post_pending)
       float* ws = p.workspace + (((int64_t)t * p.slots + slot) * 4 + ng) * (V2_SLAB / 4);
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt)
@@ -378,97 +390,110 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         for (int g = 0; g < 4; ++g) {
           const f32x4 v = {acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
           float* dst = ws + ((mt * 4 + g) * 64 + lane) * 4;
-          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
+          if constexpr (!(ABL & 16))
+            asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(v) : "memory");
         }
-      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      int old = 0;
-      if (lane == 0)
-        old = __hip_atomic_fetch_add(&p.counters[t * 4 + ng], c_hi - c_lo + 1, __ATOMIC_RELAXED,
-                                     __HIP_MEMORY_SCOPE_AGENT);
-      old = __builtin_amdgcn_readfirstlane(old);
-      if (old + (c_hi - c_lo + 1) != chunks) return;
-      if (lane == 0)
-        __hip_atomic_store(&p.counters[t * 4 + ng], 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-      __builtin_amdgcn_fence(__ATOMIC_ACQUIRE, "agent");
-      zero_acc();
-      const int w1 = (int)((((int64_t)t + 1) * chunks - 1) / p.upw);
-      for (int sl = 0; sl <= w1 - w0; ++sl) {
-        const float* wr = p.workspace + (((int64_t)t * p.slots + sl) * 4 + ng) * (V2_SLAB / 4);
+      pend_ctr = &p.counters[t * 4 + ng];
+      pend_val = c_hi - c_lo + 1;
+      return;
+    }
+    if (c_lo != 0 && !(ABL & 32)) {
+      // owner: chunks [0, c_lo) were computed by the `slot` earlier contributors
+      int32_t* ctr = &p.counters[t * 4 + ng];
+      for (;;) {
+        const int seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if (__builtin_amdgcn_readfirstlane(seen) == c_lo) break;
+        __builtin_amdgcn_s_sleep(4);
+      }
+      if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      // The slabs were written through to memory (sc1 stores) before their flag; read them with
+      // agent-coherent (sc1) loads instead of paying an acquire fence (buffer_inv sc1, ~4 us when
+      // every CU does it at once).  Two slabs in flight; the second of an odd tail is masked to +0.
+      for (int sl = 0; sl < slot; sl += 2) {
+        const int sl2 = sl + 1 < slot ? sl + 1 : sl;
+        const int keep = sl + 1 < slot ? -1 : 0;
+        const float* wa = p.workspace + (((int64_t)t * p.slots + sl) * 4 + ng) * (V2_SLAB / 4) + lane * 4;
+        const float* wb = p.workspace + (((int64_t)t * p.slots + sl2) * 4 + ng) * (V2_SLAB / 4) + lane * 4;
+        i32x4 va[MT * 4], vb[MT * 4];
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) {
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(va[i]) : "v"(wa + i * 256) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(vb[i]) : "v"(wb + i * 256) : "memory");
+        }
+        asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+#pragma unroll
+        for (int i = 0; i < MT * 4; ++i) asm volatile("" : "+v"(va[i]), "+v"(vb[i]));  // uses stay below the wait
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) {
-            const f32x4 v = *reinterpret_cast<const f32x4*>(wr + ((mt * 4 + g) * 64 + lane) * 4);
+          for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) acc[mt][4 * g + e] += v[e];
-          }
+            for (int e = 0; e < 4; ++e) {
+              acc[mt][4 * g + e] += __int_as_float(va[mt * 4 + g][e]);
+              acc[mt][4 * g + e] += __int_as_float(vb[mt * 4 + g][e] & keep);
+            }
       }
     }
     const bool has_bias = p.bias != nullptr;
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
-      const int64_t mrow = m0 + nl + mt * 32;
+      const int64_t mrow = nl + mt * 32;
       if (mrow >= p.m) continue;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int64_t nn = (int64_t)nb * V2_BN + ng * 32 + 8 * g + 4 * h;
+        const int64_t nn = (int64_t)t * V2_BN + ng * 32 + 8 * g + 4 * h;
         uint16_t o[4];
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const int64_t nc = (nn + e) < p.n ? (nn + e) : (p.n - 1);
           float v = acc[mt][4 * g + e];
-          if (has_bias) v += f16_bits_to_f32(p.bias[nc]);
+          if (has_bias) v += f16_bits_to_f32(p.bias[nn + e]);
           o[e] = f32_to_f16_bits(v);
         }
-        if (nn + 3 < p.n && (p.n & 3) == 0) {
-          uint2 pk;
-          pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-          pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-          *reinterpret_cast<uint2*>(p.out + mrow * p.n + nn) = pk;
-        } else {
-#pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (nn + e < p.n) p.out[mrow * p.n + nn + e] = o[e];
-        }
+        uint2 pk;
+        pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+        pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+        *reinterpret_cast<uint2*>(p.out + mrow * p.n + nn) = pk;
       }
     }
   };
 
-  __syncthreads();  // prologue barrier: units ub, ub+1 staged
-  const unsigned long long tpro = dbgp ? __builtin_amdgcn_s_memtime() : 0;
-  unsigned long long tflush = 0;
-  int tile = tile0, chunk = chunk0, seg_lo = chunk0;
+  int cv = 0;
+  int seg_lo = (tab[0].w >> 1) & 0xFFF;
   int rbuf = 0, wslot = 0;
-  for (int u = ub; u < ue; ++u) {
-    if (!(p.ablate & 4)) {
-    const unsigned char* wt = lds + V2_OFF_W + wslot * 8192;
-    const Q4 wq = *reinterpret_cast<const Q4*>(wt + woff);
-    const uint2 sz = *reinterpret_cast<const uint2*>(lds + V2_OFF_S + wslot * 1024 + soff);
-    const unsigned char* ab = lds + V2_OFF_A + rbuf * V2_A_TILE + aoff;
-    f16x8 acur[MT], anxt[MT];
+  __syncthreads();  // prologue barrier: units 0, 1 staged
+  for (;;) {
+    if constexpr (!(ABL & 4)) {
+      const unsigned char* wt = lds + V2_OFF_W + wslot * 8192;
+      const Q4 wq = *reinterpret_cast<const Q4*>(wt + woff);
+      const uint2 sz = *reinterpret_cast<const uint2*>(lds + V2_OFF_S + wslot * 1024 + soff);
+      const unsigned char* ab = lds + V2_OFF_A + rbuf * V2_A_TILE + aoff;
+      f16x8 acur[MT], anxt[MT];
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) acur[mt] = *reinterpret_cast<const f16x8*>(ab + mt * 32 * V2_A_ROW);
+      for (int mt = 0; mt < MT; ++mt) acur[mt] = *reinterpret_cast<const f16x8*>(ab + mt * 32 * V2_A_ROW);
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      if (s + 1 < 4) {
+      for (int s = 0; s < 4; ++s) {
+        if (s + 1 < 4) {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            anxt[mt] = *reinterpret_cast<const f16x8*>(ab + mt * 32 * V2_A_ROW + (s + 1) * 16);
+        }
+        const uint32_t word = s == 0 ? wq.x : s == 1 ? wq.y : s == 2 ? wq.z : wq.w;
+        const Q4 wf = v2_dequant(word, sz.x, sz.y, magic);
+        const f16x8 wfrag = __builtin_bit_cast(f16x8, wf);
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
-          anxt[mt] = *reinterpret_cast<const f16x8*>(ab + mt * 32 * V2_A_ROW + (s + 1) * 16);
+          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, acur[mt], acc[mt], 0, 0, 0);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) acur[mt] = anxt[mt];
       }
-      const uint32_t word = s == 0 ? wq.x : s == 1 ? wq.y : s == 2 ? wq.z : wq.w;
-      const Q4 wf = v2_dequant(word, sz.x, sz.y, magic);
-      const f16x8 wfrag = __builtin_bit_cast(f16x8, wf);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, acur[mt], acc[mt], 0, 0, 0);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acur[mt] = anxt[mt];
-    }
     }
     rbuf = rbuf == V2_XR - 1 ? 0 : rbuf + 1;
     wslot = wslot == V2_RW - 1 ? 0 : wslot + 1;
-    V2_TBAR()
-    if (chunk == chunks - 1 || u + 1 >= ue) {
+    __syncthreads();
+    if (pend_ctr) post_pending();  // the previous segment's slab stores are a unit old by now
+    const int fl = __builtin_amdgcn_readfirstlane(tab[cv].w);
+    const bool se = fl & 1;
+    if (se) {
       // sum the two k-halves through LDS, then the kh = 0 wave flushes the tile segment
       float* red = reinterpret_cast<float*>(lds + V2_OFF_R + ng * 8192);
       if (kh == 1) {
@@ -480,7 +505,6 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
                 f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
       }
       __syncthreads();
-      const unsigned long long f0 = dbgp ? __builtin_amdgcn_s_memtime() : 0;
       if (kh == 0) {
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt)
@@ -490,25 +514,21 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 #pragma unroll
             for (int e = 0; e < 4; ++e) acc[mt][4 * g + e] += v[e];
           }
-        flush(tile, seg_lo, chunk);
+        if constexpr (!(ABL & 8)) flush(fl >> 13, seg_lo, (fl >> 1) & 0xFFF);
       }
-      if (dbgp) { asm volatile("s_waitcnt vmcnt(0)" ::: "memory"); tflush += __builtin_amdgcn_s_memtime() - f0; }
       zero_acc();
-      chunk = 0;
-      seg_lo = 0;
-      ++tile;
-    } else {
-      ++chunk;
     }
+    if (++cv >= cnt) break;
+    if (se) seg_lo = (__builtin_amdgcn_readfirstlane(tab[cv].w) >> 1) & 0xFFF;
   }
-  if (dbgp) { dbgp[0] = tpro - tstart; dbgp[1] = __builtin_amdgcn_s_memtime() - tpro; dbgp[2] = bwait; dbgp[3] = tflush; }
+  if (pend_ctr) post_pending();
 }
 
 // ---------------------------------------------------------------------------------- //
 // host side
 // ---------------------------------------------------------------------------------- //
 struct V2Plan {
-  int mblocks, nblocks, chunks, total_units, upw, grid, slots;
+  int nblocks, chunks, total_units, upw, grid, slots;
 };
 
 static int v2_num_cus() {
@@ -523,18 +543,18 @@ static int v2_num_cus() {
   return cus;
 }
 
-static V2Plan v2_plan(int64_t m, int64_t n, int64_t k) {
+static V2Plan v2_plan(int64_t n, int64_t k) {
   V2Plan pl;
-  pl.mblocks = (int)((m + V2_BM - 1) / V2_BM);
-  pl.nblocks = (int)((n + V2_BN - 1) / V2_BN);
-  pl.chunks = (int)((k + V2_CK - 1) / V2_CK);
-  pl.total_units = pl.mblocks * pl.nblocks * pl.chunks;
+  pl.nblocks = (int)(n / V2_BN);
+  pl.chunks = (int)(k / V2_CK);
+  pl.total_units = pl.nblocks * pl.chunks;
   int target = v2_num_cus();  // one persistent 12-wave workgroup per CU
   if (const char* e = getenv("LL_GEMM2_WGS")) {
     const int v = atoi(e);
     if (v > 0) target = v;
   }
   int upw = (pl.total_units + target - 1) / target;
+  // a tile has at most (chunks - 2) / upw + 2 contributors
   const int min_upw = (pl.chunks + (V2_MAX_SLOTS - 2) - 1) / (V2_MAX_SLOTS - 2);
   if (upw < min_upw) upw = min_upw;
   if (upw < 2) upw = 2;
@@ -546,25 +566,35 @@ static V2Plan v2_plan(int64_t m, int64_t n, int64_t k) {
   return pl;
 }
 
-// exported for gemm_wq.hip's dispatcher
-extern "C" int ll_w4a16_v2_workspace(int64_t m, int64_t n, int64_t k, int64_t* floats, int64_t* ints) {
-  const V2Plan pl = v2_plan(m, n, k);
-  const int64_t tiles = (int64_t)pl.mblocks * pl.nblocks;
-  if (floats) *floats = tiles * pl.slots * V2_SLAB;
-  if (ints) *ints = tiles * 4;
-  return LL_OK;
+static bool v2_shape_ok(int64_t m, int64_t n, int64_t k) {
+  if (!((m >= 1) && (m <= V2_BM) && (n >= V2_BN) && (n % V2_BN == 0) && (k >= V2_CK) && (k % V2_CK == 0)))
+    return false;
+  if (n * k / 2 >= (1ll << 31) || k / V2_CK > 4095 || n / V2_BN >= (1 << 18)) return false;  // 32-bit table fields
+  return v2_plan(n, k).upw <= V2_MAX_UNITS;
 }
 
+// exported for gemm_wq.hip's dispatcher
 extern "C" int ll_w4a16_v2_supported(int64_t m, int64_t n, int64_t k, int group_size) {
   if (getenv("LL_GEMM_V1")) return 0;
-  return (group_size % 128 == 0) && (k % 128 == 0) && (n >= 1) && (m >= 1);
+  const int gdiv = group_size / 128;
+  return v2_shape_ok(m, n, k) && (group_size % 128 == 0) && ((gdiv & (gdiv - 1)) == 0);
+}
+
+extern "C" int ll_w4a16_v2_workspace(int64_t m, int64_t n, int64_t k, int64_t* floats, int64_t* ints) {
+  if (floats) *floats = 0;
+  if (ints) *ints = 0;
+  if (!v2_shape_ok(m, n, k)) return LL_OK;
+  const V2Plan pl = v2_plan(n, k);
+  if (floats) *floats = (int64_t)pl.nblocks * pl.slots * V2_SLAB;
+  if (ints) *ints = (int64_t)pl.nblocks * 4;
+  return LL_OK;
 }
 
 extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweight, const float* scales,
                                   const float* zeros, const void* bias, int64_t m, int64_t n, int64_t k,
                                   int group_size, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
                                   float* workspace, int32_t* counters, void* stream) {
-  const V2Plan pl = v2_plan(m, n, k);
+  const V2Plan pl = v2_plan(n, k);
   V2Params p{};
   p.out = (uint16_t*)out; p.x = (const uint16_t*)x; p.w = (const uint32_t*)qweight; p.scales = scales;
   p.zeros = zeros; p.bias = (const uint16_t*)bias; p.workspace = workspace; p.counters = counters;
@@ -577,19 +607,41 @@ extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweig
     while ((1 << sh) < p.gdiv) ++sh;
     p.gshift = sh;
   }
-  p.dbg = nullptr;
-  p.ablate = getenv("LL_GEMM2_ABLATE") ? atoi(getenv("LL_GEMM2_ABLATE")) : 0;
-  if (const char* e = getenv("LL_GEMM_TRACE")) p.dbg = (unsigned long long*)strtoull(e, nullptr, 0);
-  static bool attr_set = false;
-  if (!attr_set) {
-    hipFuncSetAttribute((const void*)wgemm2_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES);
-    hipFuncSetAttribute((const void*)wgemm2_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES);
-    attr_set = true;
-  }
   hipStream_t st = (hipStream_t)stream;
-  if (m <= 32)
-    wgemm2_kernel<1><<<dim3((unsigned)pl.grid), V2_THREADS, V2_LDS_BYTES, st>>>(p);
-  else
-    wgemm2_kernel<2><<<dim3((unsigned)pl.grid), V2_THREADS, V2_LDS_BYTES, st>>>(p);
+#define V2_LAUNCH(ABL)                                                                                          \
+  {                                                                                                             \
+    static bool attr_set = false;                                                                               \
+    if (!attr_set) {                                                                                            \
+      (void)hipFuncSetAttribute((const void*)wgemm2_kernel<1, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                V2_LDS_BYTES);                                                                  \
+      (void)hipFuncSetAttribute((const void*)wgemm2_kernel<2, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
+                                V2_LDS_BYTES);                                                                  \
+      attr_set = true;                                                                                          \
+    }                                                                                                           \
+    if (m <= 32)                                                                                                \
+      wgemm2_kernel<1, ABL><<<dim3((unsigned)pl.grid), V2_THREADS, V2_LDS_BYTES, st>>>(p);                      \
+    else                                                                                                        \
+      wgemm2_kernel<2, ABL><<<dim3((unsigned)pl.grid), V2_THREADS, V2_LDS_BYTES, st>>>(p);                      \
+  }
+#ifdef V2_DEBUG_ABLATE
+  const int abl = getenv("LL_GEMM2_ABLATE") ? atoi(getenv("LL_GEMM2_ABLATE")) : 0;
+  switch (abl) {
+    case 1: V2_LAUNCH(1) break;
+    case 2: V2_LAUNCH(2) break;
+    case 3: V2_LAUNCH(3) break;
+    case 4: V2_LAUNCH(4) break;
+    case 7: V2_LAUNCH(7) break;
+    case 8: V2_LAUNCH(8) break;
+    case 12: V2_LAUNCH(12) break;
+    case 15: V2_LAUNCH(15) break;
+    case 23: V2_LAUNCH(23) break;
+    case 39: V2_LAUNCH(39) break;
+    case 55: V2_LAUNCH(55) break;
+    case 71: V2_LAUNCH(71) break;
+    default: V2_LAUNCH(0) break;
+  }
+#else
+  V2_LAUNCH(0)
+#endif
   return LL_LAUNCH_CHECK();
 }
