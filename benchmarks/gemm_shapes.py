@@ -16,13 +16,17 @@ for name, n, k in shapes:
            torch.rand(n, k // 128, device=dev) * 0.01 + 0.005,
            torch.randint(0, 16, (n, k // 128), device=dev).float()) for _ in range(copies)]
     x = torch.randn(M, k, device=dev, dtype=torch.float16)
-    K.w4a16_matmul(x, *ws[0], group_size=128)
+    packed = [None] * copies
+    if os.environ.get("PACKED", "1") == "1":
+        from lite_llama_amd.kernels.quantization import pack_w4a16_scales
+        packed = [pack_w4a16_scales(w[1], w[2]) for w in ws]
+    K.w4a16_matmul(x, *ws[0], group_size=128, packed_scales=packed[0])
     torch.cuda.synchronize()
     reps = max(copies, 16)
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
         for i in range(reps):
-            K.w4a16_matmul(x, *ws[i % copies], group_size=128)
+            K.w4a16_matmul(x, *ws[i % copies], group_size=128, packed_scales=packed[i % copies])
     g.replay()
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)

@@ -119,6 +119,18 @@ int ll_w4a16_matmul(void* out, const void* x, const int32_t* qweight, const floa
                     const float* zeros, const void* bias, int64_t m, int64_t n, int64_t k,
                     int group_size, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
                     float* workspace, int32_t* counters, void* stream);
+/* Load-time companion (no reference counterpart; the reference keeps the fp32 grids only):
+ * packed[g][n] = 8 bytes {fp16 s, fp16 s, fp16 -z*s, fp16 -z*s} -- exactly the pair the GEMM
+ * otherwise derives on the fly, transposed so that one 128-row tile of one group is contiguous.
+ * ll_w4a16_matmul_packed takes it as an optional extra operand (NULL = identical to
+ * ll_w4a16_matmul); results are bit-identical either way. */
+int ll_w4a16_pack_scales(void* packed, const float* scales, const float* zeros, int64_t n,
+                         int64_t groups, int64_t s_stride_n, void* stream);
+int ll_w4a16_matmul_packed(void* out, const void* x, const int32_t* qweight, const float* scales,
+                           const float* zeros, const void* packed_sz, const void* bias, int64_t m,
+                           int64_t n, int64_t k, int group_size, int64_t x_stride_m,
+                           int64_t qw_stride_n, int64_t s_stride_n, float* workspace,
+                           int32_t* counters, void* stream);
 
 /* ---- a9: w8a16_matmul  (kernels/quantization/w8a16.py:155-216) ---------------
  * qweight [N,K] uint8 (fp8-e4m3 bits) or int8; scales fp32 [ceil(N/gn), ceil(K/gk)]. */

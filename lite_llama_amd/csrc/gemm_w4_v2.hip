@@ -47,6 +47,7 @@ struct V2Params {
   const uint32_t* w;
   const float* scales;
   const float* zeros;
+  const void* packed;  // optional [K/g][N] x 8 B (s, -z*s) fp16 pairs, see ll_w4a16_pack_scales
   const uint16_t* bias;
   float* workspace;
   int32_t* counters;
@@ -113,7 +114,7 @@ __device__ __forceinline__ int v2_wslot(int r, int p) { return (r * 4 + (p ^ ((r
 // segment (last chunks of the first tile).  LT / NF / LH = units in each part.
 
 // ABL (debug builds only, -DV2_DEBUG_ABLATE): 1 no x loads, 2 no weight loads, 4 no compute, 8 no flush
-template <int MT, int ABL>
+template <int MT, int PK, int ABL>
 __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgemm2_kernel(const V2Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
@@ -158,7 +159,10 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     const int se = (c == chunks - 1) | (v == LT - 1) | (v == cnt - 1);
     i32x4 e;
     e.x = (int)((uint32_t)t * (uint32_t)(V2_BN * 4) * (uint32_t)p.w_stride + (uint32_t)c * 64u);
-    e.y = (int)((uint32_t)t * (uint32_t)(V2_BN * 4) * (uint32_t)p.s_stride + (uint32_t)(c >> p.gshift) * 4u);
+    if constexpr (PK)
+      e.y = (int)(((uint32_t)(c >> p.gshift) * (uint32_t)p.n + (uint32_t)t * V2_BN) * 8u);
+    else
+      e.y = (int)((uint32_t)t * (uint32_t)(V2_BN * 4) * (uint32_t)p.s_stride + (uint32_t)(c >> p.gshift) * 4u);
     e.z = c * (V2_CK * 2);
     e.w = se | (c << 1) | (t << 13);
     tab[v] = e;
@@ -170,6 +174,9 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   if (wv >= 10) {
     // =============================== activation producers =============================== //
     // rows half*32 .. +31 of the [64 x 128] fp16 x-tile; lane = (row sub 0..3, 16-B column 0..15)
+    // The memory roles have few instructions per unit but every one of them gates the stream:
+    // they outrank the consumers sharing their SIMD.
+    __builtin_amdgcn_s_setprio(3);
     const int half = wv - 10;
     const int xcol = lane & 15, xrsub = lane >> 4;
     uint32_t roff[8];
@@ -250,6 +257,7 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 
   if (wv >= 8) {
     // ================================== weight loaders ================================== //
+    __builtin_amdgcn_s_setprio(3);
     const int half = wv - 8;                       // rows half*64 .. +63
     const int piece = lane & 3, rsub = lane >> 2;  // 4 lanes x 16 B = the unit's 64-B row slice
     uint32_t woff[4];                              // byte offsets relative to (tile row 0, chunk 0)
@@ -260,7 +268,8 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       woff[q] = (uint32_t)((int64_t)r * p.w_stride * 4 + piece * 16);
       st_off[q] = v2_wslot(r, piece);
     }
-    const uint32_t soff = (uint32_t)((int64_t)(half * 64 + lane) * p.s_stride * 4);
+    const uint32_t soff = PK ? (uint32_t)((half * 64 + lane) * 8) : (uint32_t)((int64_t)(half * 64 + lane) * p.s_stride * 4);
+    const unsigned char* pbase = (const unsigned char*)p.packed;
     const unsigned char* wbase = (const unsigned char*)p.w;
     const unsigned char* sbase = (const unsigned char*)p.scales;
     const unsigned char* zbase = (const unsigned char*)p.zeros;
@@ -268,7 +277,7 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     i32x4 le = V2_ENTRY(0);
     // NOTE: plain scalars + macros on purpose -- structs/arrays passed through lambdas ended up
     // in scratch memory (hipcc did not promote them to registers).
-#define V2_DECL_W(P) i32x4 P##0, P##1, P##2, P##3; float P##s, P##z
+#define V2_DECL_W(P) i32x4 P##0, P##1, P##2, P##3; float P##s, P##z; uint2 P##p
 #define V2_LOAD_W(P)                                                                     \
   {                                                                                      \
     const uint32_t wo_ = (uint32_t)le.x, so_ = (uint32_t)le.y + soff;                    \
@@ -277,8 +286,12 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     P##1 = *reinterpret_cast<const i32x4*>(wbase + (wo_ + woff[1]));                     \
     P##2 = *reinterpret_cast<const i32x4*>(wbase + (wo_ + woff[2]));                     \
     P##3 = *reinterpret_cast<const i32x4*>(wbase + (wo_ + woff[3]));                     \
-    P##s = *reinterpret_cast<const float*>(sbase + so_);                                 \
-    P##z = *reinterpret_cast<const float*>(zbase + so_);                                 \
+    if constexpr (PK) {                                                                  \
+      P##p = *reinterpret_cast<const uint2*>(pbase + so_);                               \
+    } else {                                                                             \
+      P##s = *reinterpret_cast<const float*>(sbase + so_);                               \
+      P##z = *reinterpret_cast<const float*>(zbase + so_);                               \
+    }                                                                                    \
     }                                                                                    \
     ++lv;                                                                                \
     le = V2_ENTRY(lv);                                                                   \
@@ -291,8 +304,12 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     *reinterpret_cast<i32x4*>(wt_ + st_off[2]) = P##2;                                    \
     *reinterpret_cast<i32x4*>(wt_ + st_off[3]) = P##3;                                    \
     uint2 sz_; /* (s, -z*s) as packed fp16 pairs: one fp32 product, one rounding */       \
-    sz_.x = v2_bcast(P##s);                                                               \
-    sz_.y = v2_bcast(-P##z * P##s);                                                       \
+    if constexpr (PK) {                                                                   \
+      sz_ = P##p;                                                                         \
+    } else {                                                                              \
+      sz_.x = v2_bcast(P##s);                                                             \
+      sz_.y = v2_bcast(-P##z * P##s);                                                     \
+    }                                                                                     \
     *reinterpret_cast<uint2*>(lds + V2_OFF_S + (SLOT) * 1024 + (half * 64 + lane) * 8) = sz_; \
   }
     // prologue: units 0 .. D+PF-1 in one round trip
@@ -478,11 +495,21 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
             anxt[mt] = *reinterpret_cast<const f16x8*>(ab + mt * 32 * V2_A_ROW + (s + 1) * 16);
         }
         const uint32_t word = s == 0 ? wq.x : s == 1 ? wq.y : s == 2 ? wq.z : wq.w;
-        const Q4 wf = v2_dequant(word, sz.x, sz.y, magic);
+        Q4 wf;
+        if constexpr (ABL & 256) {
+          wf.x = word; wf.y = word ^ sz.x; wf.z = word ^ sz.y; wf.w = word;  // debug: no dequant
+        } else {
+          wf = v2_dequant(word, sz.x, sz.y, magic);
+        }
         const f16x8 wfrag = __builtin_bit_cast(f16x8, wf);
+        if constexpr (ABL & 128) {  // debug: no MFMA
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt)
-          acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, acur[mt], acc[mt], 0, 0, 0);
+          for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(wfrag), "v"(acur[mt]));
+        } else {
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt)
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, acur[mt], acc[mt], 0, 0, 0);
+        }
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acur[mt] = anxt[mt];
       }
@@ -573,6 +600,31 @@ static bool v2_shape_ok(int64_t m, int64_t n, int64_t k) {
   return v2_plan(n, k).upw <= V2_MAX_UNITS;
 }
 
+// (s, -z*s) as fp16 pairs, transposed to [group][row]: a unit's 128 rows become 1 KB contiguous
+// (the fp32 [N, K/g] grids cost 256 scattered 4-B requests per unit -- twice the weight stream's).
+// Same arithmetic as the loader's in-flight conversion: fp32 product, one rounding each.
+__global__ void w4a16_pack_scales_kernel(uint2* packed, const float* scales, const float* zeros, int64_t n,
+                                         int64_t groups, int64_t s_stride) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * groups) return;
+  const int64_t g = i / n, r = i - g * n;
+  const float s = scales[r * s_stride + g], z = zeros[r * s_stride + g];
+  uint2 o;
+  o.x = v2_bcast(s);
+  o.y = v2_bcast(-z * s);
+  packed[i] = o;
+}
+
+extern "C" int ll_w4a16_pack_scales(void* packed, const float* scales, const float* zeros, int64_t n,
+                                    int64_t groups, int64_t s_stride_n, void* stream) {
+  if (n <= 0 || groups <= 0) return LL_ERR_SHAPE;
+  if (!packed || !scales || !zeros) return LL_ERR_ARG;
+  const int64_t total = n * groups;
+  w4a16_pack_scales_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
+      (uint2*)packed, scales, zeros, n, groups, s_stride_n);
+  return LL_LAUNCH_CHECK();
+}
+
 // exported for gemm_wq.hip's dispatcher
 extern "C" int ll_w4a16_v2_supported(int64_t m, int64_t n, int64_t k, int group_size) {
   if (getenv("LL_GEMM_V1")) return 0;
@@ -591,13 +643,13 @@ extern "C" int ll_w4a16_v2_workspace(int64_t m, int64_t n, int64_t k, int64_t* f
 }
 
 extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweight, const float* scales,
-                                  const float* zeros, const void* bias, int64_t m, int64_t n, int64_t k,
+                                  const float* zeros, const void* packed, const void* bias, int64_t m, int64_t n, int64_t k,
                                   int group_size, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
                                   float* workspace, int32_t* counters, void* stream) {
   const V2Plan pl = v2_plan(n, k);
   V2Params p{};
   p.out = (uint16_t*)out; p.x = (const uint16_t*)x; p.w = (const uint32_t*)qweight; p.scales = scales;
-  p.zeros = zeros; p.bias = (const uint16_t*)bias; p.workspace = workspace; p.counters = counters;
+  p.zeros = zeros; p.packed = packed; p.bias = (const uint16_t*)bias; p.workspace = workspace; p.counters = counters;
   p.m = m; p.n = n; p.k = k; p.x_stride = x_stride_m; p.w_stride = qw_stride_n; p.s_stride = s_stride_n;
   p.nblocks = pl.nblocks; p.chunks = pl.chunks; p.total_units = pl.total_units; p.upw = pl.upw; p.slots = pl.slots;
   p.gdiv = group_size / 128;
@@ -608,21 +660,23 @@ extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweig
     p.gshift = sh;
   }
   hipStream_t st = (hipStream_t)stream;
-#define V2_LAUNCH(ABL)                                                                                          \
+#define V2_LAUNCH_PK(PK, ABL)                                                                                   \
   {                                                                                                             \
     static bool attr_set = false;                                                                               \
     if (!attr_set) {                                                                                            \
-      (void)hipFuncSetAttribute((const void*)wgemm2_kernel<1, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                V2_LDS_BYTES);                                                                  \
-      (void)hipFuncSetAttribute((const void*)wgemm2_kernel<2, ABL>, hipFuncAttributeMaxDynamicSharedMemorySize, \
-                                V2_LDS_BYTES);                                                                  \
+      (void)hipFuncSetAttribute((const void*)wgemm2_kernel<1, PK, ABL>,                                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES);                      \
+      (void)hipFuncSetAttribute((const void*)wgemm2_kernel<2, PK, ABL>,                                         \
+                                hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES);                      \
       attr_set = true;                                                                                          \
     }                                                                                                           \
     if (m <= 32)                                                                                                \
-      wgemm2_kernel<1, ABL><<<dim3((unsigned)pl.grid), V2_THREADS, V2_LDS_BYTES, st>>>(p);                      \
+      wgemm2_kernel<1, PK, ABL><<<dim3((unsigned)pl.grid), V2_THREADS, V2_LDS_BYTES, st>>>(p);                  \
     else                                                                                                        \
-      wgemm2_kernel<2, ABL><<<dim3((unsigned)pl.grid), V2_THREADS, V2_LDS_BYTES, st>>>(p);                      \
+      wgemm2_kernel<2, PK, ABL><<<dim3((unsigned)pl.grid), V2_THREADS, V2_LDS_BYTES, st>>>(p);                  \
   }
+#define V2_LAUNCH(ABL)                                  \
+  if (packed) V2_LAUNCH_PK(1, ABL) else V2_LAUNCH_PK(0, ABL)
 #ifdef V2_DEBUG_ABLATE
   const int abl = getenv("LL_GEMM2_ABLATE") ? atoi(getenv("LL_GEMM2_ABLATE")) : 0;
   switch (abl) {
@@ -633,6 +687,13 @@ extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweig
     case 7: V2_LAUNCH(7) break;
     case 8: V2_LAUNCH(8) break;
     case 12: V2_LAUNCH(12) break;
+    case 136: V2_LAUNCH(136) break;
+    case 264: V2_LAUNCH(264) break;
+    case 139: V2_LAUNCH(139) break;
+    case 267: V2_LAUNCH(267) break;
+    case 11: V2_LAUNCH(11) break;
+    case 13: V2_LAUNCH(13) break;
+    case 14: V2_LAUNCH(14) break;
     case 15: V2_LAUNCH(15) break;
     case 23: V2_LAUNCH(23) break;
     case 39: V2_LAUNCH(39) break;

@@ -645,7 +645,7 @@ static Plan make_plan(int64_t m, int64_t n, int64_t k) {
 extern "C" int ll_w4a16_v2_workspace(int64_t m, int64_t n, int64_t k, int64_t* floats, int64_t* ints);
 extern "C" int ll_w4a16_v2_supported(int64_t m, int64_t n, int64_t k, int group_size);
 extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweight, const float* scales,
-                                  const float* zeros, const void* bias, int64_t m, int64_t n, int64_t k,
+                                  const float* zeros, const void* packed, const void* bias, int64_t m, int64_t n, int64_t k,
                                   int group_size, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
                                   float* workspace, int32_t* counters, void* stream);
 
@@ -683,10 +683,11 @@ static int launch_wgemm(GemmParams& p, hipStream_t st) {
   return LL_LAUNCH_CHECK();
 }
 
-extern "C" int ll_w4a16_matmul(void* out, const void* x, const int32_t* qweight, const float* scales,
-                               const float* zeros, const void* bias, int64_t m, int64_t n, int64_t k,
-                               int group_size, int64_t x_stride_m, int64_t qw_stride_n,
-                               int64_t s_stride_n, float* workspace, int32_t* counters, void* stream) {
+extern "C" int ll_w4a16_matmul_packed(void* out, const void* x, const int32_t* qweight, const float* scales,
+                                      const float* zeros, const void* packed_sz, const void* bias, int64_t m,
+                                      int64_t n, int64_t k, int group_size, int64_t x_stride_m,
+                                      int64_t qw_stride_n, int64_t s_stride_n, float* workspace,
+                                      int32_t* counters, void* stream) {
   if (m < 0 || n <= 0 || k <= 0 || group_size <= 0 || k % group_size != 0) return LL_ERR_SHAPE;
   if (k % 32 != 0 || x_stride_m % 8 != 0 || qw_stride_n % 4 != 0) return LL_ERR_SHAPE;
   if (!ll_aligned16(x) || !ll_aligned16(qweight)) return LL_ERR_ARG;
@@ -698,13 +699,21 @@ extern "C" int ll_w4a16_matmul(void* out, const void* x, const int32_t* qweight,
   p.s_stride_n = s_stride_n; p.s_stride_k = 1; p.group_n = 1; p.group_k = group_size;
   hipStream_t st = (hipStream_t)stream;
   if (workspace && counters && ll_w4a16_v2_supported(m, n, k, group_size))
-    return ll_w4a16_v2_launch(out, x, qweight, scales, zeros, bias, m, n, k, group_size, x_stride_m,
+    return ll_w4a16_v2_launch(out, x, qweight, scales, zeros, packed_sz, bias, m, n, k, group_size, x_stride_m,
                               qw_stride_n, s_stride_n, workspace, counters, stream);
   if (group_size % 64 == 0) return launch_wgemm<FMT_W4, 1>(p, st);
   if (group_size == 32) return launch_wgemm<FMT_W4, 2>(p, st);
   if (group_size == 16) return launch_wgemm<FMT_W4, 4>(p, st);
   if (group_size == 8) return launch_wgemm<FMT_W4, 8>(p, st);
   return LL_ERR_SHAPE;
+}
+
+extern "C" int ll_w4a16_matmul(void* out, const void* x, const int32_t* qweight, const float* scales,
+                               const float* zeros, const void* bias, int64_t m, int64_t n, int64_t k,
+                               int group_size, int64_t x_stride_m, int64_t qw_stride_n,
+                               int64_t s_stride_n, float* workspace, int32_t* counters, void* stream) {
+  return ll_w4a16_matmul_packed(out, x, qweight, scales, zeros, nullptr, bias, m, n, k, group_size, x_stride_m,
+                                qw_stride_n, s_stride_n, workspace, counters, stream);
 }
 
 extern "C" int ll_w8a16_matmul(void* out, const void* x, const void* qweight, const float* scales,

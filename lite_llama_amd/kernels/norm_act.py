@@ -53,8 +53,19 @@ def swiglu_forward(a, b):
     ori_shape = a.shape
     n_cols = ori_shape[-1]
     _check_row(n_cols)
-    a2 = a.view(-1, n_cols)
-    b2 = b.view(-1, n_cols)
+    if (a.dim() >= 2 and a.dtype == b.dtype and a.shape == b.shape and a.stride() == b.stride()
+            and a.stride(-1) == 1 and b.data_ptr() == a.data_ptr() + n_cols * a.element_size()
+            and all(a.stride(i) == a.stride(i + 1) * a.shape[i + 1] for i in range(a.dim() - 2))
+            and a.stride(-2) == 2 * n_cols and n_cols % 8 == 0 and a.data_ptr() % 16 == 0):
+        # a | b are the two column halves of one row-major [rows, 2n] buffer (the fused gate/up
+        # projection): read them in place instead of materialising contiguous copies
+        rows = a.numel() // n_cols
+        c = torch.empty(ori_shape, dtype=a.dtype, device=a.device)
+        L.check(L.lib().ll_silu_and_mul(c.data_ptr(), a.data_ptr(), rows, n_cols, L.dtype_code(a.dtype),
+                                        L.stream_ptr()), "swiglu_forward")
+        return c
+    a2 = a.reshape(-1, n_cols)
+    b2 = b.reshape(-1, n_cols)
     if not a2.is_contiguous():
         a2 = a2.contiguous()
     if not b2.is_contiguous():
@@ -76,8 +87,14 @@ def rope_emb_forward(q, k, cos, sin, batch_size, seq_len):
     N, n_qh, hd = q.shape
     _, n_kh, _ = k.shape
     assert batch_size * seq_len == N
-    q = q.contiguous()
-    k = k.contiguous()
+
+    def _rows_ok(t):  # [N, H, D] with dense heads; the token stride is free (views of a fused qkv row)
+        return t.stride(2) == 1 and t.stride(1) == t.shape[2] and t.stride(0) % 8 == 0 and t.data_ptr() % 16 == 0
+
+    if not _rows_ok(q):
+        q = q.contiguous()
+    if not _rows_ok(k):
+        k = k.contiguous()
     cos = cos.contiguous()
     sin = sin.contiguous()
     if cos.dtype != sin.dtype:

@@ -26,8 +26,12 @@ def w4a16_matmul(
     *,
     group_size: int = 128,
     bias: torch.Tensor | None = None,
+    packed_scales: torch.Tensor | None = None,
 ) -> torch.Tensor:
-    """``x @ dequant(qweight).T (+ bias)``; ``W[n,k] = (nib(n,k) - zeros[n,k//g]) * scales[n,k//g]``."""
+    """``x @ dequant(qweight).T (+ bias)``; ``W[n,k] = (nib(n,k) - zeros[n,k//g]) * scales[n,k//g]``.
+
+    ``packed_scales`` (extension, from :func:`pack_w4a16_scales`) is a load-time re-layout of
+    ``scales``/``zeros`` that the decode engine streams 4x cheaper; results are bit-identical."""
     if x.dtype != torch.float16:
         raise ValueError(f"w4a16 activations must be fp16, got {x.dtype}")
     if qweight.dtype != torch.int32:
@@ -51,17 +55,37 @@ def w4a16_matmul(
         scales = scales.contiguous()
     if bias is not None and bias.dtype != torch.float16:
         bias = bias.half()
+    if packed_scales is not None:
+        L.require_cuda(packed_scales)
+        if tuple(packed_scales.shape) != (k // group_size, n, 2) or packed_scales.dtype != torch.int32 \
+                or not packed_scales.is_contiguous():
+            raise ValueError("packed_scales must be the int32 [K/g, N, 2] tensor made by pack_w4a16_scales")
     out = torch.empty((m, n), dtype=x.dtype, device=x.device)
     ws, cnt = L.gemm_workspace(x.device, m, n, k)
     L.check(
-        L.lib().ll_w4a16_matmul(
+        L.lib().ll_w4a16_matmul_packed(
             out.data_ptr(), a.data_ptr(), qweight.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
-            L.ptr(bias), m, n, k, int(group_size), a.stride(0), qweight.stride(0), scales.stride(0),
+            L.ptr(packed_scales), L.ptr(bias), m, n, k, int(group_size), a.stride(0), qweight.stride(0), scales.stride(0),
             ws.data_ptr(), cnt.data_ptr(), L.stream_ptr(),
         ),
         "w4a16_matmul",
     )
     return out.reshape(*leading, n)
+
+
+def pack_w4a16_scales(scales: torch.Tensor, zeros: torch.Tensor) -> torch.Tensor:
+    """Load-time companion of :func:`w4a16_matmul`: ``[N, K/g]`` fp32 scales/zeros -> int32
+    ``[K/g, N, 2]`` holding the fp16 pairs ``(s, s)``, ``(-z*s, -z*s)`` the GEMM feeds its dequant."""
+    L.require_cuda(scales, zeros)
+    if scales.shape != zeros.shape or scales.dim() != 2:
+        raise ValueError("scales and zeros must both be [N, K/g]")
+    scales = scales.float().contiguous()
+    zeros = zeros.float().contiguous()
+    n, groups = scales.shape
+    packed = torch.empty((groups, n, 2), dtype=torch.int32, device=scales.device)
+    L.check(L.lib().ll_w4a16_pack_scales(packed.data_ptr(), scales.data_ptr(), zeros.data_ptr(), n, groups,
+                                         scales.stride(0), L.stream_ptr()), "pack_w4a16_scales")
+    return packed
 
 
 def w8a16_matmul(

@@ -74,3 +74,81 @@ def _check_shard_alignment(quant, local_size: int, what: str) -> None:
             f"multiple of the {quant.format} scale block ({quant.group_n}x{quant.group_k}); "
             "use a smaller tensor_parallel_size"
         )
+
+
+class MergedColumnLinear:
+    """Several column-parallel linears that read the SAME input, run as one GEMM launch.
+
+    MI355X-first extension (the reference launches q/kv and gate/up separately): at batch 64 a
+    projection GEMM is dominated by per-launch fixed costs, so ``[q | k | v]`` and ``[gate | up]``
+    go out as single launches.  The member layers keep their parameter NAMES and shapes (so
+    ``state_dict`` round-trips and the reference's loaders still apply); their tensors are re-pointed
+    at row-block views of one merged storage, so there is no second copy of the weights.  Row
+    blocks of every format concatenate along N (int4 words, per-channel / per-group / per-block
+    scale grids, biases); when a scale grid would not line up the members simply run unmerged.
+    Not an ``nn.Module``: it owns no parameters of its own.
+    """
+
+    def __init__(self, layers):
+        self.layers = list(layers)
+        self._key = None
+        self._holder = None
+
+    def _snapshot(self):
+        return tuple((n, t.data_ptr(), t._version) for l in self.layers for n, t in l._parameters.items()
+                     if t is not None) + tuple(id(l.quant_method) for l in self.layers)
+
+    @torch.no_grad()
+    def refresh(self) -> bool:
+        """(Re)build the merged storage if a member's parameters were replaced; returns whether the
+        merged path can be used.  Never allocates inside a graph capture."""
+        key = self._snapshot()
+        if key == self._key:
+            return self._holder is not None
+        first = self.layers[0]
+        if not first.weight.is_cuda or torch.cuda.is_current_stream_capturing():
+            return False
+        self._holder = None
+        ok = all(type(l.quant_method) is type(first.quant_method) and l.quant == first.quant
+                 and l.input_size == first.input_size for l in self.layers)
+        holder = _MergedHolder()
+        holder.input_size = first.input_size
+        holder.output_size = sum(l.output_size for l in self.layers)
+        holder.quant, holder.quant_method = first.quant, first.quant_method
+        merged = {}
+        for name in first._parameters:
+            ts = [l._parameters.get(name) for l in self.layers]
+            if all(t is None for t in ts):
+                merged[name] = None
+                continue
+            if any(t is None for t in ts) or len({(t.dtype, t.shape[1:]) for t in ts}) != 1:
+                ok = False
+                break
+            merged[name] = torch.cat([t.data for t in ts], dim=0)
+            if first.quant is not None and ("scale" in name or "zeros" in name):
+                if tuple(merged[name].shape) != tuple(first.quant.scale_shape(holder.output_size, holder.input_size)):
+                    ok = False
+                    break
+        if ok:
+            for name, cat in merged.items():
+                setattr(holder, name, cat)
+                if cat is None:
+                    continue
+                off = 0
+                for l in self.layers:
+                    rows = l._parameters[name].shape[0]
+                    l._parameters[name] = nn.Parameter(cat[off:off + rows], requires_grad=False)
+                    off += rows
+            self._holder = holder
+        self._key = self._snapshot()
+        return ok
+
+    def __call__(self, x: torch.Tensor):
+        """-> one output view per member (column blocks of the merged ``[..., sum N]`` result)."""
+        out = self._holder.quant_method.apply(self._holder, x)
+        return torch.split(out, [l.output_size for l in self.layers], dim=-1)
+
+
+class _MergedHolder:
+    """Attribute bag with the fields a quant method's ``apply`` reads from a layer."""
+    bias = None

@@ -30,7 +30,7 @@ from .kernels import (
     swiglu_forward,
     update_kv_buffer,
 )
-from .linear import ColumnParallelLinear, LinearBase, RowParallelLinear
+from .linear import ColumnParallelLinear, LinearBase, MergedColumnLinear, RowParallelLinear
 from .quantization import QuantConfig, get_moe_method
 
 _LOG2E = 1.4426950408889634  # prefill kernel evaluates exp2 (base.py:45-47)
@@ -133,10 +133,12 @@ class PagedAttention(nn.Module):
         self.head_dim = head_dim
         self.scale = 1.0 / math.sqrt(head_dim)
 
-    def forward(self, xq, xk, xv, atten_info, layer_index: int, is_prefill: bool):
-        update_kv_buffer(torch.cat([xk, xv], dim=-2), atten_info.cur_select_index,
-                         atten_info.kv_buffer[layer_index])
+    def forward(self, xq, xkv, atten_info, layer_index: int, is_prefill: bool):
+        """``xkv [n, 2*Hkv, D]`` = this step's K heads then V heads (the pool's row layout), possibly
+        a strided view of the fused projection output."""
+        update_kv_buffer(xkv, atten_info.cur_select_index, atten_info.kv_buffer[layer_index])
         if is_prefill:
+            xk, xv = xkv[:, : self.num_kv_heads], xkv[:, self.num_kv_heads :]
             return flash_attention2_no_pad(xq, xk, xv, self.scale * _LOG2E, atten_info.b_start_loc,
                                            atten_info.b_seq_len, atten_info.max_actual_seq_len)
         kv = atten_info.kv_buffer[layer_index]
@@ -168,23 +170,28 @@ class Attention(nn.Module):
             self.q_norm_weight = nn.Parameter(torch.ones(self.head_dim, dtype=torch.float16), requires_grad=False)
             self.k_norm_weight = nn.Parameter(torch.ones(self.head_dim, dtype=torch.float16), requires_grad=False)
         self.attn = PagedAttention(self.num_kv_heads, self.head_dim)
+        object.__setattr__(self, "_qkv", MergedColumnLinear([self.q_proj, self.kv_proj]))
 
     def forward(self, x, atten_info, layer_index, position_embeddings):
         batch, seq_len, _ = x.shape
         x2 = x.view(-1, self.hidden_size)
-        xq = self.q_proj(x2)
-        xkv = self.kv_proj(x2)
-        xk, xv = torch.split(xkv, self.kv_size, dim=-1)
+        if self._qkv.refresh():
+            xq, xkv = self._qkv(x2)  # one launch; strided column views of [n, q + 2 kv]
+        else:
+            xq = self.q_proj(x2)
+            xkv = self.kv_proj(x2)
         n = batch * seq_len
         xq = xq.view(n, self.num_heads, self.head_dim)
-        xk = xk.view(n, self.num_kv_heads, self.head_dim)
-        xv = xv.view(n, self.num_kv_heads, self.head_dim)
+        xkv = xkv.view(n, 2 * self.num_kv_heads, self.head_dim)
+        xk, xv = xkv[:, : self.num_kv_heads], xkv[:, self.num_kv_heads :]
         if self.use_qk_norm:
             xq, _ = skip_rmsnorm(xq, None, self.q_norm_weight, self.eps)
             xk, _ = skip_rmsnorm(xk, None, self.k_norm_weight, self.eps)
         cos, sin = position_embeddings
         xq, xk = rope_emb_forward(xq, xk, cos, sin, batch, seq_len)
-        out = self.attn(xq, xk, xv, atten_info, layer_index, is_prefill=seq_len > 1)
+        if xk.data_ptr() != xkv.data_ptr():  # rope returned a copy of k: rebuild the [K heads | V heads] row
+            xkv = torch.cat([xk, xv], dim=-2)
+        out = self.attn(xq, xkv, atten_info, layer_index, is_prefill=seq_len > 1)
         return self.o_proj(out.view(batch, seq_len, self.q_size))
 
 
@@ -197,9 +204,14 @@ class FusedMLP(nn.Module):
         self.gate_proj = ColumnParallelLinear(h, i, quant=quant, what="MLP intermediate")
         self.up_proj = ColumnParallelLinear(h, i, quant=quant, what="MLP intermediate")
         self.down_proj = RowParallelLinear(i, h, quant=quant, what="MLP intermediate")
+        object.__setattr__(self, "_gate_up", MergedColumnLinear([self.gate_proj, self.up_proj]))
 
     def forward(self, x):
-        return self.down_proj(swiglu_forward(self.gate_proj(x), self.up_proj(x)))
+        if self._gate_up.refresh():
+            gate, up = self._gate_up(x)  # adjacent column halves of one [.., 2I] buffer
+        else:
+            gate, up = self.gate_proj(x), self.up_proj(x)
+        return self.down_proj(swiglu_forward(gate, up))
 
 
 class SparseMoeBlock(nn.Module):

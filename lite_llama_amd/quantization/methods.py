@@ -14,6 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..kernels import fused_moe, smoothquant_matmul, w4a16_matmul, w8a16_matmul
+from ..kernels.quantization import pack_w4a16_scales
 from .config import FP8, INT4, INT8, SMOOTHQUANT, QuantConfig
 from .params import (
     quantize_fp8_per_channel,
@@ -71,7 +72,23 @@ class W4A16LinearMethod(LinearQuantMethod):
 
     def apply(self, layer, x):
         return w4a16_matmul(x, layer.weight, layer.weight_scale, layer.weight_zeros,
-                            group_size=layer.quant.group_k, bias=layer.bias)
+                            group_size=layer.quant.group_k, bias=layer.bias,
+                            packed_scales=self._packed(layer))
+
+    @staticmethod
+    def _packed(layer):
+        """Load-time re-layout of the scale/zero grids for the decode GEMM (extension; cached on the
+        layer, rebuilt if the parameters were replaced).  Not built inside a graph capture."""
+        key = (layer.weight_scale.data_ptr(), layer.weight_zeros.data_ptr(),
+               layer.weight_scale._version, layer.weight_zeros._version)
+        cached = getattr(layer, "_w4_packed", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        if not layer.weight_scale.is_cuda or torch.cuda.is_current_stream_capturing():
+            return None
+        packed = pack_w4a16_scales(layer.weight_scale.data, layer.weight_zeros.data)
+        layer._w4_packed = (key, packed)
+        return packed
 
     def convert_from_fp16(self, layer, quant):
         qw, sc, zr = quantize_int4_groupwise(layer.weight.data, quant.group_k)

@@ -315,6 +315,31 @@ def test_w4a16_oracle(M, N, K_, gs):
     close(y, ref, 1e-2)
 
 
+@pytest.mark.parametrize("M,N,K_,gs", [(64, 18944, 3584, 128), (64, 3584, 18944, 128), (17, 1024, 3584, 128),
+                                       (64, 4608, 3584, 256), (1, 128, 512, 128), (64, 37888, 3584, 128)])
+def test_w4a16_decode_engine_shapes_and_packed_scales(M, N, K_, gs):
+    """The decode engine's stream-K paths (tiles split over 1..10 workgroups) at the real Qwen2.5-7B
+    shapes: vs the oracle on a row sample, and bit-identical with/without the packed scale grid."""
+    from lite_llama_amd.kernels.quantization import pack_w4a16_scales
+    g = torch.Generator().manual_seed(N + K_)
+    x = torch.randn(M, K_, dtype=torch.float16, generator=g) * 0.5
+    qw = torch.randint(-(2**31), 2**31 - 1, (N, K_ // 8), dtype=torch.int64, generator=g).to(torch.int32)
+    sc = torch.rand(N, K_ // gs, generator=g) * 0.01 + 0.005
+    zr = torch.randint(0, 16, (N, K_ // gs), generator=g).float()
+    xd, qd, sd, zd = x.to(DEV), qw.to(DEV), sc.to(DEV), zr.to(DEV)
+    y0 = K().w4a16_matmul(xd, qd, sd, zd, group_size=gs)
+    pk = pack_w4a16_scales(sd, zd)
+    for _ in range(3):  # repeated launches reuse the stream-K scratch (counters must come back to zero)
+        y1 = K().w4a16_matmul(xd, qd, sd, zd, group_size=gs, packed_scales=pk)
+        assert torch.equal(y0, y1)
+    rows = torch.randperm(N, generator=g)[:256].sort().values
+    ref = O.w4a16_matmul(x, qw[rows], sc[rows], zr[rows], group_size=gs)
+    close(y0[:, rows.to(DEV)], ref, 5e-2)
+    close(y0[:, rows.to(DEV)], ref, 1e-2)
+    with pytest.raises(ValueError):
+        K().w4a16_matmul(xd, qd, sd, zd, group_size=gs, packed_scales=pk[:, : N // 2])
+
+
 def test_w4a16_float_zero_points_and_errors():
     x = torch.randn(4, 256, dtype=torch.float16)
     qw = torch.randint(0, 2**31 - 1, (64, 32), dtype=torch.int64).to(torch.int32)
