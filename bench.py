@@ -65,32 +65,41 @@ def algorithmic_bytes(geo, quant, batch, ctx, tp):
 def gemm_roofline(model, batch, quant, iters=6):
     """Average launch duration of the dominant kernel (the weight-streaming dequant-GEMM) over every
     projection of the model with its real weights, by HIP events on the launch stream."""
-    from lite_llama_amd.linear import LinearBase
+    from lite_llama_amd.linear import LinearBase, MergedColumnLinear
 
-    lins = [m for m in model.modules() if isinstance(m, LinearBase) and m.quant is not None]
-    if not lins:
+    # the GEMM launches one decode step really makes: fused [q|k|v] and [gate|up] where merged
+    merged = [m for mod in model.modules() for m in vars(mod).values() if isinstance(m, MergedColumnLinear)]
+    fused_members = set()
+    launches_list = []  # (callable, input_size, weights in the launch)
+    for mc in merged:
+        if mc.layers[0].quant is not None and mc.refresh():
+            fused_members.update(id(l) for l in mc.layers)
+            launches_list.append((lambda x, mc=mc: mc(x), mc.layers[0].input_size,
+                                  sum(l.input_size * l.output_size for l in mc.layers)))
+    for m in model.modules():
+        if isinstance(m, LinearBase) and m.quant is not None and id(m) not in fused_members:
+            launches_list.append((m.apply_linear, m.input_size, m.input_size * m.output_size))
+    if not launches_list:
         return None
     dev = next(model.parameters()).device
-    xs = {}
-    for lin in lins:
-        if lin.input_size not in xs:
-            xs[lin.input_size] = torch.randn(batch, lin.input_size, device=dev, dtype=torch.float16) * 0.5
+    xs = {k: torch.randn(batch, k, device=dev, dtype=torch.float16) * 0.5 for _, k, _ in launches_list}
     per_w = {"int4": 0.5 + 8.0 / 128, "int8": 1.0, "smoothquant": 1.0, "fp8": 1.0}[quant]
-    nbytes = sum(lin.input_size * lin.output_size * per_w for lin in lins)
+    nbytes = sum(w * per_w for _, _, w in launches_list)
     stream = torch.cuda.current_stream()
-    for lin in lins:  # warm
-        lin.apply_linear(xs[lin.input_size])
+    for fn, k, _ in launches_list:  # warm
+        fn(xs[k])
     torch.cuda.synchronize()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(iters):
-        for lin in lins:
-            lin.apply_linear(xs[lin.input_size])
+        for fn, k, _ in launches_list:
+            fn(xs[k])
     e1.record(stream)
     torch.cuda.synchronize()
-    launches = iters * len(lins) * (2 if quant == "smoothquant" else 1)
-    avg_s = e0.elapsed_time(e1) * 1e-3 / (iters * len(lins))
-    bytes_per_launch = nbytes / len(lins)
+    nl = len(launches_list)
+    launches = iters * nl * (2 if quant == "smoothquant" else 1)
+    avg_s = e0.elapsed_time(e1) * 1e-3 / (iters * nl)
+    bytes_per_launch = nbytes / nl
     achieved = bytes_per_launch / avg_s
     traffic = None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
@@ -100,7 +109,7 @@ def gemm_roofline(model, batch, quant, iters=6):
         except Exception:
             traffic = None
     return {
-        "bound": "hbm", "kernel": "wgemm_kernel (w4a16 dequant-GEMM)" if quant == "int4" else "wgemm_kernel",
+        "bound": "hbm", "kernel": "wgemm2_kernel (w4a16 dequant-GEMM, decode engine)" if quant == "int4" else "wgemm_kernel",
         "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
         "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic,
         "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),

@@ -475,24 +475,46 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   };
 
   int cv = 0;
-  int seg_lo = (tab[0].w >> 1) & 0xFFF;
+  int fl = __builtin_amdgcn_readfirstlane(tab[0].w);
+  int seg_lo = (fl >> 1) & 0xFFF;
   int rbuf = 0, wslot = 0;
   __syncthreads();  // prologue barrier: units 0, 1 staged
+  // Operands are fetched ONE UNIT AHEAD, across the barrier (a unit is staged in LDS two steps
+  // before it is consumed, so unit v+1 is already there while unit v is being multiplied): the
+  // LDS round trips of the first MFMA step never sit on the critical path.
+  Q4 wq = *reinterpret_cast<const Q4*>(lds + V2_OFF_W + woff);
+  uint2 sz = *reinterpret_cast<const uint2*>(lds + V2_OFF_S + soff);
+  f16x8 a0[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) a0[mt] = *reinterpret_cast<const f16x8*>(lds + V2_OFF_A + aoff + mt * 32 * V2_A_ROW);
   for (;;) {
+    const int rbuf_n = rbuf == V2_XR - 1 ? 0 : rbuf + 1;
+    const int wslot_n = wslot == V2_RW - 1 ? 0 : wslot + 1;
+    Q4 wq_n = wq;
+    uint2 sz_n = sz;
+    f16x8 a0_n[MT];
+    int fl_n = 0;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a0_n[mt] = a0[mt];
     if constexpr (!(ABL & 4)) {
-      const unsigned char* wt = lds + V2_OFF_W + wslot * 8192;
-      const Q4 wq = *reinterpret_cast<const Q4*>(wt + woff);
-      const uint2 sz = *reinterpret_cast<const uint2*>(lds + V2_OFF_S + wslot * 1024 + soff);
       const unsigned char* ab = lds + V2_OFF_A + rbuf * V2_A_TILE + aoff;
       f16x8 acur[MT], anxt[MT];
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acur[mt] = *reinterpret_cast<const f16x8*>(ab + mt * 32 * V2_A_ROW);
+      for (int mt = 0; mt < MT; ++mt) acur[mt] = a0[mt];
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
         if (s + 1 < 4) {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
             anxt[mt] = *reinterpret_cast<const f16x8*>(ab + mt * 32 * V2_A_ROW + (s + 1) * 16);
+        }
+        if (s == 2) {  // next unit's first operands, issued under this unit's last MFMAs
+          wq_n = *reinterpret_cast<const Q4*>(lds + V2_OFF_W + wslot_n * 8192 + woff);
+          sz_n = *reinterpret_cast<const uint2*>(lds + V2_OFF_S + wslot_n * 1024 + soff);
+          const unsigned char* abn = lds + V2_OFF_A + rbuf_n * V2_A_TILE + aoff;
+#pragma unroll
+          for (int mt = 0; mt < MT; ++mt) a0_n[mt] = *reinterpret_cast<const f16x8*>(abn + mt * 32 * V2_A_ROW);
+          fl_n = V2_ENTRY(cv + 1).w;
         }
         const uint32_t word = s == 0 ? wq.x : s == 1 ? wq.y : s == 2 ? wq.z : wq.w;
         Q4 wf;
@@ -513,12 +535,13 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 #pragma unroll
         for (int mt = 0; mt < MT; ++mt) acur[mt] = anxt[mt];
       }
+    } else {
+      fl_n = V2_ENTRY(cv + 1).w;
     }
-    rbuf = rbuf == V2_XR - 1 ? 0 : rbuf + 1;
-    wslot = wslot == V2_RW - 1 ? 0 : wslot + 1;
+    rbuf = rbuf_n;
+    wslot = wslot_n;
     __syncthreads();
     if (pend_ctr) post_pending();  // the previous segment's slab stores are a unit old by now
-    const int fl = __builtin_amdgcn_readfirstlane(tab[cv].w);
     const bool se = fl & 1;
     if (se) {
       // sum the two k-halves through LDS, then the kh = 0 wave flushes the tile segment
@@ -546,7 +569,12 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       zero_acc();
     }
     if (++cv >= cnt) break;
-    if (se) seg_lo = (__builtin_amdgcn_readfirstlane(tab[cv].w) >> 1) & 0xFFF;
+    fl = __builtin_amdgcn_readfirstlane(fl_n);
+    if (se) seg_lo = (fl >> 1) & 0xFFF;
+    wq = wq_n;
+    sz = sz_n;
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) a0[mt] = a0_n[mt];
   }
   if (pend_ctr) post_pending();
 }
