@@ -353,6 +353,93 @@ extern "C" int ll_rope(void* q, void* k, const void* cos_t, const void* sin_t, i
 }
 
 // --------------------------------------------------------------------------- //
+// rope + KV scatter in one launch (decode step: both are ~1 us of work behind ~2 us of launch
+// latency each).  Exactly rope_emb_forward(q, k) followed by update_kv_buffer(cat(k, v)):
+// q and k are rotated IN PLACE, and the rotated k heads + the v heads of token i land in pool row
+// select_index[i].  kv = [tokens, 2*n_kh, hd] rows (K heads first), token stride given.
+// --------------------------------------------------------------------------- //
+template <int DT, int CS, int VEC>
+__global__ __launch_bounds__(256) void rope_cache_kernel(
+    uint16_t* __restrict__ q, uint16_t* __restrict__ kv, const void* __restrict__ cos_t,
+    const void* __restrict__ sin_t, uint16_t* __restrict__ pool, const void* __restrict__ sel, int n_qh,
+    int n_kh, int hd, int64_t q_rs, int64_t kv_rs, int64_t seq_len, int64_t cbs, int64_t css, int64_t sbs,
+    int64_t sss, int64_t pst, int64_t psh, int idx_w) {
+  const int64_t tok = blockIdx.x;
+  const int64_t bi = tok / seq_len, si = tok % seq_len;
+  const int64_t dst = idx_w == LL_I32 ? (int64_t)((const int32_t*)sel)[tok] : ((const int64_t*)sel)[tok];
+  const int half = hd / 2;
+  const int vph = half / VEC;  // vectors per head-half
+  const int total = (n_qh + 2 * n_kh) * vph;
+  const int64_t cbase = bi * cbs + si * css;
+  const int64_t sbase = bi * sbs + si * sss;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int h = i / vph, j = (i % vph) * VEC;
+    const int hk = h - n_qh;  // >= 0: row of the [2*n_kh, hd] kv block
+    uint16_t* base = (hk < 0) ? (q + tok * q_rs + (int64_t)h * hd) : (kv + tok * kv_rs + (int64_t)hk * hd);
+    uint16_t x1[VEC], x2[VEC], o1[VEC], o2[VEC];
+    VecIO<VEC>::load(base + j, x1);
+    VecIO<VEC>::load(base + half + j, x2);
+    if (hk < n_kh) {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        const float c = load_cs<CS>(cos_t, cbase + j + e);
+        const float s = load_cs<CS>(sin_t, sbase + j + e);
+        const float a = to_f32<DT>(x1[e]), b = to_f32<DT>(x2[e]);
+        o1[e] = from_f32<DT>(a * c - b * s);
+        o2[e] = from_f32<DT>(b * c + a * s);
+      }
+      VecIO<VEC>::store(base + j, o1);
+      VecIO<VEC>::store(base + half + j, o2);
+    } else {
+#pragma unroll
+      for (int e = 0; e < VEC; ++e) {
+        o1[e] = x1[e];
+        o2[e] = x2[e];
+      }
+    }
+    if (hk >= 0) {
+      uint16_t* prow = pool + dst * pst + (int64_t)hk * psh;
+      VecIO<VEC>::store(prow + j, o1);
+      VecIO<VEC>::store(prow + half + j, o2);
+    }
+  }
+}
+
+extern "C" int ll_rope_kv_update(void* q, void* kv, const void* cos_t, const void* sin_t, void* kv_buffer,
+                                 const void* select_index, int64_t tokens, int n_qh, int n_kh, int hd,
+                                 int64_t q_row_stride, int64_t kv_row_stride, int64_t seq_len,
+                                 int64_t cos_b_stride, int64_t cos_s_stride, int64_t sin_b_stride,
+                                 int64_t sin_s_stride, int64_t pool_stride_t, int64_t pool_stride_h,
+                                 int qk_dtype, int cs_dtype, int idx_width, void* stream) {
+  if (qk_dtype != LL_F16 && qk_dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (cs_dtype != LL_F16 && cs_dtype != LL_BF16 && cs_dtype != LL_F32) return LL_ERR_DTYPE;
+  if (idx_width != LL_I32 && idx_width != LL_I64) return LL_ERR_DTYPE;
+  if (tokens < 0 || hd <= 0 || (hd & 1) || seq_len <= 0 || n_qh < 0 || n_kh <= 0) return LL_ERR_SHAPE;
+  if (tokens == 0) return LL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (hd % 16 == 0) && ll_aligned16(q) && ll_aligned16(kv) && ll_aligned16(kv_buffer) &&
+                   (q_row_stride % 8 == 0) && (kv_row_stride % 8 == 0) && (pool_stride_t % 8 == 0) &&
+                   (pool_stride_h % 8 == 0);
+#define LL_RC(DT, CS, VEC)                                                                              \
+  rope_cache_kernel<DT, CS, VEC><<<dim3((unsigned)tokens), 256, 0, st>>>(                               \
+      (uint16_t*)q, (uint16_t*)kv, cos_t, sin_t, (uint16_t*)kv_buffer, select_index, n_qh, n_kh, hd,    \
+      q_row_stride, kv_row_stride, seq_len, cos_b_stride, cos_s_stride, sin_b_stride, sin_s_stride,     \
+      pool_stride_t, pool_stride_h, idx_width)
+#define LL_RC_CS(DT, VEC)                                   \
+  if (cs_dtype == LL_F16) LL_RC(DT, LL_F16, VEC);           \
+  else if (cs_dtype == LL_BF16) LL_RC(DT, LL_BF16, VEC);    \
+  else LL_RC(DT, LL_F32, VEC)
+  if (qk_dtype == LL_F16) {
+    if (vec) { LL_RC_CS(LL_F16, 8); } else { LL_RC_CS(LL_F16, 1); }
+  } else {
+    if (vec) { LL_RC_CS(LL_BF16, 8); } else { LL_RC_CS(LL_BF16, 1); }
+  }
+#undef LL_RC_CS
+#undef LL_RC
+  return LL_LAUNCH_CHECK();
+}
+
+// --------------------------------------------------------------------------- //
 // greedy argmax -- reference lite_llama/engine/sampler.py:227-228,264
 // (torch.argmax: first index of the maximum).  One block per row.
 // --------------------------------------------------------------------------- //

@@ -22,6 +22,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .distributed.parallel_state import all_reduce_tp, divide, get_tp_rank, get_tp_world_size
+from .kernels.norm_act import rope_and_cache
 from .kernels import (
     flash_attention2_no_pad,
     flash_decoding,
@@ -133,10 +134,11 @@ class PagedAttention(nn.Module):
         self.head_dim = head_dim
         self.scale = 1.0 / math.sqrt(head_dim)
 
-    def forward(self, xq, xkv, atten_info, layer_index: int, is_prefill: bool):
+    def forward(self, xq, xkv, atten_info, layer_index: int, is_prefill: bool, cached: bool = False):
         """``xkv [n, 2*Hkv, D]`` = this step's K heads then V heads (the pool's row layout), possibly
-        a strided view of the fused projection output."""
-        update_kv_buffer(xkv, atten_info.cur_select_index, atten_info.kv_buffer[layer_index])
+        a strided view of the fused projection output; ``cached``: already scattered to the pool."""
+        if not cached:
+            update_kv_buffer(xkv, atten_info.cur_select_index, atten_info.kv_buffer[layer_index])
         if is_prefill:
             xk, xv = xkv[:, : self.num_kv_heads], xkv[:, self.num_kv_heads :]
             return flash_attention2_no_pad(xq, xk, xv, self.scale * _LOG2E, atten_info.b_start_loc,
@@ -188,10 +190,16 @@ class Attention(nn.Module):
             xq, _ = skip_rmsnorm(xq, None, self.q_norm_weight, self.eps)
             xk, _ = skip_rmsnorm(xk, None, self.k_norm_weight, self.eps)
         cos, sin = position_embeddings
-        xq, xk = rope_emb_forward(xq, xk, cos, sin, batch, seq_len)
-        if xk.data_ptr() != xkv.data_ptr():  # rope returned a copy of k: rebuild the [K heads | V heads] row
-            xkv = torch.cat([xk, xv], dim=-2)
-        out = self.attn(xq, xkv, atten_info, layer_index, is_prefill=seq_len > 1)
+        if not self.use_qk_norm and xkv.stride(1) == self.head_dim and xq.stride(1) == self.head_dim:
+            # decode fast path: rope + KV scatter in one launch, in place on the projection output
+            rope_and_cache(xq, xkv, cos, sin, batch, seq_len, atten_info.cur_select_index,
+                           atten_info.kv_buffer[layer_index])
+            out = self.attn(xq, xkv, atten_info, layer_index, is_prefill=seq_len > 1, cached=True)
+        else:
+            xq, xk = rope_emb_forward(xq, xk, cos, sin, batch, seq_len)
+            if xk.data_ptr() != xkv.data_ptr():  # rope returned a copy of k: rebuild the [K heads | V heads] row
+                xkv = torch.cat([xk, xv], dim=-2)
+            out = self.attn(xq, xkv, atten_info, layer_index, is_prefill=seq_len > 1)
         return self.o_proj(out.view(batch, seq_len, self.q_size))
 
 

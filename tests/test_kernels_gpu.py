@@ -564,3 +564,27 @@ def test_fused_moe_routing_weight_and_quant():
     close(out, ref, 2e-2)
     with pytest.raises(ValueError):
         K().fused_moe(x.to(DEV), q1.to(DEV), w2.half().to(DEV), wts.to(DEV), ids.to(DEV), w1_scale=s1.to(DEV))
+
+
+# ------------------------------------------------------------------------------------- #
+# decode-step fusions (extensions): bit-identical to the reference-shaped call sequences
+# ------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("HQ,HKV,D,B,S", [(28, 4, 128, 64, 1), (4, 2, 64, 3, 5), (8, 8, 128, 2, 1)])
+def test_rope_and_cache_equals_rope_then_update_kv_buffer(HQ, HKV, D, B, S):
+    from lite_llama_amd.kernels.norm_act import rope_and_cache
+    g = torch.Generator().manual_seed(HQ * 131 + D)
+    n = B * S
+    qkv = torch.randn(n, (HQ + 2 * HKV) * D, generator=g).half().to(DEV)  # fused projection rows
+    cos = torch.randn(B, S, D // 2, generator=g).half().to(DEV)
+    sin = torch.randn(B, S, D // 2, generator=g).half().to(DEV)
+    sel = torch.randperm(4 * n, generator=g)[:n].int().to(DEV)
+    pool_a = torch.zeros(4 * n, 2 * HKV, D, dtype=torch.float16, device=DEV)
+    pool_b = torch.zeros_like(pool_a)
+    a, b = qkv.clone(), qkv.clone()
+    qa, kva = a[:, : HQ * D].view(n, HQ, D), a[:, HQ * D:].view(n, 2 * HKV, D)
+    K().rope_emb_forward(qa, kva[:, :HKV], cos, sin, B, S)
+    K().update_kv_buffer(kva, sel, pool_a)
+    qb, kvb = b[:, : HQ * D].view(n, HQ, D), b[:, HQ * D:].view(n, 2 * HKV, D)
+    rope_and_cache(qb, kvb, cos, sin, B, S, sel, pool_b)
+    assert torch.equal(a, b) and torch.equal(pool_a, pool_b)
+    assert not torch.equal(a, qkv)  # really rotated in place
