@@ -88,94 +88,108 @@ __global__ __launch_bounds__(64) void fd_stage1(
 #pragma unroll
   for (int i = 0; i < NT; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  for (int64_t pos0 = start; pos0 < end; pos0 += 32) {
-    // ---- gather: lane (t, c) fetches rows pos0+t and pos0+16+t, d-range [c*DQ, +DQ) ----
-    const int64_t tokA = pos0 + t, tokB = pos0 + 16 + t;
-    const bool okA = tokA < end, okB = tokB < end;
-    const int64_t rowA = okA ? (int64_t)trow[tokA] : 0;
-    const int64_t rowB = okB ? (int64_t)trow[tokB] : 0;
-    const uint16_t* kA = kc + rowA * k_st + (int64_t)kvh * k_sh + c * DQ;
-    const uint16_t* kB = kc + rowB * k_st + (int64_t)kvh * k_sh + c * DQ;
-    const uint16_t* vA = vc + rowA * v_st + (int64_t)kvh * v_sh + c * DQ;
-    const uint16_t* vB = vc + rowB * v_st + (int64_t)kvh * v_sh + c * DQ;
-    Q4 ka[NS], kb[NS], va[NS], vb[NS];
-#pragma unroll
-    for (int s = 0; s < NS; ++s) ka[s] = *reinterpret_cast<const Q4*>(kA + s * 8);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) kb[s] = *reinterpret_cast<const Q4*>(kB + s * 8);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) va[s] = *reinterpret_cast<const Q4*>(vA + s * 8);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) vb[s] = *reinterpret_cast<const Q4*>(vB + s * 8);
+  // Pool rows of the whole partition, fetched ONCE: lane l holds the rows of tokens start+l and
+  // start+64+l (clamped to the last valid token, so every later gather reads a valid row); the
+  // tiles pick theirs with a lane shuffle instead of a dependent table load per tile.
+  static_assert(FD_PART == 128, "the tile schedule below is written for 4 tiles of 32 tokens");
+  const int64_t lastt = end - 1;
+  const int64_t tk0 = start + lane < lastt ? start + lane : lastt;
+  const int64_t tk1 = start + 64 + lane < lastt ? start + 64 + lane : lastt;
+  const int r0 = trow[tk0], r1 = trow[tk1];
 
-    // ---- S^T tiles: rows = tokens (4c+r), cols = heads (t) ----
-    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
-#pragma unroll
-    for (int s = 0; s < NS; ++s) sa = mfma16<DT>(ka[s], qf[s], sa);
-#pragma unroll
-    for (int s = 0; s < NS; ++s) sb = mfma16<DT>(kb[s], qf[s], sb);
-
-    float sc[8];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const bool va_ok = pos0 + 4 * c + r < end;
-      const bool vb_ok = pos0 + 16 + 4 * c + r < end;
-      sc[r] = va_ok ? sa[r] * scale : -INFINITY;
-      sc[4 + r] = vb_ok ? sb[r] * scale : -INFINITY;
-      mx = fmaxf(mx, fmaxf(sc[r], sc[4 + r]));
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));
-    const float m_new = fmaxf(m_i, mx);  // finite: token pos0 is always valid
-    const float alpha = expf(m_i - m_new);
-    float p[8];
-    float ps = 0.f;
-#pragma unroll
-    for (int j = 0; j < 8; ++j) {
-      p[j] = expf(sc[j] - m_new);
-      ps += p[j];
-    }
-    ps += __shfl_xor(ps, 16, 64);
-    ps += __shfl_xor(ps, 32, 64);
-    d_i = d_i * alpha + ps;
-    m_i = m_new;
-
-    // P^T fragment (MFMA B operand): k-slot j <-> token 16*(j>>2) + 4c + (j&3)
-    Q4 pf;
-    pf.x = pack2<DT>(p[0], p[1]);
-    pf.y = pack2<DT>(p[2], p[3]);
-    pf.z = pack2<DT>(p[4], p[5]);
-    pf.w = pack2<DT>(p[6], p[7]);
-
-    // ---- stage V rows through LDS (zero rows past the end: garbage could be NaN) ----
-    __syncthreads();  // previous tile's reads done
-#pragma unroll
-    for (int s = 0; s < NS; ++s) {
-      *reinterpret_cast<Q4*>(&lds_v[t * VSTR + c * DQ + s * 8]) = okA ? va[s] : Q4{0, 0, 0, 0};
-      *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + c * DQ + s * 8]) = okB ? vb[s] : Q4{0, 0, 0, 0};
-    }
-    __syncthreads();
-
-    // ---- O^T[d][head] += V^T[d][tok] . P^T[tok][head] ----
-#pragma unroll
-    for (int dt = 0; dt < NT; ++dt) {
-      uint32_t w[4];
-#pragma unroll
-      for (int jj = 0; jj < 4; ++jj) {
-        const int j0 = 2 * jj, j1 = 2 * jj + 1;
-        const int r0 = 16 * (j0 >> 2) + 4 * c + (j0 & 3);
-        const int r1 = 16 * (j1 >> 2) + 4 * c + (j1 & 3);
-        const uint32_t lo = lds_v[r0 * VSTR + dt * 16 + t];
-        const uint32_t hi = lds_v[r1 * VSTR + dt * 16 + t];
-        w[jj] = lo | (hi << 16);
-      }
-      const Q4 vf = {w[0], w[1], w[2], w[3]};
-      f32x4 acc = ot[dt];
-      acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;
-      ot[dt] = mfma16<DT>(vf, pf, acc);
-    }
+  // ---- gather of tile TI (32 tokens): lane (t, c) fetches rows TI*32+t and TI*32+16+t, d-range
+  //      [c*DQ, +DQ), straight into MFMA fragment layout.  Unconditional (clamped rows): hipcc
+  //      drains vmcnt(0) around any branch that contains a load.
+#define FD_LOAD(S, TI)                                                                         \
+  {                                                                                            \
+    const int rsrc_ = (TI) < 2 ? r0 : r1;                                                      \
+    const int64_t rowA_ = __shfl(rsrc_, ((TI) & 1) * 32 + t, 64);                              \
+    const int64_t rowB_ = __shfl(rsrc_, ((TI) & 1) * 32 + 16 + t, 64);                         \
+    const uint16_t* kA_ = kc + rowA_ * k_st + (int64_t)kvh * k_sh + c * DQ;                    \
+    const uint16_t* kB_ = kc + rowB_ * k_st + (int64_t)kvh * k_sh + c * DQ;                    \
+    const uint16_t* vA_ = vc + rowA_ * v_st + (int64_t)kvh * v_sh + c * DQ;                    \
+    const uint16_t* vB_ = vc + rowB_ * v_st + (int64_t)kvh * v_sh + c * DQ;                    \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) ka##S[s] = *reinterpret_cast<const Q4*>(kA_ + s * 8); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) kb##S[s] = *reinterpret_cast<const Q4*>(kB_ + s * 8); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) va##S[s] = *reinterpret_cast<const Q4*>(vA_ + s * 8); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) vb##S[s] = *reinterpret_cast<const Q4*>(vB_ + s * 8); \
   }
+
+  // ---- one 32-token tile: S^T, online softmax, O^T += V^T P^T ----
+#define FD_COMPUTE(S, TI)                                                                      \
+  {                                                                                            \
+    const int64_t pos0 = start + (TI) * 32;                                                    \
+    const bool okA = pos0 + t < end, okB = pos0 + 16 + t < end;                                \
+    /* S^T tiles: rows = tokens (4c+r), cols = heads (t) */                                    \
+    f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};                                \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) sa = mfma16<DT>(ka##S[s], qf[s], sa);       \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) sb = mfma16<DT>(kb##S[s], qf[s], sb);       \
+    float sc[8];                                                                               \
+    float mx = -INFINITY;                                                                      \
+    _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
+      const bool va_ok = pos0 + 4 * c + r < end;                                               \
+      const bool vb_ok = pos0 + 16 + 4 * c + r < end;                                          \
+      sc[r] = va_ok ? sa[r] * scale : -INFINITY;                                               \
+      sc[4 + r] = vb_ok ? sb[r] * scale : -INFINITY;                                           \
+      mx = fmaxf(mx, fmaxf(sc[r], sc[4 + r]));                                                 \
+    }                                                                                          \
+    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));                                                    \
+    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                    \
+    const float m_new = fmaxf(m_i, mx); /* finite: token pos0 is always valid */               \
+    const float alpha = expf(m_i - m_new);                                                     \
+    float p[8];                                                                                \
+    float ps = 0.f;                                                                            \
+    _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
+      p[j] = expf(sc[j] - m_new);                                                              \
+      ps += p[j];                                                                              \
+    }                                                                                          \
+    ps += __shfl_xor(ps, 16, 64);                                                              \
+    ps += __shfl_xor(ps, 32, 64);                                                              \
+    d_i = d_i * alpha + ps;                                                                    \
+    m_i = m_new;                                                                               \
+    /* P^T fragment (MFMA B operand): k-slot j <-> token 16*(j>>2) + 4c + (j&3) */             \
+    Q4 pf;                                                                                     \
+    pf.x = pack2<DT>(p[0], p[1]);                                                              \
+    pf.y = pack2<DT>(p[2], p[3]);                                                              \
+    pf.z = pack2<DT>(p[4], p[5]);                                                              \
+    pf.w = pack2<DT>(p[6], p[7]);                                                              \
+    /* stage V rows through LDS (zero rows past the end: garbage could be NaN) */              \
+    __syncthreads(); /* previous tile's reads done */                                          \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                           \
+      *reinterpret_cast<Q4*>(&lds_v[t * VSTR + c * DQ + s * 8]) = okA ? va##S[s] : Q4{0, 0, 0, 0};        \
+      *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + c * DQ + s * 8]) = okB ? vb##S[s] : Q4{0, 0, 0, 0}; \
+    }                                                                                          \
+    __syncthreads();                                                                           \
+    /* O^T[d][head] += V^T[d][tok] . P^T[tok][head] */                                         \
+    _Pragma("unroll") for (int dt = 0; dt < NT; ++dt) {                                        \
+      uint32_t w[4];                                                                           \
+      _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                       \
+        const int j0 = 2 * jj, j1 = 2 * jj + 1;                                                \
+        const int q0 = 16 * (j0 >> 2) + 4 * c + (j0 & 3);                                      \
+        const int q1 = 16 * (j1 >> 2) + 4 * c + (j1 & 3);                                      \
+        const uint32_t lo = lds_v[q0 * VSTR + dt * 16 + t];                                    \
+        const uint32_t hi = lds_v[q1 * VSTR + dt * 16 + t];                                    \
+        w[jj] = lo | (hi << 16);                                                               \
+      }                                                                                        \
+      const Q4 vf = {w[0], w[1], w[2], w[3]};                                                  \
+      f32x4 acc = ot[dt];                                                                      \
+      acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;                      \
+      ot[dt] = mfma16<DT>(vf, pf, acc);                                                        \
+    }                                                                                          \
+  }
+
+  // two register sets: tile i+1 is in flight while tile i is multiplied
+  Q4 kaA[NS], kbA[NS], vaA[NS], vbA[NS], kaB[NS], kbB[NS], vaB[NS], vbB[NS];
+  FD_LOAD(A, 0)
+  FD_LOAD(B, 1)
+  FD_COMPUTE(A, 0)
+  FD_LOAD(A, 2)
+  if (start + 32 < end) FD_COMPUTE(B, 1)
+  FD_LOAD(B, 3)
+  if (start + 64 < end) FD_COMPUTE(A, 2)
+  if (start + 96 < end) FD_COMPUTE(B, 3)
+#undef FD_LOAD
+#undef FD_COMPUTE
 
   if (head_ok) {
     const float inv = 1.0f / d_i;
