@@ -179,6 +179,10 @@ int ll_moe_sum(void* out, const void* x, int64_t tokens, int top_k, int64_t n, i
 /* ---- a16: greedy argmax over logits [rows, n] (engine/sampler.py:227-228) ----- */
 int ll_argmax(int64_t* out, const void* logits, int64_t rows, int64_t n, int64_t stride_row,
               int dtype, void* stream);
+/* Same result through a [rows x chunks] grid + a merge kernel (vocabulary-sized rows at small
+ * batch); scratch = rows * chunks * 16 bytes, 8-byte aligned. */
+int ll_argmax_split(int64_t* out, const void* logits, int64_t rows, int64_t n, int64_t stride_row,
+                    int dtype, void* scratch, int chunks, void* stream);
 
 #ifdef __cplusplus
 }

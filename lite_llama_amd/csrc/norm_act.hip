@@ -490,6 +490,103 @@ __global__ __launch_bounds__(1024) void argmax_kernel(int64_t* __restrict__ out,
   }
 }
 
+// Two-stage variant for vocabulary-sized rows: a [rows x chunks] grid fills the chip (one block
+// per row leaves 3/4 of the CUs idle at batch 64), a second tiny kernel merges the per-chunk
+// winners in chunk order (strict >, so the first maximum still wins).
+struct ArgPart {
+  float v;
+  int pad;
+  int64_t i;
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void argmax_part_kernel(ArgPart* __restrict__ part,
+                                                          const void* __restrict__ logits, int64_t n,
+                                                          int64_t stride_row, int chunks) {
+  __shared__ float sv[4];
+  __shared__ int64_t si[4];
+  const int64_t row = blockIdx.y;
+  const int64_t per = (n + chunks - 1) / chunks;
+  const int64_t lo = (int64_t)blockIdx.x * per;
+  const int64_t hi = lo + per < n ? lo + per : n;
+  float best = -INFINITY;
+  int64_t bi = INT64_MAX;
+  for (int64_t i = lo + threadIdx.x; i < hi; i += 256) {
+    const float v = load_logit<DT>(logits, row * stride_row + i);
+    if (bi == INT64_MAX || v > best) {
+      best = v;
+      bi = i;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int64_t oi = __shfl_xor(bi, off, 64);
+    if (ov > best || (ov == best && oi < bi)) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  const int wid = threadIdx.x >> 6;
+  if ((threadIdx.x & 63) == 0) {
+    sv[wid] = best;
+    si[wid] = bi;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    for (int w = 1; w < 4; ++w)
+      if (sv[w] > best || (sv[w] == best && si[w] < bi)) {
+        best = sv[w];
+        bi = si[w];
+      }
+    ArgPart o;
+    o.v = best;
+    o.pad = 0;
+    o.i = bi;
+    part[row * chunks + blockIdx.x] = o;
+  }
+}
+
+__global__ __launch_bounds__(64) void argmax_merge_kernel(int64_t* __restrict__ out,
+                                                         const ArgPart* __restrict__ part, int chunks) {
+  const int64_t row = blockIdx.x;
+  float best = -INFINITY;
+  int64_t bi = INT64_MAX;
+  for (int c = threadIdx.x; c < chunks; c += 64) {
+    const ArgPart pp = part[row * chunks + c];
+    if (pp.i != INT64_MAX && (bi == INT64_MAX || pp.v > best)) {
+      best = pp.v;
+      bi = pp.i;
+    }
+  }
+#pragma unroll
+  for (int off = 32; off > 0; off >>= 1) {
+    const float ov = __shfl_xor(best, off, 64);
+    const int64_t oi = __shfl_xor(bi, off, 64);
+    if (oi != INT64_MAX && (bi == INT64_MAX || ov > best || (ov == best && oi < bi))) {
+      best = ov;
+      bi = oi;
+    }
+  }
+  if (threadIdx.x == 0) out[row] = bi;
+}
+
+extern "C" int ll_argmax_split(int64_t* out, const void* logits, int64_t rows, int64_t n, int64_t stride_row,
+                               int dtype, void* scratch, int chunks, void* stream) {
+  if (rows < 0 || n <= 0 || chunks <= 0 || chunks > 65535) return LL_ERR_SHAPE;
+  if (!scratch) return LL_ERR_ARG;
+  if (rows == 0) return LL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const dim3 grid((unsigned)chunks, (unsigned)rows);
+  ArgPart* part = (ArgPart*)scratch;
+  if (dtype == LL_F16) argmax_part_kernel<LL_F16><<<grid, 256, 0, st>>>(part, logits, n, stride_row, chunks);
+  else if (dtype == LL_BF16) argmax_part_kernel<LL_BF16><<<grid, 256, 0, st>>>(part, logits, n, stride_row, chunks);
+  else if (dtype == LL_F32) argmax_part_kernel<LL_F32><<<grid, 256, 0, st>>>(part, logits, n, stride_row, chunks);
+  else return LL_ERR_DTYPE;
+  argmax_merge_kernel<<<dim3((unsigned)rows), 64, 0, st>>>(out, part, chunks);
+  return LL_LAUNCH_CHECK();
+}
+
 extern "C" int ll_argmax(int64_t* out, const void* logits, int64_t rows, int64_t n, int64_t stride_row,
                          int dtype, void* stream) {
   if (rows < 0 || n <= 0) return LL_ERR_SHAPE;

@@ -444,6 +444,12 @@ def test_argmax_exact():
     logits[3, 100] = logits[3, 70000] = 50.0  # tie -> first index
     got = greedy_argmax(logits.to(DEV))
     assert torch.equal(got.cpu(), torch.argmax(logits, dim=-1))
+    # small rows (single-kernel path), ragged sizes (split path with a short last chunk), ties across chunks
+    for rows, n in [(5, 1000), (3, 16385), (64, 40001), (2000, 20000)]:
+        lg = torch.randint(-3, 4, (rows, n)).to(torch.float16)  # many exact ties
+        assert torch.equal(greedy_argmax(lg.to(DEV)).cpu(), torch.argmax(lg, dim=-1)), (rows, n)
+    lg = torch.randn(4, 50000, dtype=torch.float32)
+    assert torch.equal(greedy_argmax(lg.to(DEV)).cpu(), torch.argmax(lg, dim=-1))
 
 
 # ------------------------------------------------------------------------------------- #
