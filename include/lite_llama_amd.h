@@ -142,6 +142,19 @@ int ll_w4a16_matmul_packed(void* out, const void* x, const int32_t* qweight, con
                            int64_t qw_stride_n, int64_t s_stride_n, float* workspace,
                            int32_t* counters, void* stream);
 
+/* Decode-step fusion (no reference counterpart: the reference runs gate_proj, up_proj and
+ * swiglu.py:45-65 as three launches): qweight / scales / zeros hold the two projections
+ * row-interleaved (row 2j = gate_j, row 2j+1 = up_j; n = 2 * intermediate), out [M, n/2] fp16 =
+ * silu(gate) * up with the stand-alone kernels' rounding (same arithmetic; only the fp32 summation
+ * order of the stream-K split can differ from the two-launch form).  Returns LL_ERR_SHAPE when
+ * the shape is outside the decode engine (M > 64, n % 128, k % 128, group % 128): run the
+ * two-step form then. */
+int ll_w4a16_decode_supported(int64_t m, int64_t n, int64_t k, int group_size); /* 1 / 0 */
+int ll_w4a16_gateup_swiglu(void* out, const void* x, const int32_t* qweight, const float* scales,
+                           const float* zeros, const void* packed_sz, int64_t m, int64_t n, int64_t k,
+                           int group_size, int64_t x_stride_m, int64_t qw_stride_n,
+                           int64_t s_stride_n, float* workspace, int32_t* counters, void* stream);
+
 /* ---- a9: w8a16_matmul  (kernels/quantization/w8a16.py:155-216) ---------------
  * qweight [N,K] uint8 (fp8-e4m3 bits) or int8; scales fp32 [ceil(N/gn), ceil(K/gk)]. */
 int ll_w8a16_matmul(void* out, const void* x, const void* qweight, const float* scales,

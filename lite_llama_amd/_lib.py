@@ -37,6 +37,8 @@ SIGNATURES = {
     "ll_gemm_workspace": [L, L, L, P, P],
     "ll_w4a16_matmul": [P, P, P, P, P, P, L, L, L, I, L, L, L, P, P, P],
     "ll_w4a16_pack_scales": [P, P, P, L, L, L, P],
+    "ll_w4a16_decode_supported": [L, L, L, I],
+    "ll_w4a16_gateup_swiglu": [P, P, P, P, P, P, L, L, L, I, L, L, L, P, P, P],
     "ll_w4a16_matmul_packed": [P, P, P, P, P, P, P, L, L, L, I, L, L, L, P, P, P],
     "ll_w8a16_matmul": [P, P, P, P, P, L, L, L, I, L, I, L, L, L, L, P, P, P],
     "ll_quantize_activations_int8": [P, P, P, L, L, L, P],

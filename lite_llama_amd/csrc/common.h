@@ -91,6 +91,10 @@ __device__ __forceinline__ float wave_max(float v) {
   return v;
 }
 
+// shared by swiglu / silu_and_mul and the GEMM's fused gate-up epilogue (must stay ONE definition:
+// the fused path is tested bit-identical against the separate kernels)
+__device__ __forceinline__ float ll_sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
+
 static inline bool ll_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define LL_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? LL_OK : LL_ERR_LAUNCH)

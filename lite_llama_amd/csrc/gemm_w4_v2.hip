@@ -56,6 +56,7 @@ struct V2Params {
   int nblocks, chunks, total_units, upw, slots;
   int gshift;  // log2(group_size / 128) when a power of two, else -1
   int gdiv;    // group_size / 128
+  int epi;     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu (ll_w4a16_gateup_swiglu)
 };
 
 __device__ __forceinline__ uint32_t v2_pk_add(uint32_t a, uint32_t b) {
@@ -466,10 +467,20 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
           if (has_bias) v += f16_bits_to_f32(p.bias[nn + e]);
           o[e] = f32_to_f16_bits(v);
         }
-        uint2 pk;
-        pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-        pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-        *reinterpret_cast<uint2*>(p.out + mrow * p.n + nn) = pk;
+        if (p.epi) {
+          // weight rows 2j / 2j+1 are gate_j / up_j: both land in this lane.  Same arithmetic as the
+          // stand-alone kernels: the two GEMM outputs rounded to fp16, then silu(g) * u in fp32.
+          const float g0 = f16_bits_to_f32(o[0]), u0 = f16_bits_to_f32(o[1]);
+          const float g1 = f16_bits_to_f32(o[2]), u1 = f16_bits_to_f32(o[3]);
+          const uint32_t s0 = f32_to_f16_bits(g0 * ll_sigmoidf(g0) * u0);
+          const uint32_t s1 = f32_to_f16_bits(g1 * ll_sigmoidf(g1) * u1);
+          *reinterpret_cast<uint32_t*>(p.out + mrow * (p.n >> 1) + (nn >> 1)) = s0 | (s1 << 16);
+        } else {
+          uint2 pk;
+          pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+          pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+          *reinterpret_cast<uint2*>(p.out + mrow * p.n + nn) = pk;
+        }
       }
     }
   };
@@ -673,13 +684,14 @@ extern "C" int ll_w4a16_v2_workspace(int64_t m, int64_t n, int64_t k, int64_t* f
 extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweight, const float* scales,
                                   const float* zeros, const void* packed, const void* bias, int64_t m, int64_t n, int64_t k,
                                   int group_size, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
-                                  float* workspace, int32_t* counters, void* stream) {
+                                  float* workspace, int32_t* counters, int epilogue, void* stream) {
   const V2Plan pl = v2_plan(n, k);
   V2Params p{};
   p.out = (uint16_t*)out; p.x = (const uint16_t*)x; p.w = (const uint32_t*)qweight; p.scales = scales;
   p.zeros = zeros; p.packed = packed; p.bias = (const uint16_t*)bias; p.workspace = workspace; p.counters = counters;
   p.m = m; p.n = n; p.k = k; p.x_stride = x_stride_m; p.w_stride = qw_stride_n; p.s_stride = s_stride_n;
   p.nblocks = pl.nblocks; p.chunks = pl.chunks; p.total_units = pl.total_units; p.upw = pl.upw; p.slots = pl.slots;
+  p.epi = epilogue;
   p.gdiv = group_size / 128;
   p.gshift = -1;
   if ((p.gdiv & (p.gdiv - 1)) == 0) {

@@ -647,7 +647,7 @@ extern "C" int ll_w4a16_v2_supported(int64_t m, int64_t n, int64_t k, int group_
 extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweight, const float* scales,
                                   const float* zeros, const void* packed, const void* bias, int64_t m, int64_t n, int64_t k,
                                   int group_size, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
-                                  float* workspace, int32_t* counters, void* stream);
+                                  float* workspace, int32_t* counters, int epilogue, void* stream);
 
 extern "C" int ll_gemm_workspace(int64_t m, int64_t n, int64_t k, int64_t* workspace_floats,
                                  int64_t* counter_ints) {
@@ -700,12 +700,31 @@ extern "C" int ll_w4a16_matmul_packed(void* out, const void* x, const int32_t* q
   hipStream_t st = (hipStream_t)stream;
   if (workspace && counters && ll_w4a16_v2_supported(m, n, k, group_size))
     return ll_w4a16_v2_launch(out, x, qweight, scales, zeros, packed_sz, bias, m, n, k, group_size, x_stride_m,
-                              qw_stride_n, s_stride_n, workspace, counters, stream);
+                              qw_stride_n, s_stride_n, workspace, counters, 0, stream);
   if (group_size % 64 == 0) return launch_wgemm<FMT_W4, 1>(p, st);
   if (group_size == 32) return launch_wgemm<FMT_W4, 2>(p, st);
   if (group_size == 16) return launch_wgemm<FMT_W4, 4>(p, st);
   if (group_size == 8) return launch_wgemm<FMT_W4, 8>(p, st);
   return LL_ERR_SHAPE;
+}
+
+extern "C" int ll_w4a16_decode_supported(int64_t m, int64_t n, int64_t k, int group_size) {
+  return ll_w4a16_v2_supported(m, n, k, group_size) ? 1 : 0;
+}
+
+// Fused gate/up projection + swiglu for the decode engine: weight rows are interleaved
+// (row 2j = gate_j, row 2j+1 = up_j), out[m, n/2] = silu(gate) * up.  Only the decode engine
+// implements it; LL_ERR_SHAPE tells the caller to run the two-step form instead.
+extern "C" int ll_w4a16_gateup_swiglu(void* out, const void* x, const int32_t* qweight, const float* scales,
+                                      const float* zeros, const void* packed_sz, int64_t m, int64_t n, int64_t k,
+                                      int group_size, int64_t x_stride_m, int64_t qw_stride_n,
+                                      int64_t s_stride_n, float* workspace, int32_t* counters, void* stream) {
+  if (m <= 0 || n <= 0 || k <= 0 || group_size <= 0 || k % group_size != 0 || (n & 1)) return LL_ERR_SHAPE;
+  if (x_stride_m % 8 != 0 || qw_stride_n % 4 != 0) return LL_ERR_SHAPE;
+  if (!ll_aligned16(x) || !ll_aligned16(qweight) || !workspace || !counters) return LL_ERR_ARG;
+  if (!ll_w4a16_v2_supported(m, n, k, group_size)) return LL_ERR_SHAPE;
+  return ll_w4a16_v2_launch(out, x, qweight, scales, zeros, packed_sz, nullptr, m, n, k, group_size, x_stride_m,
+                            qw_stride_n, s_stride_n, workspace, counters, 1, stream);
 }
 
 extern "C" int ll_w4a16_matmul(void* out, const void* x, const int32_t* qweight, const float* scales,

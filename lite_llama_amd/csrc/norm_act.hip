@@ -167,7 +167,6 @@ extern "C" int ll_skip_rmsnorm(void* y, const void* x, void* residual, const voi
 // swiglu_forward -- reference lite_llama/kernels/swiglu.py:24-65
 // silu_and_mul   -- reference lite_llama/kernels/fused_moe.py:298-315
 // --------------------------------------------------------------------------- //
-__device__ __forceinline__ float sigmoidf(float v) { return 1.0f / (1.0f + expf(-v)); }
 
 // MODE 0: c[row, col] = silu(a[row, col]) * b[row, col]
 // MODE 1: c[row, col] = silu(x[row, col]) * x[row, n + col]   (x has 2n columns)
@@ -191,7 +190,7 @@ __global__ __launch_bounds__(256) void swiglu_kernel(uint16_t* __restrict__ c,
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const float g = to_f32<DT>(av[j]);
-      cv[j] = from_f32<DT>(g * sigmoidf(g) * to_f32<DT>(bv[j]));
+      cv[j] = from_f32<DT>(g * ll_sigmoidf(g) * to_f32<DT>(bv[j]));
     }
     VecIO<VEC>::store(c + row * n + col, cv);
   }

@@ -73,6 +73,36 @@ def w4a16_matmul(
     return out.reshape(*leading, n)
 
 
+def w4a16_gate_up_swiglu(x, qweight, scales, zeros, *, group_size=128, packed_scales=None):
+    """Extension: ``silu(x @ Wg.T) * (x @ Wu.T)`` in ONE launch, where ``qweight/scales/zeros`` hold the
+    gate and up projections row-interleaved (row ``2j`` = gate_j, row ``2j+1`` = up_j).  Same arithmetic as
+    ``swiglu_forward(w4a16_matmul(x, Wg..), w4a16_matmul(x, Wu..))`` (only the fp32 summation order of the
+    stream-K split can differ).  Returns ``None`` when the shape is
+    outside the decode engine (more than 64 rows, ...): the caller then runs the two-step form."""
+    L.require_cuda(x, qweight, scales, zeros, packed_scales)
+    n, k_packed = qweight.shape
+    k = k_packed * 8
+    leading = x.shape[:-1]
+    a = _flatten(x, k)
+    m = a.shape[0]
+    if (x.dtype != torch.float16 or qweight.dtype != torch.int32 or qweight.stride(1) != 1 or n % 2
+            or scales.dtype != torch.float32 or zeros.dtype != torch.float32 or scales.stride(1) != 1
+            or zeros.stride() != scales.stride() or m == 0
+            or not L.lib().ll_w4a16_decode_supported(m, n, k, int(group_size))):
+        return None
+    out = torch.empty((m, n // 2), dtype=x.dtype, device=x.device)
+    ws, cnt = L.gemm_workspace(x.device, m, n, k)
+    L.check(
+        L.lib().ll_w4a16_gateup_swiglu(
+            out.data_ptr(), a.data_ptr(), qweight.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
+            L.ptr(packed_scales), m, n, k, int(group_size), a.stride(0), qweight.stride(0), scales.stride(0),
+            ws.data_ptr(), cnt.data_ptr(), L.stream_ptr(),
+        ),
+        "w4a16_gate_up_swiglu",
+    )
+    return out.reshape(*leading, n // 2)
+
+
 def pack_w4a16_scales(scales: torch.Tensor, zeros: torch.Tensor) -> torch.Tensor:
     """Load-time companion of :func:`w4a16_matmul`: ``[N, K/g]`` fp32 scales/zeros -> int32
     ``[K/g, N, 2]`` holding the fp16 pairs ``(s, s)``, ``(-z*s, -z*s)`` the GEMM feeds its dequant."""

@@ -89,8 +89,12 @@ class MergedColumnLinear:
     Not an ``nn.Module``: it owns no parameters of its own.
     """
 
-    def __init__(self, layers):
+    def __init__(self, layers, interleave: bool = False):
+        """``interleave``: for a (gate, up) pair whose quant method offers ``apply_gate_up_swiglu``,
+        store the two row-INTERLEAVED (row 2j = gate_j, row 2j+1 = up_j; the members become the
+        stride-2 row views) so that :meth:`swiglu` can run projection + activation as one launch."""
         self.layers = list(layers)
+        self.interleave = interleave
         self._key = None
         self._holder = None
 
@@ -111,7 +115,10 @@ class MergedColumnLinear:
         self._holder = None
         ok = all(type(l.quant_method) is type(first.quant_method) and l.quant == first.quant
                  and l.input_size == first.input_size for l in self.layers)
+        il = (self.interleave and ok and len(self.layers) == 2 and hasattr(first.quant_method, "apply_gate_up_swiglu")
+              and self.layers[0].output_size == self.layers[1].output_size)
         holder = _MergedHolder()
+        holder.interleaved = il
         holder.input_size = first.input_size
         holder.output_size = sum(l.output_size for l in self.layers)
         holder.quant, holder.quant_method = first.quant, first.quant_method
@@ -124,7 +131,10 @@ class MergedColumnLinear:
             if any(t is None for t in ts) or len({(t.dtype, t.shape[1:]) for t in ts}) != 1:
                 ok = False
                 break
-            merged[name] = torch.cat([t.data for t in ts], dim=0)
+            if il:
+                merged[name] = torch.stack([t.data for t in ts], dim=1).reshape(-1, *ts[0].shape[1:])
+            else:
+                merged[name] = torch.cat([t.data for t in ts], dim=0)
             if first.quant is not None and ("scale" in name or "zeros" in name):
                 if tuple(merged[name].shape) != tuple(first.quant.scale_shape(holder.output_size, holder.input_size)):
                     ok = False
@@ -135,9 +145,10 @@ class MergedColumnLinear:
                 if cat is None:
                     continue
                 off = 0
-                for l in self.layers:
+                for i, l in enumerate(self.layers):
                     rows = l._parameters[name].shape[0]
-                    l._parameters[name] = nn.Parameter(cat[off:off + rows], requires_grad=False)
+                    view = cat[i::2] if il else cat[off:off + rows]
+                    l._parameters[name] = nn.Parameter(view, requires_grad=False)
                     off += rows
             self._holder = holder
         self._key = self._snapshot()
@@ -146,7 +157,22 @@ class MergedColumnLinear:
     def __call__(self, x: torch.Tensor):
         """-> one output view per member (column blocks of the merged ``[..., sum N]`` result)."""
         out = self._holder.quant_method.apply(self._holder, x)
+        if self._holder.interleaved:
+            return out[..., 0::2], out[..., 1::2]
         return torch.split(out, [l.output_size for l in self.layers], dim=-1)
+
+    def swiglu(self, x: torch.Tensor) -> torch.Tensor:
+        """``silu(gate(x)) * up(x)`` for a (gate, up) pair: one launch when interleaved and the shape is
+        in the decode engine, else the merged GEMM followed by ``swiglu_forward``."""
+        from .kernels import swiglu_forward
+
+        h = self._holder
+        if h.interleaved:
+            y = h.quant_method.apply_gate_up_swiglu(h, x)
+            if y is not None:
+                return y
+        gate, up = self(x)
+        return swiglu_forward(gate, up)
 
 
 class _MergedHolder:

@@ -212,14 +212,12 @@ class FusedMLP(nn.Module):
         self.gate_proj = ColumnParallelLinear(h, i, quant=quant, what="MLP intermediate")
         self.up_proj = ColumnParallelLinear(h, i, quant=quant, what="MLP intermediate")
         self.down_proj = RowParallelLinear(i, h, quant=quant, what="MLP intermediate")
-        object.__setattr__(self, "_gate_up", MergedColumnLinear([self.gate_proj, self.up_proj]))
+        object.__setattr__(self, "_gate_up", MergedColumnLinear([self.gate_proj, self.up_proj], interleave=True))
 
     def forward(self, x):
         if self._gate_up.refresh():
-            gate, up = self._gate_up(x)  # adjacent column halves of one [.., 2I] buffer
-        else:
-            gate, up = self.gate_proj(x), self.up_proj(x)
-        return self.down_proj(swiglu_forward(gate, up))
+            return self.down_proj(self._gate_up.swiglu(x))  # one launch (int4 decode) or merged GEMM + swiglu
+        return self.down_proj(swiglu_forward(self.gate_proj(x), self.up_proj(x)))
 
 
 class SparseMoeBlock(nn.Module):

@@ -14,7 +14,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..kernels import fused_moe, smoothquant_matmul, w4a16_matmul, w8a16_matmul
-from ..kernels.quantization import pack_w4a16_scales
+from ..kernels.quantization import pack_w4a16_scales, w4a16_gate_up_swiglu
 from .config import FP8, INT4, INT8, SMOOTHQUANT, QuantConfig
 from .params import (
     quantize_fp8_per_channel,
@@ -74,6 +74,14 @@ class W4A16LinearMethod(LinearQuantMethod):
         return w4a16_matmul(x, layer.weight, layer.weight_scale, layer.weight_zeros,
                             group_size=layer.quant.group_k, bias=layer.bias,
                             packed_scales=self._packed(layer))
+
+    def apply_gate_up_swiglu(self, layer, x):
+        """``layer`` holds gate/up row-interleaved (linear.py::MergedColumnLinear): one launch for
+        both projections and the activation; ``None`` -> the caller falls back to the two-step form."""
+        if layer.bias is not None:
+            return None
+        return w4a16_gate_up_swiglu(x, layer.weight, layer.weight_scale, layer.weight_zeros,
+                                    group_size=layer.quant.group_k, packed_scales=self._packed(layer))
 
     @staticmethod
     def _packed(layer):

@@ -594,3 +594,29 @@ def test_rope_and_cache_equals_rope_then_update_kv_buffer(HQ, HKV, D, B, S):
     rope_and_cache(qb, kvb, cos, sin, B, S, sel, pool_b)
     assert torch.equal(a, b) and torch.equal(pool_a, pool_b)
     assert not torch.equal(a, qkv)  # really rotated in place
+
+
+@pytest.mark.parametrize("M,I,K_,gs", [(64, 18944, 3584, 128), (5, 512, 256, 128), (33, 1024, 1024, 256)])
+def test_w4a16_gate_up_swiglu_equals_two_gemms_and_swiglu(M, I, K_, gs):
+    from lite_llama_amd.kernels.quantization import pack_w4a16_scales, w4a16_gate_up_swiglu
+    g = torch.Generator().manual_seed(I + K_)
+    x = (torch.randn(M, K_, generator=g) * 0.5).half().to(DEV)
+
+    def rand_w():
+        return (torch.randint(-(2**31), 2**31 - 1, (I, K_ // 8), dtype=torch.int64, generator=g).to(torch.int32).to(DEV),
+                (torch.rand(I, K_ // gs, generator=g) * 0.01 + 0.005).to(DEV),
+                torch.randint(0, 16, (I, K_ // gs), generator=g).float().to(DEV))
+
+    (qg, sg, zg), (qu, su, zu) = rand_w(), rand_w()
+    ref = K().swiglu_forward(K().w4a16_matmul(x, qg, sg, zg, group_size=gs), K().w4a16_matmul(x, qu, su, zu, group_size=gs))
+    il = lambda a, b: torch.stack([a, b], dim=1).reshape(2 * I, -1).contiguous()
+    q2, s2, z2 = il(qg, qu), il(sg, su), il(zg, zu)
+    for pk in (None, pack_w4a16_scales(s2, z2)):
+        got = w4a16_gate_up_swiglu(x, q2, s2, z2, group_size=gs, packed_scales=pk)
+        assert got is not None
+        # same arithmetic; the stream-K split points of the 2I-row launch differ from those of the two
+        # I-row launches, so the fp32 summation order (and rarely the last fp16 bit) may differ
+        torch.testing.assert_close(got.float(), ref.float(), rtol=2e-3, atol=2e-3)
+        assert (got == ref).float().mean() > 0.99
+        assert torch.equal(got, w4a16_gate_up_swiglu(x, q2, s2, z2, group_size=gs, packed_scales=pk))  # deterministic
+    assert w4a16_gate_up_swiglu(x.repeat(14, 1)[:65], q2, s2, z2, group_size=gs) is None  # > 64 rows
