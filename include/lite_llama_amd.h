@@ -189,6 +189,17 @@ int ll_silu_and_mul(void* out, const void* x, int64_t rows, int64_t n, int dtype
 int ll_moe_sum(void* out, const void* x, int64_t tokens, int top_k, int64_t n, int dtype,
                void* stream);
 
+/* Decode-step bookkeeping in one launch (executor extension; the reference issues these as
+ * separate tensor ops, model_runner.py:200-218 + llm_engine.py:173-213): records the sampled
+ * tokens, feeds them back, advances positions / sequence lengths / the bump-allocated KV rows and
+ * writes the new rows into the token table (= update_kv_index).  int64: out [batch, *] (row stride
+ * given), step [1], next_tokens, input_ids, positions; int32: cur_select_index, b_seq_len,
+ * b_req_idx, table. */
+int ll_decode_advance(int64_t* out, int64_t out_stride, int64_t* step, const int64_t* next_tokens,
+                      int64_t* input_ids, int64_t* positions, int32_t* cur_select_index,
+                      int32_t* b_seq_len, const int32_t* b_req_idx, int32_t* table,
+                      int64_t table_stride_b, int64_t table_stride_s, int batch, void* stream);
+
 /* ---- a16: greedy argmax over logits [rows, n] (engine/sampler.py:227-228) ----- */
 int ll_argmax(int64_t* out, const void* logits, int64_t rows, int64_t n, int64_t stride_row,
               int dtype, void* stream);

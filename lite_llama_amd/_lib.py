@@ -48,6 +48,7 @@ SIGNATURES = {
     "ll_silu_and_mul": [P, P, L, L, I, P],
     "ll_moe_sum": [P, P, L, I, L, I, P],
     "ll_argmax": [P, P, L, L, L, I, P],
+    "ll_decode_advance": [P, L, P, P, P, P, P, P, P, P, L, L, I, P],
     "ll_argmax_split": [P, P, L, L, L, I, P, I, P],
 }
 

@@ -73,4 +73,49 @@ extern "C" int ll_update_kv_index(int32_t* table, const void* b_req_idx, const v
   return LL_LAUNCH_CHECK();
 }
 
+// --------------------------------------------------------------------------- //
+// One launch for the per-token bookkeeping of a lockstep greedy decode step (the reference does it
+// with a handful of host-issued tensor ops: model_runner.py:200-218 + llm_engine.py:173-213):
+//   out[i, step] = next[i]; input_ids[i] = next[i]; positions[i] += 1;
+//   cur_select_index[i] += batch (the bump allocator's next rows); b_seq_len[i] += 1;
+//   table[b_req_idx[i], b_seq_len[i] - 1] = cur_select_index[i]   (= update_kv_index);  step += 1
+// Single workgroup (rows are independent; the shared step counter is bumped after a barrier).
+// --------------------------------------------------------------------------- //
+__global__ __launch_bounds__(256) void decode_advance_kernel(
+    int64_t* __restrict__ out, int64_t out_stride, int64_t* __restrict__ step, const int64_t* __restrict__ next,
+    int64_t* __restrict__ input_ids, int64_t* __restrict__ positions, int32_t* __restrict__ cur_select,
+    int32_t* __restrict__ b_seq_len, const int32_t* __restrict__ b_req_idx, int32_t* __restrict__ table,
+    int64_t t_sb, int64_t t_ss, int batch) {
+  const int64_t st = *step;
+  for (int i = threadIdx.x; i < batch; i += 256) {
+    const int64_t tok = next[i];
+    out[(int64_t)i * out_stride + st] = tok;
+    input_ids[i] = tok;
+    positions[i] += 1;
+    const int32_t sel = cur_select[i] + batch;
+    cur_select[i] = sel;
+    const int32_t len = b_seq_len[i] + 1;
+    b_seq_len[i] = len;
+    table[(int64_t)b_req_idx[i] * t_sb + (int64_t)(len - 1) * t_ss] = sel;
+  }
+  __syncthreads();
+  if (threadIdx.x == 0) *step = st + 1;
+}
+
+extern "C" int ll_decode_advance(int64_t* out, int64_t out_stride, int64_t* step, const int64_t* next_tokens,
+                                 int64_t* input_ids, int64_t* positions, int32_t* cur_select_index,
+                                 int32_t* b_seq_len, const int32_t* b_req_idx, int32_t* table,
+                                 int64_t table_stride_b, int64_t table_stride_s, int batch, void* stream) {
+  if (batch < 0) return LL_ERR_SHAPE;
+  if (batch == 0) return LL_OK;
+  if (!out || !step || !next_tokens || !input_ids || !positions || !cur_select_index || !b_seq_len ||
+      !b_req_idx || !table)
+    return LL_ERR_ARG;
+  decode_advance_kernel<<<dim3(1), 256, 0, (hipStream_t)stream>>>(out, out_stride, step, next_tokens, input_ids,
+                                                                 positions, cur_select_index, b_seq_len,
+                                                                 b_req_idx, table, table_stride_b,
+                                                                 table_stride_s, batch);
+  return LL_LAUNCH_CHECK();
+}
+
 extern "C" int ll_abi_version(void) { return 1; }

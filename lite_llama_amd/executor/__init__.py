@@ -18,6 +18,7 @@ from dataclasses import dataclass, field
 
 import torch
 
+from .. import _lib as L
 from ..kernels import update_kv_index
 from ..sampling import greedy_argmax
 
@@ -84,6 +85,8 @@ class DecodeEngine:
         self.info.b_req_tokens_table = torch.zeros(max_batch, max_seq_len, dtype=torch.int32, device=device)
         self._graph = None
         self._graph_key = None
+        if hasattr(model, "rotary_emb") and torch.device(device).type == "cuda":
+            model.rotary_emb.ensure(max_seq_len + 1, device, model.embed_tokens.weight.dtype)
 
     # ------------------------------------------------------------------ prefill ----- #
     @torch.no_grad()
@@ -154,6 +157,25 @@ class DecodeEngine:
         info, b = self.info, self._batch
         logits = self.model(self._input_ids, self._positions, info)
         nxt = greedy_argmax(logits[:, -1, :])
+        self._advance(nxt)
+
+    def _advance(self, nxt: torch.Tensor) -> None:
+        """record -> feed back -> positions/lengths/KV rows += -> token table: one launch when the state
+        has the engine's own dtypes, else the reference-shaped sequence of tensor ops."""
+        info, b = self.info, self._batch
+        t = info.b_req_tokens_table
+        if (nxt.dtype == torch.int64 and info.cur_select_index.dtype == torch.int32 and info.b_seq_len.dtype == torch.int32
+                and info.b_req_idx.dtype == torch.int32 and t.dtype == torch.int32 and nxt.is_contiguous()
+                and info.cur_select_index.is_contiguous() and info.b_seq_len.is_contiguous()
+                and info.b_req_idx.is_contiguous()):
+            L.check(
+                L.lib().ll_decode_advance(
+                    self._out.data_ptr(), self._out.stride(0), self._step.data_ptr(), nxt.data_ptr(),
+                    self._input_ids.data_ptr(), self._positions.data_ptr(), info.cur_select_index.data_ptr(),
+                    info.b_seq_len.data_ptr(), info.b_req_idx.data_ptr(), t.data_ptr(), t.stride(0), t.stride(1),
+                    b, L.stream_ptr()),
+                "decode_advance")
+            return
         self._out.view(-1).scatter_(0, self._row_base + self._step, nxt)
         self._step += 1
         self._input_ids.copy_(nxt.view(b, 1))

@@ -112,13 +112,32 @@ class RotaryEmbedding(nn.Module):
             mid = (wavelen <= orig / lo) & (wavelen >= orig / hi)
             inv_freq = torch.where(mid, smoothed, scaled)
         self.register_buffer("inv_freq", inv_freq, persistent=False)
+        self._cache = None  # (cos [P, D], sin [P, D]) for positions 0..P-1, built with the very same ops
+
+    @torch.no_grad()
+    def _tables(self, pos: torch.Tensor, dtype):
+        freqs = pos.to(torch.float32)[..., None] * self.inv_freq.to(pos.device)
+        emb = torch.cat((freqs, freqs), dim=-1)
+        return emb.cos().to(dtype), emb.sin().to(dtype)
+
+    @torch.no_grad()
+    def ensure(self, max_positions: int, device, dtype=torch.float16) -> None:
+        """Pre-build the position-indexed cos/sin cache (a decode step then needs one gather per table
+        instead of seven elementwise launches).  Entries are computed by exactly the ops of the direct
+        path, so both paths return identical values.  Call before graph capture."""
+        c = self._cache
+        if c is not None and c[0].shape[0] >= max_positions and c[0].device == torch.device(device) and c[0].dtype == dtype:
+            return
+        self._cache = self._tables(torch.arange(max_positions, device=device), dtype)
 
     @torch.no_grad()
     def forward(self, x: torch.Tensor, position_ids: torch.Tensor):
         """``(cos, sin)`` shaped ``[batch, seq, head_dim]`` in ``x.dtype``."""
-        freqs = position_ids.to(torch.float32)[:, :, None] * self.inv_freq.to(x.device)[None, None, :]
-        emb = torch.cat((freqs, freqs), dim=-1)
-        return emb.cos().to(x.dtype), emb.sin().to(x.dtype)
+        c = self._cache
+        if (c is not None and position_ids.shape[1] == 1 and c[0].dtype == x.dtype and c[0].device == x.device):
+            # decode: cached rows (callers guarantee positions < the size given to ``ensure``)
+            return c[0][position_ids], c[1][position_ids]
+        return self._tables(position_ids, x.dtype)
 
 
 # ------------------------------------------------------------------------------------- #

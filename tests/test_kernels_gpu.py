@@ -620,3 +620,32 @@ def test_w4a16_gate_up_swiglu_equals_two_gemms_and_swiglu(M, I, K_, gs):
         assert (got == ref).float().mean() > 0.99
         assert torch.equal(got, w4a16_gate_up_swiglu(x, q2, s2, z2, group_size=gs, packed_scales=pk))  # deterministic
     assert w4a16_gate_up_swiglu(x.repeat(14, 1)[:65], q2, s2, z2, group_size=gs) is None  # > 64 rows
+
+
+def test_decode_advance_equals_the_separate_tensor_ops():
+    import lite_llama_amd._lib as L
+    g = torch.Generator().manual_seed(7)
+    b, max_new, max_req, max_len = 64, 9, 80, 40
+    out = torch.zeros(b, max_new, dtype=torch.int64, device=DEV)
+    step = torch.tensor([3], dtype=torch.int64, device=DEV)
+    nxt = torch.randint(0, 50000, (b,), generator=g).to(DEV)
+    ids = torch.zeros(b, 1, dtype=torch.int64, device=DEV)
+    pos = torch.randint(5, 20, (b, 1), generator=g).to(DEV)
+    sel = torch.arange(1000, 1000 + b, dtype=torch.int32, device=DEV)
+    seq = torch.randint(5, 20, (b,), generator=g).int().to(DEV)
+    req = torch.randperm(max_req, generator=g)[:b].int().to(DEV)
+    table = torch.zeros(max_req, max_len, dtype=torch.int32, device=DEV)
+    e = [t.clone() for t in (out, step, ids, pos, sel, seq, table)]
+    # reference-shaped sequence
+    e[0].view(-1).scatter_(0, torch.arange(b, device=DEV) * max_new + e[1], nxt)
+    e[1] += 1
+    e[2].copy_(nxt.view(b, 1))
+    e[3] += 1
+    e[4] += b
+    e[5] += 1
+    K().update_kv_index(e[6], req, e[5], e[4])
+    L.check(L.lib().ll_decode_advance(out.data_ptr(), out.stride(0), step.data_ptr(), nxt.data_ptr(), ids.data_ptr(),
+                                      pos.data_ptr(), sel.data_ptr(), seq.data_ptr(), req.data_ptr(), table.data_ptr(),
+                                      table.stride(0), table.stride(1), b, L.stream_ptr()), "decode_advance")
+    for got, want in zip((out, step, ids, pos, sel, seq, table), e):
+        assert torch.equal(got, want)
