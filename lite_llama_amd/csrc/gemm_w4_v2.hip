@@ -54,6 +54,9 @@ struct V2Params {
   int64_t m, n, k;
   int64_t x_stride, w_stride, s_stride;  // elements / int32 words / floats per row
   int nblocks, chunks, total_units, upw, slots;
+  // tile-group split (gt > 0, see v2_plan): gt workgroups per tile; contributor j owns
+  // gbase + (j < grem) chunks, the last one (the owner) gbase + glead
+  int gt, gbase, grem, glead;
   int gshift;  // log2(group_size / 128) when a power of two, else -1
   int gdiv;    // group_size / 128
   int epi;     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu (ll_w4a16_gateup_swiglu)
@@ -122,9 +125,17 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chunks = p.chunks;
-  const int ub = blockIdx.x * p.upw;
-  int ue = ub + p.upw;
-  if (ue > p.total_units) ue = p.total_units;
+  int ub, ue;
+  if (p.gt) {
+    const int gtile = (int)blockIdx.x / p.gt, j = (int)blockIdx.x - gtile * p.gt;
+    const int lo = j * p.gbase + (j < p.grem ? j : p.grem);
+    ub = gtile * chunks + lo;
+    ue = j == p.gt - 1 ? (gtile + 1) * chunks : ub + p.gbase + (j < p.grem ? 1 : 0);
+  } else {
+    ub = blockIdx.x * p.upw;
+    ue = ub + p.upw;
+    if (ue > p.total_units) ue = p.total_units;
+  }
   if (ub >= ue) return;
   const int cnt = ue - ub;
   const int tA = ub / chunks, cA = ub - tA * chunks;
@@ -397,7 +408,7 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   };
 
   auto flush = [&](int t, int c_lo, int c_hi) {
-    const int w0 = (int)(((int64_t)t * chunks) / p.upw);  // first contributor of the tile
+    const int w0 = p.gt ? t * p.gt : (int)(((int64_t)t * chunks) / p.upw);  // first contributor of the tile
     const int slot = (int)blockIdx.x - w0;
     if (c_hi != chunks - 1) {
       // contributor: park the partial in this workgroup's slab (flag follows, see post_pending)
@@ -595,6 +606,7 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 // ---------------------------------------------------------------------------------- //
 struct V2Plan {
   int nblocks, chunks, total_units, upw, grid, slots;
+  int gt, gbase, grem, glead;
 };
 
 static int v2_num_cus() {
@@ -618,6 +630,32 @@ static V2Plan v2_plan(int64_t n, int64_t k) {
   if (const char* e = getenv("LL_GEMM2_WGS")) {
     const int v = atoi(e);
     if (v > 0) target = v;
+  }
+  pl.gt = pl.gbase = pl.grem = pl.glead = 0;
+  // Few tiles (N <= 16 K at K = 3584): every tile is shared by gt workgroups and, with equal
+  // shares, all of them finish together -- the owner then pays the whole merge chain (store ack,
+  // flag, poll, slab loads: ~8 us) after its last unit.  Tile-group split: the owner gets `lead`
+  // more chunks than the contributors, so their slabs and flags have landed by the time it is
+  // done; the chain collapses to one round of slab loads.
+  int lead = 4;  // measured: 4 units (~3.5 us) cover the contributors' store ack + flag
+  if (const char* e = getenv("LL_GEMM2_LEAD")) lead = atoi(e);
+  int gt = pl.nblocks > 0 ? target / pl.nblocks : 0;
+  if (gt > V2_MAX_SLOTS) gt = V2_MAX_SLOTS;
+  // the owner adds the slabs two per fabric round trip (more contributors, more rounds) and runs
+  // lead units longer than everybody else: measured optimum ~ one workgroup per 5 chunks
+  // (28 chunks -> 5, 148 chunks -> as many as there are CUs for)
+  int gt_cap = pl.chunks / 5;
+  if (const char* e = getenv("LL_GEMM2_GT")) gt_cap = atoi(e);
+  if (gt > gt_cap) gt = gt_cap;
+  if (lead > 0 && gt >= 2 && pl.chunks - lead >= gt) {
+    pl.gt = gt;
+    pl.glead = lead;
+    pl.gbase = (pl.chunks - lead) / gt;
+    pl.grem = (pl.chunks - lead) % gt;
+    pl.upw = pl.gbase + lead;  // the longest range (table capacity check)
+    pl.grid = pl.nblocks * gt;
+    pl.slots = gt;
+    return pl;
   }
   int upw = (pl.total_units + target - 1) / target;
   // a tile has at most (chunks - 2) / upw + 2 contributors
@@ -691,6 +729,7 @@ extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweig
   p.zeros = zeros; p.packed = packed; p.bias = (const uint16_t*)bias; p.workspace = workspace; p.counters = counters;
   p.m = m; p.n = n; p.k = k; p.x_stride = x_stride_m; p.w_stride = qw_stride_n; p.s_stride = s_stride_n;
   p.nblocks = pl.nblocks; p.chunks = pl.chunks; p.total_units = pl.total_units; p.upw = pl.upw; p.slots = pl.slots;
+  p.gt = pl.gt; p.gbase = pl.gbase; p.grem = pl.grem; p.glead = pl.glead;
   p.epi = epilogue;
   p.gdiv = group_size / 128;
   p.gshift = -1;
