@@ -50,7 +50,6 @@ __global__ __launch_bounds__(64) void fd_stage1(
     int hq, int hkv, int nparts, float scale, int64_t q_sb, int64_t q_sh, int64_t k_st, int64_t k_sh,
     int64_t v_st, int64_t v_sh, int64_t t_sb, int req_w, int seq_w) {
   constexpr int NS = D / 32;      // MFMA k-steps over the head dim
-  constexpr int DQ = D / 4;       // contiguous d-range owned by one lane row-group
   constexpr int NT = D / 16;      // output d-tiles
   constexpr int VSTR = D + 8;     // padded LDS row stride (elements)
   __shared__ __attribute__((aligned(16))) uint16_t lds_v[32 * VSTR];
@@ -73,12 +72,13 @@ __global__ __launch_bounds__(64) void fd_stage1(
   const int64_t req = fd_load_idx(b_req_idx, b, req_w);
   const int32_t* trow = table + req * t_sb;
 
-  // Q^T fragments (MFMA B operand): lane (head t, group c) holds q[head][c*DQ + s*8 .. +8]
+  // Q^T fragments (MFMA B operand): lane (head t, group c) holds q[head][s*32 + c*8 .. +8] -- the
+  // natural k order of MFMA step s, so the 4 lanes of a row read 64 contiguous bytes per instruction
   Q4 qf[NS];
 #pragma unroll
   for (int s = 0; s < NS; ++s) {
     if (head_ok)
-      qf[s] = *reinterpret_cast<const Q4*>(q + b * q_sb + (int64_t)head * q_sh + c * DQ + s * 8);
+      qf[s] = *reinterpret_cast<const Q4*>(q + b * q_sb + (int64_t)head * q_sh + s * 32 + c * 8);
     else
       qf[s] = Q4{0, 0, 0, 0};
   }
@@ -98,21 +98,22 @@ __global__ __launch_bounds__(64) void fd_stage1(
   const int r0 = trow[tk0], r1 = trow[tk1];
 
   // ---- gather of tile TI (32 tokens): lane (t, c) fetches rows TI*32+t and TI*32+16+t, d-range
-  //      [c*DQ, +DQ), straight into MFMA fragment layout.  Unconditional (clamped rows): hipcc
+  //      {s*32 + c*8 .. +8}, straight into MFMA fragment layout (per instruction the 4 lanes of a row
+  //      read 64 contiguous bytes: 16 sectors per wave-load instead of 64 partial ones).  Unconditional (clamped rows): hipcc
   //      drains vmcnt(0) around any branch that contains a load.
 #define FD_LOAD(S, TI)                                                                         \
   {                                                                                            \
     const int rsrc_ = (TI) < 2 ? r0 : r1;                                                      \
     const int64_t rowA_ = __shfl(rsrc_, ((TI) & 1) * 32 + t, 64);                              \
     const int64_t rowB_ = __shfl(rsrc_, ((TI) & 1) * 32 + 16 + t, 64);                         \
-    const uint16_t* kA_ = kc + rowA_ * k_st + (int64_t)kvh * k_sh + c * DQ;                    \
-    const uint16_t* kB_ = kc + rowB_ * k_st + (int64_t)kvh * k_sh + c * DQ;                    \
-    const uint16_t* vA_ = vc + rowA_ * v_st + (int64_t)kvh * v_sh + c * DQ;                    \
-    const uint16_t* vB_ = vc + rowB_ * v_st + (int64_t)kvh * v_sh + c * DQ;                    \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) ka##S[s] = *reinterpret_cast<const Q4*>(kA_ + s * 8); \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) kb##S[s] = *reinterpret_cast<const Q4*>(kB_ + s * 8); \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) va##S[s] = *reinterpret_cast<const Q4*>(vA_ + s * 8); \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) vb##S[s] = *reinterpret_cast<const Q4*>(vB_ + s * 8); \
+    const uint16_t* kA_ = kc + rowA_ * k_st + (int64_t)kvh * k_sh + c * 8;                    \
+    const uint16_t* kB_ = kc + rowB_ * k_st + (int64_t)kvh * k_sh + c * 8;                    \
+    const uint16_t* vA_ = vc + rowA_ * v_st + (int64_t)kvh * v_sh + c * 8;                    \
+    const uint16_t* vB_ = vc + rowB_ * v_st + (int64_t)kvh * v_sh + c * 8;                    \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) ka##S[s] = *reinterpret_cast<const Q4*>(kA_ + s * 32); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) kb##S[s] = *reinterpret_cast<const Q4*>(kB_ + s * 32); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) va##S[s] = *reinterpret_cast<const Q4*>(vA_ + s * 32); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) vb##S[s] = *reinterpret_cast<const Q4*>(vB_ + s * 32); \
   }
 
   // ---- one 32-token tile: S^T, online softmax, O^T += V^T P^T ----
@@ -156,8 +157,8 @@ __global__ __launch_bounds__(64) void fd_stage1(
     /* stage V rows through LDS (zero rows past the end: garbage could be NaN) */              \
     __syncthreads(); /* previous tile's reads done */                                          \
     _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                           \
-      *reinterpret_cast<Q4*>(&lds_v[t * VSTR + c * DQ + s * 8]) = okA ? va##S[s] : Q4{0, 0, 0, 0};        \
-      *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + c * DQ + s * 8]) = okB ? vb##S[s] : Q4{0, 0, 0, 0}; \
+      *reinterpret_cast<Q4*>(&lds_v[t * VSTR + s * 32 + c * 8]) = okA ? va##S[s] : Q4{0, 0, 0, 0};        \
+      *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + s * 32 + c * 8]) = okB ? vb##S[s] : Q4{0, 0, 0, 0}; \
     }                                                                                          \
     __syncthreads();                                                                           \
     /* O^T[d][head] += V^T[d][tok] . P^T[tok][head] */                                         \
