@@ -501,43 +501,37 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   int seg_lo = (fl >> 1) & 0xFFF;
   int rbuf = 0, wslot = 0;
   __syncthreads();  // prologue barrier: units 0, 1 staged
-  // Operands are fetched ONE UNIT AHEAD, across the barrier (a unit is staged in LDS two steps
-  // before it is consumed, so unit v+1 is already there while unit v is being multiplied): the
-  // LDS round trips of the first MFMA step never sit on the critical path.
+  // ALL operands of a unit are fetched ONE UNIT AHEAD, across the barrier (a unit is staged in LDS
+  // two steps before it is consumed, so unit v+1 is already there while unit v is multiplied).
+  // The consumers are the critical role (they wait at the barrier 20 % of the time, the loaders
+  // 55 %): with same-unit reads all 8 consumer waves hit the LDS together right after the barrier
+  // (80 ds_read_b128 = ~320 LDS cycles, plus the memory roles' stores) while the matrix pipes
+  // idle; one unit ahead, the LDS time hides under the MFMAs.  Each step's prefetch is pinned
+  // behind that step's MFMAs with a scheduling barrier (hipcc otherwise sinks the reads to their
+  // use to save registers).
   Q4 wq = *reinterpret_cast<const Q4*>(lds + V2_OFF_W + woff);
   uint2 sz = *reinterpret_cast<const uint2*>(lds + V2_OFF_S + soff);
-  f16x8 a0[MT];
+  f16x8 af[4][MT];
 #pragma unroll
-  for (int mt = 0; mt < MT; ++mt) a0[mt] = *reinterpret_cast<const f16x8*>(lds + V2_OFF_A + aoff + mt * 32 * V2_A_ROW);
+  for (int s = 0; s < 4; ++s)
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+      af[s][mt] = *reinterpret_cast<const f16x8*>(lds + V2_OFF_A + aoff + mt * 32 * V2_A_ROW + s * 16);
   for (;;) {
     const int rbuf_n = rbuf == V2_XR - 1 ? 0 : rbuf + 1;
     const int wslot_n = wslot == V2_RW - 1 ? 0 : wslot + 1;
     Q4 wq_n = wq;
     uint2 sz_n = sz;
-    f16x8 a0_n[MT];
+    f16x8 an[4][MT];
     int fl_n = 0;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a0_n[mt] = a0[mt];
-    if constexpr (!(ABL & 4)) {
-      const unsigned char* ab = lds + V2_OFF_A + rbuf * V2_A_TILE + aoff;
-      f16x8 acur[MT], anxt[MT];
+    for (int s = 0; s < 4; ++s)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) acur[mt] = a0[mt];
+      for (int mt = 0; mt < MT; ++mt) an[s][mt] = af[s][mt];
+    if constexpr (!(ABL & 4)) {
+      const unsigned char* abn = lds + V2_OFF_A + rbuf_n * V2_A_TILE + aoff;
 #pragma unroll
       for (int s = 0; s < 4; ++s) {
-        if (s + 1 < 4) {
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt)
-            anxt[mt] = *reinterpret_cast<const f16x8*>(ab + mt * 32 * V2_A_ROW + (s + 1) * 16);
-        }
-        if (s == 2) {  // next unit's first operands, issued under this unit's last MFMAs
-          wq_n = *reinterpret_cast<const Q4*>(lds + V2_OFF_W + wslot_n * 8192 + woff);
-          sz_n = *reinterpret_cast<const uint2*>(lds + V2_OFF_S + wslot_n * 1024 + soff);
-          const unsigned char* abn = lds + V2_OFF_A + rbuf_n * V2_A_TILE + aoff;
-#pragma unroll
-          for (int mt = 0; mt < MT; ++mt) a0_n[mt] = *reinterpret_cast<const f16x8*>(abn + mt * 32 * V2_A_ROW);
-          fl_n = V2_ENTRY(cv + 1).w;
-        }
         const uint32_t word = s == 0 ? wq.x : s == 1 ? wq.y : s == 2 ? wq.z : wq.w;
         Q4 wf;
         if constexpr (ABL & 256) {
@@ -548,21 +542,34 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         const f16x8 wfrag = __builtin_bit_cast(f16x8, wf);
         if constexpr (ABL & 128) {  // debug: no MFMA
 #pragma unroll
-          for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(wfrag), "v"(acur[mt]));
+          for (int mt = 0; mt < MT; ++mt) asm volatile("" ::"v"(wfrag), "v"(af[s][mt]));
         } else {
 #pragma unroll
           for (int mt = 0; mt < MT; ++mt)
-            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, acur[mt], acc[mt], 0, 0, 0);
+            acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, af[s][mt], acc[mt], 0, 0, 0);
         }
+        // next unit, same step
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acur[mt] = anxt[mt];
+        for (int mt = 0; mt < MT; ++mt)
+          an[s][mt] = *reinterpret_cast<const f16x8*>(abn + mt * 32 * V2_A_ROW + s * 16);
+        if (s == 0) {
+          wq_n = *reinterpret_cast<const Q4*>(lds + V2_OFF_W + wslot_n * 8192 + woff);
+          sz_n = *reinterpret_cast<const uint2*>(lds + V2_OFF_S + wslot_n * 1024 + soff);
+          // only the flags dword: a 16-B read into temporaries the dequant wants back would force
+          // a full lgkmcnt(0) right here
+          fl_n = reinterpret_cast<const int*>(&tab[cv + 1 < last ? cv + 1 : last])[3];
+        }
+        __builtin_amdgcn_sched_barrier(0);
       }
     } else {
       fl_n = V2_ENTRY(cv + 1).w;
     }
     rbuf = rbuf_n;
     wslot = wslot_n;
-    __syncthreads();
+    // bare s_barrier: __syncthreads() would first drain lgkmcnt(0), i.e. wait for the prefetched
+    // reads of the next unit; the consumers have no LDS stores of their own to publish here, and the
+    // slots they are reading are not rewritten before two more barriers
+    __builtin_amdgcn_s_barrier();
     if (pend_ctr) post_pending();  // the previous segment's slab stores are a unit old by now
     const bool se = fl & 1;
     if (se) {
@@ -596,7 +603,9 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     wq = wq_n;
     sz = sz_n;
 #pragma unroll
-    for (int mt = 0; mt < MT; ++mt) a0[mt] = a0_n[mt];
+    for (int s = 0; s < 4; ++s)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) af[s][mt] = an[s][mt];
   }
   if (pend_ctr) post_pending();
 }
