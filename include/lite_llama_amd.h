@@ -70,13 +70,17 @@ int ll_rope(void* q, void* k, const void* cos_t, const void* sin_t, int64_t toke
 /* Decode-step fusion of the two entries above (no reference counterpart: the reference launches
  * rope_emb.py:86-134 and update_kv_buffer.py:54-89 back to back): rotate q and the K heads of
  * kv = [tokens, 2*n_kh, hd] in place and scatter the rotated K heads + the V heads of token i to
- * kv_buffer row select_index[i].  Bit-identical to ll_rope followed by ll_update_kv_buffer. */
+ * kv_buffer row select_index[i].  Bit-identical to ll_rope followed by ll_update_kv_buffer.
+ * positions (int64 [tokens], optional): cos/sin are then position-indexed tables [max_pos, >= hd/2]
+ * (row stride = the *_s_stride arguments) and token i reads row positions[i] -- the rotary producer
+ * (models/rotary_embedding.py:34-137) leaves the per-step graph. */
 int ll_rope_kv_update(void* q, void* kv, const void* cos_t, const void* sin_t, void* kv_buffer,
                       const void* select_index, int64_t tokens, int n_qh, int n_kh, int hd,
                       int64_t q_row_stride, int64_t kv_row_stride, int64_t seq_len,
                       int64_t cos_b_stride, int64_t cos_s_stride, int64_t sin_b_stride,
                       int64_t sin_s_stride, int64_t pool_stride_t, int64_t pool_stride_h,
-                      int qk_dtype, int cs_dtype, int idx_width, void* stream);
+                      int qk_dtype, int cs_dtype, int idx_width, const int64_t* positions,
+                      void* stream);
 
 /* ---- a3: update_kv_buffer  (kernels/update_kv_buffer.py:54-89) ---------------
  * buf[idx[i], h, :] = vals[i, h, :]  (bit-exact copy; 2-byte elements). */

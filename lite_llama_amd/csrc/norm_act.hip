@@ -362,9 +362,10 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(
     uint16_t* __restrict__ q, uint16_t* __restrict__ kv, const void* __restrict__ cos_t,
     const void* __restrict__ sin_t, uint16_t* __restrict__ pool, const void* __restrict__ sel, int n_qh,
     int n_kh, int hd, int64_t q_rs, int64_t kv_rs, int64_t seq_len, int64_t cbs, int64_t css, int64_t sbs,
-    int64_t sss, int64_t pst, int64_t psh, int idx_w) {
+    int64_t sss, int64_t pst, int64_t psh, int idx_w, const int64_t* __restrict__ positions) {
   const int64_t tok = blockIdx.x;
-  const int64_t bi = tok / seq_len, si = tok % seq_len;
+  // positions != NULL: cos/sin are [max_pos, hd] tables indexed by the token's position
+  const int64_t bi = positions ? 0 : tok / seq_len, si = positions ? positions[tok] : tok % seq_len;
   const int64_t dst = idx_w == LL_I32 ? (int64_t)((const int32_t*)sel)[tok] : ((const int64_t*)sel)[tok];
   const int half = hd / 2;
   const int vph = half / VEC;  // vectors per head-half
@@ -409,7 +410,8 @@ extern "C" int ll_rope_kv_update(void* q, void* kv, const void* cos_t, const voi
                                  int64_t q_row_stride, int64_t kv_row_stride, int64_t seq_len,
                                  int64_t cos_b_stride, int64_t cos_s_stride, int64_t sin_b_stride,
                                  int64_t sin_s_stride, int64_t pool_stride_t, int64_t pool_stride_h,
-                                 int qk_dtype, int cs_dtype, int idx_width, void* stream) {
+                                 int qk_dtype, int cs_dtype, int idx_width, const int64_t* positions,
+                                 void* stream) {
   if (qk_dtype != LL_F16 && qk_dtype != LL_BF16) return LL_ERR_DTYPE;
   if (cs_dtype != LL_F16 && cs_dtype != LL_BF16 && cs_dtype != LL_F32) return LL_ERR_DTYPE;
   if (idx_width != LL_I32 && idx_width != LL_I64) return LL_ERR_DTYPE;
@@ -423,7 +425,7 @@ extern "C" int ll_rope_kv_update(void* q, void* kv, const void* cos_t, const voi
   rope_cache_kernel<DT, CS, VEC><<<dim3((unsigned)tokens), 256, 0, st>>>(                               \
       (uint16_t*)q, (uint16_t*)kv, cos_t, sin_t, (uint16_t*)kv_buffer, select_index, n_qh, n_kh, hd,    \
       q_row_stride, kv_row_stride, seq_len, cos_b_stride, cos_s_stride, sin_b_stride, sin_s_stride,     \
-      pool_stride_t, pool_stride_h, idx_width)
+      pool_stride_t, pool_stride_h, idx_width, positions)
 #define LL_RC_CS(DT, VEC)                                   \
   if (cs_dtype == LL_F16) LL_RC(DT, LL_F16, VEC);           \
   else if (cs_dtype == LL_BF16) LL_RC(DT, LL_BF16, VEC);    \

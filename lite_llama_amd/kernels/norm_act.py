@@ -111,11 +111,13 @@ def rope_emb_forward(q, k, cos, sin, batch_size, seq_len):
 
 
 @torch.no_grad()
-def rope_and_cache(q, kv, cos, sin, batch_size, seq_len, select_index, kv_buffer):
+def rope_and_cache(q, kv, cos, sin, batch_size, seq_len, select_index, kv_buffer, positions=None):
     """Extension (one launch instead of two): ``rope_emb_forward(q, k)`` + ``update_kv_buffer(cat(k, v))``
     where ``kv [N, 2*Hkv, D]`` holds this step's K heads then V heads (typically a strided view of the
     fused qkv projection).  ``q`` and the K half of ``kv`` are rotated in place; rotated K and V of
-    token ``i`` are written to ``kv_buffer[select_index[i]]``.  Bit-identical to the two-call form."""
+    token ``i`` are written to ``kv_buffer[select_index[i]]``.  Bit-identical to the two-call form.
+    With ``positions`` (int64 ``[N]``) ``cos``/``sin`` are position-indexed tables ``[max_pos, >= D/2]``
+    and token ``i`` reads row ``positions[i]`` (no per-step table producer)."""
     L.require_cuda(q, kv, cos, sin, select_index, kv_buffer)
     N, n_qh, hd = q.shape
     n_kh = kv.shape[1] // 2
@@ -125,16 +127,26 @@ def rope_and_cache(q, kv, cos, sin, batch_size, seq_len, select_index, kv_buffer
         if t.stride(2) != 1 or t.stride(1) != hd:
             raise ValueError("rope_and_cache needs dense [heads, head_dim] rows (only the token stride is free)")
     assert kv_buffer.stride(2) == 1
-    cos = cos.contiguous()
-    sin = sin.contiguous()
     if cos.dtype != sin.dtype:
         sin = sin.to(cos.dtype)
+    if positions is not None:
+        L.require_cuda(positions)
+        positions = positions.reshape(-1)
+        if positions.dtype != torch.int64 or positions.shape[0] != N or not positions.is_contiguous():
+            raise ValueError("positions must be a contiguous int64 tensor with one entry per token")
+        if cos.dim() != 2 or sin.dim() != 2 or cos.stride(1) != 1 or sin.stride(1) != 1:
+            raise ValueError("with positions, cos / sin must be [max_pos, >= head_dim/2] tables")
+        strides = (0, cos.stride(0), 0, sin.stride(0))
+    else:
+        cos = cos.contiguous()
+        sin = sin.contiguous()
+        strides = (cos.stride(0), cos.stride(1), sin.stride(0), sin.stride(1))
     L.check(
         L.lib().ll_rope_kv_update(
             q.data_ptr(), kv.data_ptr(), cos.data_ptr(), sin.data_ptr(), kv_buffer.data_ptr(),
-            select_index.data_ptr(), N, n_qh, n_kh, hd, q.stride(0), kv.stride(0), seq_len, cos.stride(0),
-            cos.stride(1), sin.stride(0), sin.stride(1), kv_buffer.stride(0), kv_buffer.stride(1),
-            L.dtype_code(q.dtype), L.dtype_code(cos.dtype), L.index_width(select_index), L.stream_ptr(),
+            select_index.data_ptr(), N, n_qh, n_kh, hd, q.stride(0), kv.stride(0), seq_len, *strides,
+            kv_buffer.stride(0), kv_buffer.stride(1), L.dtype_code(q.dtype), L.dtype_code(cos.dtype),
+            L.index_width(select_index), L.ptr(positions), L.stream_ptr(),
         ),
         "rope_and_cache",
     )

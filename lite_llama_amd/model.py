@@ -96,6 +96,18 @@ def tiny_geometry(**kw) -> ModelGeometry:
 # rotary tables (rotary_embedding.py:34-137): fp32 math, cos/sin in the activation dtype,
 # halves duplicated across the full head dim
 # ------------------------------------------------------------------------------------- #
+class RopeTables(tuple):
+    """``(cos_table [P, D], sin_table [P, D], positions [tokens])``: the decode-step form of the
+    position embeddings (instead of materialised ``[batch, 1, D]`` cos/sin)."""
+
+    def __new__(cls, cos, sin, positions):
+        return super().__new__(cls, (cos, sin, positions))
+
+    def materialise(self):
+        cos, sin, pos = self
+        return cos[pos].unsqueeze(1), sin[pos].unsqueeze(1)
+
+
 class RotaryEmbedding(nn.Module):
     def __init__(self, geo: ModelGeometry):
         super().__init__()
@@ -135,8 +147,9 @@ class RotaryEmbedding(nn.Module):
         """``(cos, sin)`` shaped ``[batch, seq, head_dim]`` in ``x.dtype``."""
         c = self._cache
         if (c is not None and position_ids.shape[1] == 1 and c[0].dtype == x.dtype and c[0].device == x.device):
-            # decode: cached rows (callers guarantee positions < the size given to ``ensure``)
-            return c[0][position_ids], c[1][position_ids]
+            # decode: hand out the position-indexed tables themselves; the fused rope kernel reads row
+            # positions[i] (callers guarantee positions < the size given to ``ensure``)
+            return RopeTables(c[0], c[1], position_ids.reshape(-1))
         return self._tables(position_ids, x.dtype)
 
 
@@ -208,9 +221,19 @@ class Attention(nn.Module):
         if self.use_qk_norm:
             xq, _ = skip_rmsnorm(xq, None, self.q_norm_weight, self.eps)
             xk, _ = skip_rmsnorm(xk, None, self.k_norm_weight, self.eps)
+        tables = position_embeddings if isinstance(position_embeddings, RopeTables) else None
+        fused = not self.use_qk_norm and xkv.stride(1) == self.head_dim and xq.stride(1) == self.head_dim
+        if tables is not None and not fused:
+            position_embeddings = tables.materialise()
+        if fused and tables is not None:
+            # decode: rope (position-indexed tables) + KV scatter in one launch, in place
+            rope_and_cache(xq, xkv, tables[0], tables[1], batch, seq_len, atten_info.cur_select_index,
+                           atten_info.kv_buffer[layer_index], positions=tables[2])
+            out = self.attn(xq, xkv, atten_info, layer_index, is_prefill=seq_len > 1, cached=True)
+            return self.o_proj(out.view(batch, seq_len, self.q_size))
         cos, sin = position_embeddings
-        if not self.use_qk_norm and xkv.stride(1) == self.head_dim and xq.stride(1) == self.head_dim:
-            # decode fast path: rope + KV scatter in one launch, in place on the projection output
+        if fused:
+            # rope + KV scatter in one launch, in place on the projection output
             rope_and_cache(xq, xkv, cos, sin, batch, seq_len, atten_info.cur_select_index,
                            atten_info.kv_buffer[layer_index])
             out = self.attn(xq, xkv, atten_info, layer_index, is_prefill=seq_len > 1, cached=True)

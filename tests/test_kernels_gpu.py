@@ -594,6 +594,17 @@ def test_rope_and_cache_equals_rope_then_update_kv_buffer(HQ, HKV, D, B, S):
     rope_and_cache(qb, kvb, cos, sin, B, S, sel, pool_b)
     assert torch.equal(a, b) and torch.equal(pool_a, pool_b)
     assert not torch.equal(a, qkv)  # really rotated in place
+    if S == 1:  # decode form: position-indexed tables instead of materialised [B, 1, D/2] rows
+        pos = torch.randint(0, 40, (n,), generator=g).to(DEV)
+        tab_c = torch.randn(40, D, generator=g).half().to(DEV)
+        tab_s = torch.randn(40, D, generator=g).half().to(DEV)
+        c, d2 = qkv.clone(), qkv.clone()
+        pool_c, pool_d = torch.zeros_like(pool_a), torch.zeros_like(pool_a)
+        rope_and_cache(c[:, : HQ * D].view(n, HQ, D), c[:, HQ * D:].view(n, 2 * HKV, D), tab_c, tab_s, B, S, sel,
+                       pool_c, positions=pos)
+        rope_and_cache(d2[:, : HQ * D].view(n, HQ, D), d2[:, HQ * D:].view(n, 2 * HKV, D),
+                       tab_c[pos].unsqueeze(1), tab_s[pos].unsqueeze(1), B, S, sel, pool_d)
+        assert torch.equal(c, d2) and torch.equal(pool_c, pool_d)
 
 
 @pytest.mark.parametrize("M,I,K_,gs", [(64, 18944, 3584, 128), (5, 512, 256, 128), (33, 1024, 1024, 256)])
