@@ -145,3 +145,58 @@ def test_engine_graph_equals_eager_and_oracle():
         assert torch.equal(first.cpu(), torch.from_numpy(d["first_tokens"]))
         outs.append(eng.decode(first, 12, use_graph=use_graph).cpu())
     assert torch.equal(outs[0], outs[1])
+
+
+@pytest.mark.gpu
+def test_full_width_decode_layer_matches_oracle():
+    """One decoder layer at the REAL Qwen2.5-7B widths (hidden 3584, intermediate 18944, 28/4 heads of
+    128), int4 g128, one decode step for 4 sequences: exercises the fused [q|k|v] launch, the tile-group
+    and stream-K GEMM plans, the interleaved gate/up + swiglu epilogue, position-indexed rope + KV
+    scatter and flash-decoding at production shapes against the CPU oracle (vocab cut to 2048 to keep
+    the oracle's lm_head cheap)."""
+    from lite_llama_amd.model import CausalLM, tiny_geometry
+    from lite_llama_amd.quantization import QuantConfig
+    from oracle.model import OracleModel
+
+    H, I, L, HQ, HKV, D, V = 3584, 18944, 1, 28, 4, 128, 2048
+    B, CTX = 4, 40
+    g = torch.Generator().manual_seed(1234)
+    geo = tiny_geometry(hidden_size=H, intermediate_size=I, num_layers=L, num_heads=HQ, num_kv_heads=HKV,
+                        head_dim=D, vocab_size=V, rope_theta=1000000.0, qkv_bias=True)
+    m = CausalLM(geo)
+    params = {}
+    for name, t in m.state_dict().items():
+        if name.endswith("norm_weight") or name.endswith("layernorm_weight"):
+            params[name] = (1 + 0.1 * torch.randn(t.shape, generator=g)).half()
+        elif name.endswith("bias"):
+            params[name] = (0.01 * torch.randn(t.shape, generator=g)).half()
+        else:
+            params[name] = (0.02 * torch.randn(t.shape, generator=g)).half()
+    m.load_state_dict(params, strict=True)
+    m = m.to("cuda")
+    m.quantize_(QuantConfig.int4_groupwise(128))
+    m.rotary_emb.ensure(CTX + 8, "cuda")
+
+    rows = B * (CTX + 1)
+    kv_cpu = [(torch.randn(rows, 2 * HKV, D, generator=g) * 0.5).half() for _ in range(L)]
+    table = torch.arange(rows, dtype=torch.int32).view(B, CTX + 1)
+    ids = torch.randint(0, V, (B, 1), generator=g)
+    pos = torch.full((B, 1), CTX)
+
+    def info_on(dev, kv):
+        return types.SimpleNamespace(
+            kv_buffer=kv, cur_select_index=table[:, CTX].contiguous().to(dev), b_req_tokens_table=table.clone().to(dev),
+            b_start_loc=None, b_req_idx=torch.arange(B, dtype=torch.int32, device=dev),
+            b_seq_len=torch.full((B,), CTX + 1, dtype=torch.int32, device=dev), max_actual_seq_len=CTX + 1)
+
+    kv_gpu = [k.clone().cuda() for k in kv_cpu]
+    with torch.no_grad():
+        got = m(ids.cuda(), pos.cuda(), info_on("cuda", kv_gpu))
+    om = OracleModel({k: v.clone() for k, v in params.items()}, H, I, L, HQ, HKV, D, V, eps=geo.rms_norm_eps,
+                     rope_theta=geo.rope_theta, quant="int4")
+    kv_ref = [k.clone() for k in kv_cpu]
+    ref = om.forward(ids, pos, info_on("cpu", kv_ref))
+    new_rows = table[:, CTX].long()
+    torch.testing.assert_close(kv_gpu[0][new_rows.cuda()].float().cpu(), kv_ref[0][new_rows].float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=3e-2, atol=3e-2)
+    assert torch.equal(torch.argmax(got[:, -1], -1).cpu(), torch.argmax(ref[:, -1], -1))
