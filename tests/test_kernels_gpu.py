@@ -660,3 +660,36 @@ def test_decode_advance_equals_the_separate_tensor_ops():
                                       table.stride(0), table.stride(1), b, L.stream_ptr()), "decode_advance")
     for got, want in zip((out, step, ids, pos, sel, seq, table), e):
         assert torch.equal(got, want)
+
+
+def test_w4a16_decode_engine_random_shapes_match_generic_engine():
+    """Plan edge cases of the decode engine (stream-K vs tile groups, 1..12 contributors per tile, M = 1..64,
+    K/N from one unit to hundreds): equal to the generic engine up to the fp32 summation order, and
+    bit-identical with / without the packed scale grid."""
+    import os
+    import random
+
+    from lite_llama_amd.kernels.quantization import pack_w4a16_scales
+    rnd = random.Random(11)
+    try:
+        for it in range(36):
+            m = rnd.choice([1, 2, 7, 16, 31, 32, 33, 48, 63, 64])
+            n = 128 * rnd.choice([1, 2, 3, 5, 8, 9, 17, 28, 36, 61, 148, 255, 256, 257, 300])
+            k = 128 * rnd.choice([1, 2, 3, 4, 5, 7, 8, 13, 28, 29, 37, 64, 148])
+            gs = rnd.choice([128, 128, 256]) if k % 256 == 0 else 128
+            g = torch.Generator(device=DEV).manual_seed(it)
+            x = (torch.randn(m, k, generator=g, device=DEV) * 0.5).half()
+            qw = torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64, generator=g, device=DEV).to(torch.int32)
+            sc = torch.rand(n, k // gs, generator=g, device=DEV) * 0.01 + 0.005
+            zr = torch.randint(0, 16, (n, k // gs), generator=g, device=DEV).float()
+            bias = (torch.randn(n, generator=g, device=DEV) * 0.1).half() if it % 3 == 0 else None
+            os.environ.pop("LL_GEMM_V1", None)
+            y2 = K().w4a16_matmul(x, qw, sc, zr, group_size=gs, bias=bias, packed_scales=pack_w4a16_scales(sc, zr))
+            y2b = K().w4a16_matmul(x, qw, sc, zr, group_size=gs, bias=bias)
+            os.environ["LL_GEMM_V1"] = "1"  # read per call by the dispatcher
+            y1 = K().w4a16_matmul(x, qw, sc, zr, group_size=gs, bias=bias)
+            scale = y1.float().abs().max().item() + 1e-6
+            assert (y2.float() - y1.float()).abs().max().item() <= 2e-3 * scale + 2e-3, (m, n, k, gs)
+            assert torch.equal(y2, y2b), (m, n, k, gs)
+    finally:
+        os.environ.pop("LL_GEMM_V1", None)
