@@ -36,9 +36,9 @@
 
 enum { FMT_W4 = 0, FMT_FP8 = 1, FMT_I8 = 2, FMT_I8I8 = 3 };
 
-struct alignas(16) Q4 {
-  uint32_t x, y, z, w;
-};
+// 16-byte register quad.  An ext-vector type on purpose: arrays of a plain struct (even alignas(16))
+// were left in scratch memory by hipcc, arrays of vector types are promoted to registers.
+typedef uint32_t Q4 __attribute__((ext_vector_type(4)));
 
 struct GemmParams {
   void* out;             // fp16 [M, N]
@@ -393,13 +393,15 @@ __global__ __launch_bounds__(GEMM_THREADS, 4) void wgemm_kernel(const GemmParams
           const Q4& src = wreg[slot][s >> 1];
           const uint32_t w0 = (s & 1) ? src.z : src.x;
           const uint32_t w1 = (s & 1) ? src.w : src.y;
+          uint32_t d0, d1, d2, d3;
           if constexpr (FMT == FMT_FP8) {
-            dequant_fp8(w0, sp[0], wf.x, wf.y);
-            dequant_fp8(w1, sp[0], wf.z, wf.w);
+            dequant_fp8(w0, sp[0], d0, d1);
+            dequant_fp8(w1, sp[0], d2, d3);
           } else {
-            dequant_i8(w0, sp[0], wf.x, wf.y);
-            dequant_i8(w1, sp[0], wf.z, wf.w);
+            dequant_i8(w0, sp[0], d0, d1);
+            dequant_i8(w1, sp[0], d2, d3);
           }
+          wf = Q4{d0, d1, d2, d3};
         }
         const f16x8 wfrag = __builtin_bit_cast(f16x8, wf);
 #pragma unroll
