@@ -212,6 +212,23 @@ int ll_argmax(int64_t* out, const void* logits, int64_t rows, int64_t n, int64_t
 int ll_argmax_split(int64_t* out, const void* logits, int64_t rows, int64_t n, int64_t stride_row,
                     int dtype, void* scratch, int chunks, void* stream);
 
+/* ---- sampler row (engine/sampler.py:77-137,199-270) ---------------------------------
+ * ll_repetition_penalty: out[b, :] = logits[b, :] with, for every generated token (token_ids[b, j]
+ * where mask[b, j] != 0), logit / penalty if >= 0 else logit * penalty, computed from the ORIGINAL
+ * logit (repeats count once).  fp32 arithmetic, one rounding to out_dtype (F16->F16, F16->F32,
+ * BF16->BF16, BF16->F32, F32->F32: torch's promotion for a scalar / float32-tensor penalty).
+ * penalty_rows [batch] or NULL (then penalty_scalar).  out must not alias logits.  mask: 1 byte / entry.
+ * ll_sample_top_p: per row softmax(logits / temperature) -> nucleus (tokens whose strictly more
+ * probable mass <= top_p) -> one draw from it by inverse CDF in index order at uniform[b] in [0, 1);
+ * rows with greedy[b] != 0 (optional) return the first argmax.  out int64 [batch]. */
+int ll_repetition_penalty(void* out, const void* logits, const int64_t* token_ids, const void* mask,
+                          const float* penalty_rows, float penalty_scalar, int64_t batch, int64_t vocab,
+                          int64_t span, int64_t logits_stride, int64_t out_stride, int64_t ids_stride,
+                          int64_t mask_stride, int in_dtype, int out_dtype, void* stream);
+int ll_sample_top_p(int64_t* out, const void* logits, const float* temperature, const float* top_p,
+                    const float* uniform, const void* greedy, int64_t batch, int64_t vocab,
+                    int64_t stride, int dtype, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

@@ -398,6 +398,52 @@ def greedy_argmax(logits):
 
 
 # --------------------------------------------------------------------------- #
+# sampler row: engine/sampler.py:77-137
+# --------------------------------------------------------------------------- #
+def apply_repetition_penalty(logits, token_ids, mask, penalty):
+    """sampler.py:77-115: logits of tokens that occur at a ``mask``-ed position of ``token_ids`` are
+    divided by ``penalty`` when >= 0 and multiplied when negative; repeats are penalised once; padded
+    positions never count.  Arithmetic in fp32 with one rounding to the result dtype, which is the
+    logits dtype for a Python-scalar penalty and the promoted dtype (float32 for the reference's
+    float32 ``[batch, 1]`` factors) for a tensor penalty -- torch's type promotion."""
+    batch, vocab = logits.shape
+    if torch.is_tensor(penalty):
+        out_dtype = torch.promote_types(logits.dtype, penalty.dtype)
+        pen = penalty.reshape(batch, -1)[:, :1].float()
+    else:
+        out_dtype = logits.dtype
+        pen = torch.full((batch, 1), float(penalty), dtype=torch.float32)
+    out = logits.to(out_dtype).clone()
+    for b in range(batch):
+        for tok in set(token_ids[b][mask[b]].tolist()):
+            x = logits[b, tok].float()
+            out[b, tok] = (x * pen[b, 0] if x < 0 else x / pen[b, 0]).to(out_dtype)
+    return out
+
+
+def top_p_distribution(logits, temperature, top_p):
+    """sampler.py:118-137 up to the random draw: softmax(logits / T), sort descending, drop a token
+    once the mass BEFORE it exceeds top_p, renormalise.  Returned in token order ``[batch, vocab]``."""
+    batch, vocab = logits.shape
+    t = torch.as_tensor(temperature, dtype=torch.float32).reshape(-1, 1)
+    tp = torch.as_tensor(top_p, dtype=torch.float32).reshape(-1, 1)
+    probs = torch.softmax(logits.float() / t, dim=-1)
+    sp, si = torch.sort(probs, dim=-1, descending=True, stable=True)  # ties: ascending token index
+    cum = torch.cumsum(sp, dim=-1)
+    sp = torch.where(cum - sp > tp, torch.zeros_like(sp), sp)
+    sp = sp / sp.sum(dim=-1, keepdim=True)
+    return torch.zeros_like(probs).scatter_(1, si, sp)
+
+
+def sample_from_distribution(dist, uniform):
+    """Inverse CDF in TOKEN order: the first index whose cumulative mass exceeds ``u`` (the reference
+    draws with torch.multinomial on the sorted distribution -- same distribution, other RNG stream)."""
+    cdf = torch.cumsum(dist.double(), dim=-1)
+    u = torch.as_tensor(uniform, dtype=torch.float64).reshape(-1, 1) * cdf[:, -1:]
+    return (cdf > u).float().argmax(dim=-1)
+
+
+# --------------------------------------------------------------------------- #
 # Weight quantisers that define the on-device formats
 # (models/quantization/params/int4.py:12-49, int8.py:12-53, fp8.py:16-30)
 # --------------------------------------------------------------------------- #

@@ -693,3 +693,83 @@ def test_w4a16_decode_engine_random_shapes_match_generic_engine():
             assert torch.equal(y2, y2b), (m, n, k, gs)
     finally:
         os.environ.pop("LL_GEMM_V1", None)
+
+
+# ------------------------------------------------------------------------------------- #
+# sampler row: repetition penalty exact, nucleus sampling against the reference's
+# filtered distribution
+# ------------------------------------------------------------------------------------- #
+def _sampler_golden():
+    import numpy as np
+    return np.load(G.GOLDEN_DIR + "/sampler_reference.npz")
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+def test_repetition_penalty_matches_reference(dt):
+    from lite_llama_amd.sampling import apply_repetition_penalty
+    d = _sampler_golden()
+    dtype = torch.float32 if dt == "f32" else torch.float16
+    logits = torch.from_numpy(d[f"rp_{dt}.logits"]).to(dtype).to(DEV)
+    ids, mask = torch.from_numpy(d[f"rp_{dt}.ids"]).to(DEV), torch.from_numpy(d[f"rp_{dt}.mask"]).to(DEV)
+    keep = logits.clone()
+    got = apply_repetition_penalty(logits, ids, mask, 1.3)
+    assert got.dtype == dtype and torch.equal(got.float().cpu(), torch.from_numpy(d[f"rp_{dt}.scalar_1p3"]))
+    pen = torch.from_numpy(d[f"rp_{dt}.row_penalty"]).to(DEV)
+    got = apply_repetition_penalty(logits, ids, mask, pen)
+    assert got.dtype == torch.float32 and torch.equal(got.cpu(), torch.from_numpy(d[f"rp_{dt}.per_row"]))
+    assert torch.equal(logits, keep)  # input untouched
+    # vocabulary-sized rows, long spans with many repeats: against the oracle
+    g = torch.Generator().manual_seed(5)
+    lg = (torch.randn(8, 152064, generator=g) * 4).half()
+    ii = torch.randint(0, 152064, (8, 700), generator=g)
+    ii[:, 100:400] = ii[:, :300]
+    mm = torch.rand(8, 700, generator=g) > 0.2
+    assert torch.equal(apply_repetition_penalty(lg.to(DEV), ii.to(DEV), mm.to(DEV), 1.1).cpu(),
+                       O.apply_repetition_penalty(lg, ii, mm, 1.1))
+
+
+def _check_draws(logits, temperature, top_p, dist, n_u=257):
+    """Every draw must be the inverse CDF (token order) of ``dist`` at its uniform number; draws whose
+    number sits within 1e-5 of an interval edge are exempt (fp32 vs fp64 summation order)."""
+    from lite_llama_amd.sampling import sample_top_p
+    b = logits.shape[0]
+    cdf = torch.cumsum(dist.double(), dim=-1)
+    cdf = cdf / cdf[:, -1:]
+    for k in range(n_u):
+        u = torch.full((b,), (k + 0.37) / n_u)
+        tok = sample_top_p(logits.to(DEV), temperature, top_p, uniform=u.to(DEV)).view(-1).cpu()
+        want = (cdf > u.double().view(-1, 1)).float().argmax(dim=-1)
+        edge = (cdf - u.double().view(-1, 1)).abs().min(dim=-1).values < 1e-5
+        ok = (tok == want) | edge
+        assert bool(ok.all()), (k, tok.tolist(), want.tolist())
+        assert bool((dist[torch.arange(b), tok] > 0).all())  # never outside the nucleus
+
+
+def test_top_p_sampling_matches_reference_distribution():
+    d = _sampler_golden()
+    logits = torch.from_numpy(d["topp.logits"])
+    t, p = torch.from_numpy(d["topp.temperature"]), torch.from_numpy(d["topp.top_p"])
+    _check_draws(logits, t.to(DEV), p.to(DEV), torch.from_numpy(d["topp.dist"]))
+
+
+def test_top_p_sampling_full_vocabulary_and_greedy_rows():
+    from lite_llama_amd.sampling import Sampler, sample_top_p
+    import types
+    g = torch.Generator().manual_seed(9)
+    logits = (torch.randn(6, 152064, generator=g) * 3).half()
+    t = torch.tensor([0.7, 1.0, 0.4, 1.3, 0.9, 0.6])
+    p = torch.tensor([0.9, 0.6, 0.95, 0.2, 1.0, 0.8])
+    dist = O.top_p_distribution(logits, t, p)
+    _check_draws(logits, t.to(DEV), p.to(DEV), dist, n_u=41)
+    # greedy rows ride along in the same launch
+    greedy = torch.tensor([True, False, True, False, False, True])
+    u = torch.full((6,), 0.5)
+    tok = sample_top_p(logits.to(DEV), t.to(DEV), p.to(DEV), uniform=u.to(DEV), greedy=greedy.to(DEV)).view(-1).cpu()
+    assert torch.equal(tok[greedy], torch.argmax(logits.float(), -1)[greedy])
+    # Sampler facade: temperature 0 -> argmax, penalty applied first
+    params = types.SimpleNamespace(temperature=0.0, top_p=0.9, repetition_penalty=1.2)
+    gen = types.SimpleNamespace(token_ids=torch.argmax(logits.float(), -1).view(-1, 1).to(DEV),
+                                mask=torch.ones(6, 1, dtype=torch.bool, device=DEV))
+    got = Sampler().sample(logits.to(DEV).unsqueeze(1), params, gen).cpu()
+    ref = torch.argmax(O.apply_repetition_penalty(logits, gen.token_ids.cpu(), gen.mask.cpu(), 1.2).float(), -1).view(-1, 1)
+    assert torch.equal(got, ref)

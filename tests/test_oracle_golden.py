@@ -147,3 +147,36 @@ def test_quantisers():
     d = G.load("quantize_int8_per_channel")
     qw, sc = O.quantize_int8_per_channel(d["w"])
     assert torch.equal(qw, d["qweight"]) and torch.equal(sc, d["scales"])
+
+
+# ------------------------------------------------------------------------------------- #
+# sampler row: oracle vs vectors produced by the reference sampler
+# ------------------------------------------------------------------------------------- #
+def _sampler_golden():
+    import numpy as np
+    return np.load(G.GOLDEN_DIR + "/sampler_reference.npz")
+
+
+@pytest.mark.parametrize("dt", ["f32", "f16"])
+def test_oracle_repetition_penalty_matches_reference(dt):
+    d = _sampler_golden()
+    dtype = torch.float32 if dt == "f32" else torch.float16
+    logits = torch.from_numpy(d[f"rp_{dt}.logits"]).to(dtype)
+    ids, mask = torch.from_numpy(d[f"rp_{dt}.ids"]), torch.from_numpy(d[f"rp_{dt}.mask"])
+    got = O.apply_repetition_penalty(logits, ids, mask, 1.3)
+    assert torch.equal(got.float(), torch.from_numpy(d[f"rp_{dt}.scalar_1p3"]))
+    got = O.apply_repetition_penalty(logits, ids, mask, torch.from_numpy(d[f"rp_{dt}.row_penalty"]))
+    assert torch.equal(got.float(), torch.from_numpy(d[f"rp_{dt}.per_row"]))
+
+
+def test_oracle_top_p_distribution_matches_reference():
+    d = _sampler_golden()
+    dist = O.top_p_distribution(torch.from_numpy(d["topp.logits"]), torch.from_numpy(d["topp.temperature"]),
+                                torch.from_numpy(d["topp.top_p"]))
+    ref = torch.from_numpy(d["topp.dist"])
+    assert torch.equal(dist > 0, ref > 0)  # same nucleus
+    torch.testing.assert_close(dist, ref, rtol=1e-5, atol=1e-7)
+    # inverse CDF in token order really samples from it
+    u = torch.tensor([0.0, 0.1, 0.5, 0.77, 0.999, 0.3])
+    tok = O.sample_from_distribution(ref, u)
+    assert bool((ref[torch.arange(6), tok] > 0).all())
