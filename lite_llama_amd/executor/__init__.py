@@ -20,7 +20,7 @@ import torch
 
 from .. import _lib as L
 from ..kernels import update_kv_index
-from ..sampling import greedy_argmax
+from ..sampling import Sampler, greedy_argmax
 
 
 @dataclass
@@ -34,6 +34,14 @@ class AttentionMetadata:
     b_req_idx: torch.Tensor | None = None
     b_seq_len: torch.Tensor | None = None
     max_actual_seq_len: int = 0
+
+
+@dataclass
+class _Span:
+    """The reference's GeneratedSpan (sampler.py:64-75): padded generated tokens + validity mask."""
+
+    token_ids: torch.Tensor
+    mask: torch.Tensor
 
 
 class KVPool:
@@ -85,6 +93,7 @@ class DecodeEngine:
         self.info.b_req_tokens_table = torch.zeros(max_batch, max_seq_len, dtype=torch.int32, device=device)
         self._graph = None
         self._graph_key = None
+        self._sampling = None
         if hasattr(model, "rotary_emb") and torch.device(device).type == "cuda":
             model.rotary_emb.ensure(max_seq_len + 1, device, model.embed_tokens.weight.dtype)
 
@@ -156,8 +165,24 @@ class DecodeEngine:
         """forward -> greedy sample -> record -> advance metadata (all on device)."""
         info, b = self.info, self._batch
         logits = self.model(self._input_ids, self._positions, info)
-        nxt = greedy_argmax(logits[:, -1, :])
+        nxt = self._sample(logits[:, -1, :])
         self._advance(nxt)
+
+    def _sample(self, logits: torch.Tensor) -> torch.Tensor:
+        """Greedy argmax, or -- with ``sampling`` set by :meth:`decode` -- the reference sampler's sequence
+        (repetition penalty over the tokens generated so far, then temperature + nucleus sampling) on
+        the HIP kernels; the uniform numbers come from ``torch.rand`` (graph-safe Philox)."""
+        sp = self._sampling
+        if sp is None:
+            return greedy_argmax(logits)
+        b = self._batch
+        generated = None
+        if sp.repetition_penalty != 1.0:
+            span = self._out.shape[1]
+            mask = torch.arange(span, device=self.device).unsqueeze(0) < self._step  # [1, span] -> rows share it
+            generated = _Span(self._out, mask.expand(b, span))
+        uniform = torch.rand(b, device=self.device) if sp.temperature != 0.0 else None
+        return Sampler().sample(logits, sp, generated, uniform=uniform).view(-1)
 
     def _advance(self, nxt: torch.Tensor) -> None:
         """record -> feed back -> positions/lengths/KV rows += -> token table: one launch when the state
@@ -186,13 +211,14 @@ class DecodeEngine:
 
     @torch.no_grad()
     def decode(self, first_tokens: torch.Tensor, max_new_tokens: int, use_graph: bool = True,
-               warmup_steps: int = 0, on_step=None) -> torch.Tensor:
+               warmup_steps: int = 0, on_step=None, sampling=None) -> torch.Tensor:
         """Generate ``max_new_tokens`` greedy tokens per row; returns ``[B, max_new_tokens]``.
 
         With ``use_graph`` the step is captured once (``max_actual_seq_len`` baked as the final
         context length rounded up to the attention partition size) and replayed per token.
         ``warmup_steps`` of the total are run before ``on_step`` timing hooks fire (bench use).
         """
+        self._sampling = sampling  # None = greedy; else an object with temperature / top_p / repetition_penalty
         self._begin_decode(first_tokens, max_new_tokens)
         info = self.info
         final_len = info.max_actual_seq_len + max_new_tokens
