@@ -13,10 +13,29 @@ import torch
 from tests import _golden as G
 
 
-def _load():
-    d = np.load(G.GOLDEN_DIR + "/model_step_qwen2_tiny.npz")
+# (family, quantisations pinned in its fixture); qwen2 from gen_golden_model.py, the rest from
+# gen_golden_families.py
+FAMILIES = {
+    "qwen2": [None, "int4", "int8", "smoothquant", "fp8"],
+    "llama": [None, "int4", "int8", "smoothquant", "fp8"],
+    "qwen3": [None, "int4", "fp8"],
+    "qwen3_moe": [None, "int8", "smoothquant", "fp8"],
+}
+CASES = [(f, q) for f, qs in FAMILIES.items() for q in qs]
+
+
+def _load(family="qwen2"):
+    d = np.load(G.GOLDEN_DIR + f"/model_step_{family}_tiny.npz")
     params = {k[len("param."):]: torch.from_numpy(d[k].copy()) for k in d.files if k.startswith("param.")}
     return d, params
+
+
+def _extras(d):
+    """(rope_theta, eps, qk_norm, moe) -- the qwen2 fixture predates these keys."""
+    if "rope_theta" not in d.files:
+        return 10000.0, 1e-6, False, None
+    moe = tuple(int(x) for x in d["moe"])
+    return float(d["rope_theta"]), float(d["eps"]), bool(int(d["qk_norm"])), (moe if moe[0] else None)
 
 
 def _info(kv, table, sel, seq, start, max_len, dev="cpu"):
@@ -26,9 +45,9 @@ def _info(kv, table, sel, seq, start, max_len, dev="cpu"):
                                  b_seq_len=seq.to(dev), max_actual_seq_len=max_len)
 
 
-def _run_steps(make_model, dev, quant=None):
+def _run_steps(make_model, dev, quant=None, family="qwen2"):
     """prefill (fp16 always) + decode with ``quant``; returns (last prefill logits, decode logits, kv, table)."""
-    d, params = _load()
+    d, params = _load(family)
     H, I, L, HQ, HKV, D, V = [int(x) for x in d["geometry"]]
     lens = d["lens"].tolist()
     B, LP = len(lens), max(lens)
@@ -38,7 +57,7 @@ def _run_steps(make_model, dev, quant=None):
     for i, n in enumerate(lens):
         table[i, :n] = sel[i * LP : i * LP + n].to(dev)
     info = _info(kv, table, sel, torch.tensor(lens, dtype=torch.int32), torch.arange(B, dtype=torch.int32) * LP, LP, dev)
-    m16 = make_model(params, None)
+    m16 = make_model(params, None, family)
     ids = torch.from_numpy(d["prompt_ids"]).to(dev)
     pos = torch.arange(LP, device=dev).unsqueeze(0).expand(B, LP).contiguous()
     logits = m16.forward(ids, pos, info)
@@ -51,22 +70,24 @@ def _run_steps(make_model, dev, quant=None):
     for i in range(B):
         table[i, int(info.b_seq_len[i]) - 1] = info.cur_select_index[i]
     tok = torch.from_numpy(d["first_tokens"]).to(dev)
-    mq = make_model(params, quant) if quant else m16
+    mq = make_model(params, quant, family) if quant else m16
     dl = mq.forward(tok.view(B, 1), torch.from_numpy(d["decode_positions"]).to(dev), info)
     return d, last, dl, kv_prefill, kv, table
 
 
-def _oracle_model(params, quant):
+def _oracle_model(params, quant, family="qwen2"):
     from oracle.model import OracleModel
 
-    d = np.load(G.GOLDEN_DIR + "/model_step_qwen2_tiny.npz")
+    d = np.load(G.GOLDEN_DIR + f"/model_step_{family}_tiny.npz")
     H, I, L, HQ, HKV, D, V = [int(x) for x in d["geometry"]]
-    return OracleModel({k: v.clone() for k, v in params.items()}, H, I, L, HQ, HKV, D, V, quant=quant)
+    theta, eps, qk_norm, moe = _extras(d)
+    return OracleModel({k: v.clone() for k, v in params.items()}, H, I, L, HQ, HKV, D, V, eps=eps, rope_theta=theta,
+                       quant=quant, qk_norm=qk_norm, moe=moe)
 
 
-@pytest.mark.parametrize("quant", [None, "int4", "int8", "smoothquant", "fp8"])
-def test_oracle_model_matches_reference_step(quant):
-    d, last, dl, kvp, kvd, table = _run_steps(_oracle_model, "cpu", quant)
+@pytest.mark.parametrize("family,quant", CASES)
+def test_oracle_model_matches_reference_step(family, quant):
+    d, last, dl, kvp, kvd, table = _run_steps(_oracle_model, "cpu", quant, family)
     lens = d["lens"].tolist()
     LP = max(lens)
     torch.testing.assert_close(last.float(), torch.from_numpy(d["logits_prefill_last"]).float(), rtol=2e-2, atol=2e-2)
@@ -89,14 +110,20 @@ def test_oracle_model_matches_reference_step(quant):
         assert torch.equal(torch.argmax(dl[:, -1], -1), torch.argmax(ref[:, -1], -1))
 
 
-def _hip_model(params, quant):
+def _hip_model(params, quant, family="qwen2"):
     from lite_llama_amd.model import CausalLM, tiny_geometry
     from lite_llama_amd.quantization import QuantConfig
 
-    d = np.load(G.GOLDEN_DIR + "/model_step_qwen2_tiny.npz")
+    d = np.load(G.GOLDEN_DIR + f"/model_step_{family}_tiny.npz")
     H, I, L, HQ, HKV, D, V = [int(x) for x in d["geometry"]]
+    theta, eps, qk_norm, moe = _extras(d)
+    kw = {}
+    if moe:
+        kw = dict(num_experts=moe[0], num_experts_per_tok=moe[1], moe_intermediate_size=moe[2],
+                  norm_topk_prob=bool(moe[3]))
     geo = tiny_geometry(hidden_size=H, intermediate_size=I, num_layers=L, num_heads=HQ, num_kv_heads=HKV,
-                        head_dim=D, vocab_size=V, rope_theta=10000.0, qkv_bias=True)
+                        head_dim=D, vocab_size=V, rope_theta=theta, rms_norm_eps=eps, qkv_bias=family == "qwen2",
+                        use_qk_norm=qk_norm, **kw)
     m = CausalLM(geo)
     m.load_state_dict({k: v for k, v in params.items()}, strict=True)
     m = m.to("cuda")
@@ -108,9 +135,9 @@ def _hip_model(params, quant):
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("quant", [None, "int4", "int8", "smoothquant", "fp8"])
-def test_hip_model_matches_reference_step(quant):
-    d, last, dl, kvp, kvd, table = _run_steps(_hip_model, "cuda", quant)
+@pytest.mark.parametrize("family,quant", CASES)
+def test_hip_model_matches_reference_step(family, quant):
+    d, last, dl, kvp, kvd, table = _run_steps(_hip_model, "cuda", quant, family)
     lens = d["lens"].tolist()
     LP = max(lens)
     torch.testing.assert_close(last.float().cpu(), torch.from_numpy(d["logits_prefill_last"]).float(), rtol=3e-2, atol=3e-2)
