@@ -204,6 +204,16 @@ int ll_decode_advance(int64_t* out, int64_t out_stride, int64_t* step, const int
                       int32_t* b_seq_len, const int32_t* b_req_idx, int32_t* table,
                       int64_t table_stride_b, int64_t table_stride_s, int batch, void* stream);
 
+/* Continuous-batching step metadata in one launch (executor/slot_batch.py:135-169: the steady
+ * state of SlotBatch.begin_decode, ``b_seq_len += 1`` then ``cur_select_index = table[b_req_idx,
+ * b_seq_len - 1]``).  b_seq_len / b_req_idx are int32 or int64 (idx_width); cur_select_index and
+ * the slot table are int32.  Optional (NULL to skip): positions[i] = b_seq_len[i] - 1 (the decode
+ * position, continuous_engine.py:404-405) and input_ids[i] = next_tokens[i], all int64. */
+int ll_slot_advance(void* b_seq_len, const void* b_req_idx, int32_t* cur_select_index,
+                    int64_t* positions, int64_t* input_ids, const int64_t* next_tokens,
+                    const int32_t* table, int64_t table_stride_b, int64_t table_stride_s, int batch,
+                    int idx_width, void* stream);
+
 /* ---- a16: greedy argmax over logits [rows, n] (engine/sampler.py:227-228) ----- */
 int ll_argmax(int64_t* out, const void* logits, int64_t rows, int64_t n, int64_t stride_row,
               int dtype, void* stream);

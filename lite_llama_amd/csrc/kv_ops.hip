@@ -118,4 +118,45 @@ extern "C" int ll_decode_advance(int64_t* out, int64_t out_stride, int64_t* step
   return LL_LAUNCH_CHECK();
 }
 
+// --------------------------------------------------------------------------- //
+// Continuous batching, steady state (executor/slot_batch.py:135-169 does this with ``+= 1`` and a
+// gather against the slot table; here one launch, optionally also feeding the sampled tokens back):
+//   b_seq_len[i] += 1;  cur_select_index[i] = table[b_req_idx[i], b_seq_len[i] - 1];
+//   positions[i] = b_seq_len[i] - 1 (if given);  input_ids[i] = next_tokens[i] (if given)
+// --------------------------------------------------------------------------- //
+template <typename T>
+__global__ __launch_bounds__(256) void slot_advance_kernel(
+    T* __restrict__ b_seq_len, const T* __restrict__ b_req_idx, int32_t* __restrict__ cur_select,
+    int64_t* __restrict__ positions, int64_t* __restrict__ input_ids, const int64_t* __restrict__ next,
+    const int32_t* __restrict__ table, int64_t t_sb, int64_t t_ss, int batch) {
+  const int i = blockIdx.x * 256 + threadIdx.x;
+  if (i >= batch) return;
+  const int64_t len = (int64_t)b_seq_len[i] + 1;
+  b_seq_len[i] = (T)len;
+  cur_select[i] = table[(int64_t)b_req_idx[i] * t_sb + (len - 1) * t_ss];
+  if (positions) positions[i] = len - 1;
+  if (input_ids) input_ids[i] = next[i];
+}
+
+extern "C" int ll_slot_advance(void* b_seq_len, const void* b_req_idx, int32_t* cur_select_index,
+                               int64_t* positions, int64_t* input_ids, const int64_t* next_tokens,
+                               const int32_t* table, int64_t table_stride_b, int64_t table_stride_s,
+                               int batch, int idx_width, void* stream) {
+  if (idx_width != LL_I32 && idx_width != LL_I64) return LL_ERR_DTYPE;
+  if (batch < 0) return LL_ERR_SHAPE;
+  if (batch == 0) return LL_OK;
+  if (!b_seq_len || !b_req_idx || !cur_select_index || !table || (input_ids && !next_tokens)) return LL_ERR_ARG;
+  const dim3 grid((unsigned)((batch + 255) / 256));
+  hipStream_t st = (hipStream_t)stream;
+  if (idx_width == LL_I32)
+    slot_advance_kernel<int32_t><<<grid, 256, 0, st>>>((int32_t*)b_seq_len, (const int32_t*)b_req_idx,
+                                                       cur_select_index, positions, input_ids, next_tokens,
+                                                       table, table_stride_b, table_stride_s, batch);
+  else
+    slot_advance_kernel<int64_t><<<grid, 256, 0, st>>>((int64_t*)b_seq_len, (const int64_t*)b_req_idx,
+                                                       cur_select_index, positions, input_ids, next_tokens,
+                                                       table, table_stride_b, table_stride_s, batch);
+  return LL_LAUNCH_CHECK();
+}
+
 extern "C" int ll_abi_version(void) { return 1; }

@@ -66,6 +66,13 @@ class KVPool:
     def reset(self) -> None:
         self._next = 0
 
+    def claim(self, num_rows: int) -> None:
+        """Hand the first ``num_rows`` rows to an external owner (the slot layout); the bump cursor
+        resumes just past them (kv_cache_manager.py:336-353)."""
+        if num_rows > self.max_tokens:
+            raise ValueError(f"cannot claim {num_rows} rows: the pool holds {self.max_tokens}")
+        self._next = max(self._next, num_rows)
+
     @property
     def used(self) -> int:
         return self._next
@@ -112,9 +119,12 @@ class DecodeEngine:
         info.b_seq_len = prompt_lens.to(torch.int32).clone()
         info.max_actual_seq_len = lp
         info.b_start_loc = torch.arange(b, dtype=torch.int32, device=dev) * lp
-        # table[i, j] = row of token j of sequence i on the padded grid (pad rows included:
-        # they are overwritten by the sequence's own decode steps, slot_batch.py:104-110)
-        info.b_req_tokens_table[:b, :lp] = info.cur_select_index.view(b, lp)
+        # table[i, j] = row of token j of sequence i on the padded grid, valid tokens only
+        # (_init_req_tokens_table, model_runner.py:153-179); a sequence's pad rows hold junk K/V
+        # that attention never reads, and its own decode steps name fresh rows
+        valid = torch.arange(lp, device=dev).unsqueeze(0) < info.b_seq_len.view(b, 1)
+        info.b_req_tokens_table[:b, :lp] = torch.where(valid, info.cur_select_index.view(b, lp),
+                                                       info.b_req_tokens_table[:b, :lp])
         position_ids = torch.arange(lp, device=dev).unsqueeze(0).expand(b, lp)
         rows = torch.arange(b, device=dev) * lp + (prompt_lens.long() - 1)
         last = self.model(prompt_ids, position_ids, info, logits_rows=rows)
@@ -268,3 +278,6 @@ class DecodeEngine:
         self._step.copy_(snap[4])
         self._out.copy_(snap[5])
         info.b_req_tokens_table.copy_(snap[6])
+
+
+from .slots import DEFAULT_BATCH_SIZES, DEFAULT_SEQ_LEN_BUCKETS, SlotBatch, SlotRunner, StepGraphs, slot_advance  # noqa: E402,F401

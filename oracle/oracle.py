@@ -86,6 +86,13 @@ def update_kv_index(table, b_req_idx, b_seq_len, select_index) -> None:
 # --------------------------------------------------------------------------- #
 # a5: flash_decoding  (kernels/flashdecoding.py:23-161 stage 1, :224-287 stage 2)
 # --------------------------------------------------------------------------- #
+def slot_advance(b_seq_len, b_req_idx, cur_select_index, table):
+    """Steady state of SlotBatch.begin_decode (executor/slot_batch.py:152-166), in place:
+    ``b_seq_len += 1`` then ``cur_select_index = table[b_req_idx, b_seq_len - 1]``."""
+    b_seq_len += 1
+    cur_select_index.copy_(table[b_req_idx.long(), b_seq_len.long() - 1])
+
+
 def flash_decoding(q, k_cache, v_cache, qk_scale, table, b_req_idx, b_seq_len, max_len):
     """Two-stage split-KV decode attention in fp32: 128-token partitions, 16-token
     online-softmax chunks, per-partition normalised partials + ``m + log d``, then
