@@ -204,6 +204,24 @@ int ll_decode_advance(int64_t* out, int64_t out_stride, int64_t* step, const int
                       int32_t* b_seq_len, const int32_t* b_req_idx, int32_t* table,
                       int64_t table_stride_b, int64_t table_stride_s, int batch, void* stream);
 
+/* ---- load-time ingestion of third-party int4 checkpoint layouts -------------
+ * The reference reaches W4A16 only by re-quantising fp16 weights: AutoAWQ / AutoGPTQ tensors map
+ * to unknown parameters (models/weights.py:166-173,266-268).  These two entries convert such
+ * tensors, on the device and bit-exactly, into the layout a8 consumes: out_qweight int32 [N, K/8]
+ * (nibbles sequential along K, LSB first), out_scales / out_zeros fp32 [N, K/group].
+ *   AWQ  (AutoAWQ 0.2.x GEMM): qweight int32 [K, N/8] and qzeros int32 [K/g, N/8], eight output
+ *        channels per word in the order {0,2,4,6,1,3,5,7}; scales fp16 [K/g, N]; w = (q - z) s.
+ *   GPTQ (AutoGPTQ 0.7.x, no act-order): qweight int32 [K/8, N], eight input channels per word,
+ *        sequential; qzeros int32 [K/g, N/8] sequential; scales fp16 [K/g, N];
+ *        w = (q - (zs + zero_offset)) s with zero_offset 1 for v1 checkpoints, 0 for v2.
+ * K % 8 == 0, N % 8 == 0, K % group == 0, else LL_ERR_SHAPE. */
+int ll_w4_from_awq(int32_t* out_qweight, float* out_scales, float* out_zeros, const int32_t* qweight,
+                   const int32_t* qzeros, const void* scales_f16, int64_t k, int64_t n,
+                   int64_t group_size, void* stream);
+int ll_w4_from_gptq(int32_t* out_qweight, float* out_scales, float* out_zeros, const int32_t* qweight,
+                    const int32_t* qzeros, const void* scales_f16, int64_t k, int64_t n,
+                    int64_t group_size, int zero_offset, void* stream);
+
 /* Continuous-batching step metadata in one launch (executor/slot_batch.py:135-169: the steady
  * state of SlotBatch.begin_decode, ``b_seq_len += 1`` then ``cur_select_index = table[b_req_idx,
  * b_seq_len - 1]``).  b_seq_len / b_req_idx are int32 or int64 (idx_width); cur_select_index and

@@ -50,6 +50,8 @@ SIGNATURES = {
     "ll_argmax": [P, P, L, L, L, I, P],
     "ll_decode_advance": [P, L, P, P, P, P, P, P, P, P, L, L, I, P],
     "ll_slot_advance": [P, P, P, P, P, P, P, L, L, I, I, P],
+    "ll_w4_from_awq": [P, P, P, P, P, P, L, L, L, P],
+    "ll_w4_from_gptq": [P, P, P, P, P, P, L, L, L, I, P],
     "ll_repetition_penalty": [P, P, P, P, P, F, L, L, L, L, L, L, L, I, I, P],
     "ll_sample_top_p": [P, P, P, P, P, P, L, L, L, I, P],
     "ll_argmax_split": [P, P, L, L, L, I, P, I, P],

@@ -17,3 +17,4 @@ from .params import (
     quantize_int8_groupwise,
     quantize_int8_per_channel,
 )
+from .checkpoint_layouts import awq_to_w4a16, gptq_to_w4a16, load_int4_checkpoint_linear  # noqa: E402,F401
