@@ -204,6 +204,26 @@ int ll_decode_advance(int64_t* out, int64_t out_stride, int64_t* step, const int
                       int32_t* b_seq_len, const int32_t* b_req_idx, int32_t* table,
                       int64_t table_stride_b, int64_t table_stride_s, int batch, void* stream);
 
+/* ---- device-side KV row allocator -------------------------------------------
+ * Replaces the search of executor/kv_cache_manager.py:219-267 (``nonzero`` over the use-count
+ * vector + two ``.item()`` reads = three device synchronisations per call) with three stream-ordered
+ * launches and no read-back.  state: int32 use count per row [n_rows]; free_rows: int64 [1] device
+ * counter of zero-count rows (debited by ``need`` on success); decision: int64 [2] = {mode, start}
+ * with mode 0 = nothing allocated (fewer than ``need`` free rows, or no run in contiguous-only mode),
+ * 1 = contiguous run starting at ``start``, 2 = the first ``need`` free rows in ascending order;
+ * out_index: int32 [need] row ids (untouched when mode 0).  contiguous_first: 0 = scattered only
+ * (alloc_kvcache :219-231), 1 = first run of ``need`` consecutive free rows else scattered
+ * (alloc_kvcache_index :270-299 general path), 2 = contiguous only (alloc_contiguous_kvcache
+ * :234-267).  Allocated rows get count 1.  scratch: ll_kv_alloc_scratch_bytes(n_rows) bytes. */
+int64_t ll_kv_alloc_scratch_bytes(int64_t n_rows);
+int ll_kv_alloc(int32_t* state, int64_t n_rows, int64_t need, int contiguous_first, int32_t* out_index,
+                void* scratch, int64_t* decision, int64_t* free_rows, void* stream);
+/* add_ref (delta +1, :302-314) / release_ref (delta -1, :317-333) over ``count`` row ids (int32 or
+ * int64; duplicates each count); free_rows is debited for rows leaving 0 and credited for rows
+ * reaching 0. */
+int ll_kv_ref_update(int32_t* state, int64_t n_rows, const void* index, int64_t count, int idx_width,
+                     int delta, int64_t* free_rows, void* stream);
+
 /* ---- load-time ingestion of third-party int4 checkpoint layouts -------------
  * The reference reaches W4A16 only by re-quantising fp16 weights: AutoAWQ / AutoGPTQ tensors map
  * to unknown parameters (models/weights.py:166-173,266-268).  These two entries convert such

@@ -50,6 +50,9 @@ SIGNATURES = {
     "ll_argmax": [P, P, L, L, L, I, P],
     "ll_decode_advance": [P, L, P, P, P, P, P, P, P, P, L, L, I, P],
     "ll_slot_advance": [P, P, P, P, P, P, P, L, L, I, I, P],
+    "ll_kv_alloc_scratch_bytes": [L],
+    "ll_kv_alloc": [P, L, L, I, P, P, P, P, P],
+    "ll_kv_ref_update": [P, L, P, L, I, I, P, P],
     "ll_w4_from_awq": [P, P, P, P, P, P, L, L, L, P],
     "ll_w4_from_gptq": [P, P, P, P, P, P, L, L, L, I, P],
     "ll_repetition_penalty": [P, P, P, P, P, F, L, L, L, L, L, L, L, I, I, P],
@@ -57,6 +60,7 @@ SIGNATURES = {
     "ll_argmax_split": [P, P, L, L, L, I, P, I, P],
 }
 
+_RETURNS_I64 = {"ll_kv_alloc_scratch_bytes"}
 _lib = None
 
 
@@ -76,7 +80,7 @@ def lib() -> ctypes.CDLL:
         for name, argtypes in SIGNATURES.items():
             fn = getattr(handle, name)  # AttributeError if the symbol is missing -> loud
             fn.argtypes = argtypes
-            fn.restype = c_int
+            fn.restype = ctypes.c_int64 if name in _RETURNS_I64 else c_int
         if handle.ll_abi_version() != ABI_VERSION:
             raise RuntimeError("lite_llama_amd: ABI version mismatch between _lib.py and the .so")
         _lib = handle

@@ -281,3 +281,4 @@ class DecodeEngine:
 
 
 from .slots import DEFAULT_BATCH_SIZES, DEFAULT_SEQ_LEN_BUCKETS, SlotBatch, SlotRunner, StepGraphs, slot_advance  # noqa: E402,F401
+from .kv_cache_manager import KVCacheManager  # noqa: E402,F401

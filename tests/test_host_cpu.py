@@ -17,13 +17,14 @@ def test_abi_exports_match_header():
     build.build(verbose=False)
     lib = _lib.lib()
     header = open(os.path.join(ROOT, "include", "lite_llama_amd.h")).read()
-    declared = set(re.findall(r"^int\s+(ll_[a-z0-9_]+)\s*\(", header, flags=re.M))
+    declared = set(re.findall(r"^(?:int|int64_t)\s+(ll_[a-z0-9_]+)\s*\(", header, flags=re.M))
     assert declared, "no declarations parsed"
     assert declared == set(_lib.SIGNATURES), declared ^ set(_lib.SIGNATURES)
     for name in declared:
         assert hasattr(lib, name), name
     assert lib.ll_abi_version() == _lib.ABI_VERSION
     assert lib.ll_flash_decoding_num_partitions(129) == 2
+    assert lib.ll_kv_alloc_scratch_bytes(4097) == 2 * (16 + 8) + 64
 
 
 def test_kernel_names_match_reference_surface():
