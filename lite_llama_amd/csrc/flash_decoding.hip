@@ -217,14 +217,29 @@ __global__ void fd_stage2(uint16_t* __restrict__ out, const float* __restrict__ 
   const float* mo = mid_o + ((int64_t)b * hq + h) * nparts * d;
   const float* ml = mid_lse + ((int64_t)b * hq + h) * nparts;
   float m_i = -INFINITY, d_i = 0.f, acc = 0.f;
-  for (int pp = 0; pp < np; ++pp) {
-    const float lse = ml[pp];
-    const float m_new = fmaxf(m_i, lse);
-    const float alpha = expf(m_i - m_new);
-    const float w = expf(lse - m_new);
-    acc = acc * alpha + w * mo[(int64_t)pp * d + threadIdx.x];
-    d_i = d_i * alpha + w;
-    m_i = m_new;
+  // partitions in batches of 8: all 16 loads of a batch are issued before the first use (indices
+  // clamped, none inside a branch), so a batch costs one memory round trip instead of eight
+  // dependent ones; the merge itself stays the sequential recurrence of the reference (:264-287)
+  for (int p0 = 0; p0 < np; p0 += 8) {
+    float lse[8], mo_v[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int pp = p0 + u < np ? p0 + u : np - 1;
+      lse[u] = ml[pp];
+      mo_v[u] = mo[(int64_t)pp * d + threadIdx.x];
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const bool live = p0 + u < np;
+      const float m_new = fmaxf(m_i, lse[u]);
+      const float alpha = expf(m_i - m_new);
+      const float w = expf(lse[u] - m_new);
+      const float acc_n = acc * alpha + w * mo_v[u];
+      const float d_n = d_i * alpha + w;
+      acc = live ? acc_n : acc;
+      d_i = live ? d_n : d_i;
+      m_i = live ? m_new : m_i;
+    }
   }
   out[b * o_sb + (int64_t)h * o_sh + threadIdx.x] = from_f32<DT>(acc / d_i);  // 0/0 -> NaN like the reference
 }

@@ -35,45 +35,49 @@ __global__ __launch_bounds__(256) void skip_rmsnorm_cached(uint16_t* __restrict_
   const int64_t row = (int64_t)blockIdx.x * RPB + threadIdx.x / TPR;
   const bool active = row < rows;
   const float nf = (float)n;
+  // Every load of the kernel is issued here, unconditionally (a lane without work re-reads element
+  // 0): loads inside branches make hipcc drain the memory counter per branch, which turns the
+  // kernel into a chain of dependent round trips (x/residual per vector, then the weight per
+  // vector after the reduction) -- at decode sizes the kernel is nothing but latency.
+  U16x8 xv[VPT], rv[VPT], wv[VPT];
+  bool ok[VPT];
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    const int col = (v * TPR + tr) * 8;
+    ok[v] = active && col < n;
+    const int64_t off = ok[v] ? row * n + col : 0;
+    xv[v] = *reinterpret_cast<const U16x8*>(x + off);
+    if constexpr (HAS_RES) rv[v] = *reinterpret_cast<const U16x8*>(r + off);
+    wv[v] = *reinterpret_cast<const U16x8*>(w + (ok[v] ? col : 0));
+  }
   float s[VPT][8];
   float ssq = 0.f;
 #pragma unroll
   for (int v = 0; v < VPT; ++v) {
-    const int col = (v * TPR + tr) * 8;
-    if (active && col < n) {
-      uint16_t xv[8];
-      VecIO<8>::load(x + row * n + col, xv);
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float sv = to_f32<DT>(xv[v].v[i]);
       if constexpr (HAS_RES) {
-        uint16_t rv[8];
-        VecIO<8>::load(r + row * n + col, rv);
-#pragma unroll
-        for (int i = 0; i < 8; ++i) {
-          s[v][i] = to_f32<DT>(xv[i]) + to_f32<DT>(rv[i]);
-          rv[i] = from_f32<DT>(s[v][i]);
-        }
-        VecIO<8>::store(r + row * n + col, rv);
-      } else {
-#pragma unroll
-        for (int i = 0; i < 8; ++i) s[v][i] = to_f32<DT>(xv[i]);
+        sv += to_f32<DT>(rv[v].v[i]);
+        rv[v].v[i] = from_f32<DT>(sv);
       }
-#pragma unroll
-      for (int i = 0; i < 8; ++i) ssq += s[v][i] * s[v][i] / nf;
-    } else {
-#pragma unroll
-      for (int i = 0; i < 8; ++i) s[v][i] = 0.f;
+      s[v][i] = ok[v] ? sv : 0.f;
     }
+    if constexpr (HAS_RES) {
+      if (ok[v]) *reinterpret_cast<U16x8*>(r + row * n + (v * TPR + tr) * 8) = rv[v];
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ssq += s[v][i] * s[v][i] / nf;
   }
   const float var = row_sum<TPR>(ssq, lds);
   const float rrms = 1.0f / sqrtf(var + eps);
 #pragma unroll
   for (int v = 0; v < VPT; ++v) {
-    const int col = (v * TPR + tr) * 8;
-    if (active && col < n) {
-      uint16_t wv[8], yv[8];
-      VecIO<8>::load(w + col, wv);
+    if (ok[v]) {
+      U16x8 yv;
 #pragma unroll
-      for (int i = 0; i < 8; ++i) yv[i] = mul_storage<DT>(from_f32<DT>(s[v][i] * rrms), wv[i]);
-      VecIO<8>::store(y + row * n + col, yv);
+      for (int i = 0; i < 8; ++i) yv.v[i] = mul_storage<DT>(from_f32<DT>(s[v][i] * rrms), wv[v].v[i]);
+      *reinterpret_cast<U16x8*>(y + row * n + (v * TPR + tr) * 8) = yv;
     }
   }
 }
@@ -357,8 +361,11 @@ extern "C" int ll_rope(void* q, void* k, const void* cos_t, const void* sin_t, i
 // q and k are rotated IN PLACE, and the rotated k heads + the v heads of token i land in pool row
 // select_index[i].  kv = [tokens, 2*n_kh, hd] rows (K heads first), token stride given.
 // --------------------------------------------------------------------------- //
-template <int DT, int CS, int VEC>
-__global__ __launch_bounds__(256) void rope_cache_kernel(
+// CSV: the cos/sin rows are 16-bit and 16-byte aligned -> one vector load each per thread (else
+// element loads).  Launched with one thread per (head, vector) so the loop body runs once; every
+// load is issued before the first use and none sits in a branch (see skip_rmsnorm_cached).
+template <int DT, int CS, int VEC, bool CSV>
+__global__ __launch_bounds__(1024) void rope_cache_kernel(
     uint16_t* __restrict__ q, uint16_t* __restrict__ kv, const void* __restrict__ cos_t,
     const void* __restrict__ sin_t, uint16_t* __restrict__ pool, const void* __restrict__ sel, int n_qh,
     int n_kh, int hd, int64_t q_rs, int64_t kv_rs, int64_t seq_len, int64_t cbs, int64_t css, int64_t sbs,
@@ -372,30 +379,42 @@ __global__ __launch_bounds__(256) void rope_cache_kernel(
   const int total = (n_qh + 2 * n_kh) * vph;
   const int64_t cbase = bi * cbs + si * css;
   const int64_t sbase = bi * sbs + si * sss;
-  for (int i = threadIdx.x; i < total; i += 256) {
+  for (int i = threadIdx.x; i < total; i += blockDim.x) {
     const int h = i / vph, j = (i % vph) * VEC;
     const int hk = h - n_qh;  // >= 0: row of the [2*n_kh, hd] kv block
     uint16_t* base = (hk < 0) ? (q + tok * q_rs + (int64_t)h * hd) : (kv + tok * kv_rs + (int64_t)hk * hd);
     uint16_t x1[VEC], x2[VEC], o1[VEC], o2[VEC];
     VecIO<VEC>::load(base + j, x1);
     VecIO<VEC>::load(base + half + j, x2);
-    if (hk < n_kh) {
+    float c[VEC], sn[VEC];
+    if constexpr (CSV) {
+      uint16_t cv[VEC], sv[VEC];
+      VecIO<VEC>::load((const uint16_t*)cos_t + cbase + j, cv);
+      VecIO<VEC>::load((const uint16_t*)sin_t + sbase + j, sv);
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        const float c = load_cs<CS>(cos_t, cbase + j + e);
-        const float s = load_cs<CS>(sin_t, sbase + j + e);
-        const float a = to_f32<DT>(x1[e]), b = to_f32<DT>(x2[e]);
-        o1[e] = from_f32<DT>(a * c - b * s);
-        o2[e] = from_f32<DT>(b * c + a * s);
+        c[e] = to_f32<CS == LL_F32 ? LL_F16 : CS>(cv[e]);
+        sn[e] = to_f32<CS == LL_F32 ? LL_F16 : CS>(sv[e]);
       }
-      VecIO<VEC>::store(base + j, o1);
-      VecIO<VEC>::store(base + half + j, o2);
     } else {
 #pragma unroll
       for (int e = 0; e < VEC; ++e) {
-        o1[e] = x1[e];
-        o2[e] = x2[e];
+        c[e] = load_cs<CS>(cos_t, cbase + j + e);
+        sn[e] = load_cs<CS>(sin_t, sbase + j + e);
       }
+    }
+    const bool rot = hk < n_kh;  // q and k heads rotate, v heads pass through
+#pragma unroll
+    for (int e = 0; e < VEC; ++e) {
+      const float a = to_f32<DT>(x1[e]), b = to_f32<DT>(x2[e]);
+      const uint16_t r1 = from_f32<DT>(a * c[e] - b * sn[e]);
+      const uint16_t r2 = from_f32<DT>(b * c[e] + a * sn[e]);
+      o1[e] = rot ? r1 : x1[e];
+      o2[e] = rot ? r2 : x2[e];
+    }
+    if (rot) {
+      VecIO<VEC>::store(base + j, o1);
+      VecIO<VEC>::store(base + half + j, o2);
     }
     if (hk >= 0) {
       uint16_t* prow = pool + dst * pst + (int64_t)hk * psh;
@@ -421,15 +440,21 @@ extern "C" int ll_rope_kv_update(void* q, void* kv, const void* cos_t, const voi
   const bool vec = (hd % 16 == 0) && ll_aligned16(q) && ll_aligned16(kv) && ll_aligned16(kv_buffer) &&
                    (q_row_stride % 8 == 0) && (kv_row_stride % 8 == 0) && (pool_stride_t % 8 == 0) &&
                    (pool_stride_h % 8 == 0);
-#define LL_RC(DT, CS, VEC)                                                                              \
-  rope_cache_kernel<DT, CS, VEC><<<dim3((unsigned)tokens), 256, 0, st>>>(                               \
+  const bool csv = vec && cs_dtype != LL_F32 && ll_aligned16(cos_t) && ll_aligned16(sin_t) &&
+                   ((cos_b_stride | cos_s_stride | sin_b_stride | sin_s_stride) % 8 == 0);
+  const int work = (n_qh + 2 * n_kh) * (hd / 2 / (vec ? 8 : 1));
+  const unsigned threads = (unsigned)(work >= 1024 ? 1024 : (work + 63) / 64 * 64);
+#define LL_RC(DT, CS, VEC, CSV)                                                                         \
+  rope_cache_kernel<DT, CS, VEC, CSV><<<dim3((unsigned)tokens), threads, 0, st>>>(                      \
       (uint16_t*)q, (uint16_t*)kv, cos_t, sin_t, (uint16_t*)kv_buffer, select_index, n_qh, n_kh, hd,    \
       q_row_stride, kv_row_stride, seq_len, cos_b_stride, cos_s_stride, sin_b_stride, sin_s_stride,     \
       pool_stride_t, pool_stride_h, idx_width, positions)
-#define LL_RC_CS(DT, VEC)                                   \
-  if (cs_dtype == LL_F16) LL_RC(DT, LL_F16, VEC);           \
-  else if (cs_dtype == LL_BF16) LL_RC(DT, LL_BF16, VEC);    \
-  else LL_RC(DT, LL_F32, VEC)
+#define LL_RC_CS(DT, VEC)                                                      \
+  if (cs_dtype == LL_F16) {                                                    \
+    if (csv) LL_RC(DT, LL_F16, VEC, true); else LL_RC(DT, LL_F16, VEC, false);   \
+  } else if (cs_dtype == LL_BF16) {                                            \
+    if (csv) LL_RC(DT, LL_BF16, VEC, true); else LL_RC(DT, LL_BF16, VEC, false); \
+  } else LL_RC(DT, LL_F32, VEC, false)
   if (qk_dtype == LL_F16) {
     if (vec) { LL_RC_CS(LL_F16, 8); } else { LL_RC_CS(LL_F16, 1); }
   } else {
