@@ -99,7 +99,12 @@ int ll_update_kv_index(int32_t* table, const void* b_req_idx, const void* b_seq_
  * rows = table[b_req_idx[b], :b_seq_len[b]], kv head = h / (hq/hkv).
  * K/V are (possibly strided) views [tokens, hkv, d], d contiguous.  Scratch:
  * mid_o fp32 [batch, hq, nparts, d], mid_lse fp32 [batch, hq, nparts], with
- * nparts = ll_flash_decoding_num_partitions(max_len). */
+ * nparts = ll_flash_decoding_num_partitions(max_len).
+ * counters: NULL, or an int32 vector of batch * hkv * ceil((hq/hkv)/16) entries that is ZERO at
+ * launch; with it the log-sum-exp merge runs inside the same launch (the wave finishing a row's
+ * last partition merges; the vector is zero again when the kernel ends); mid_lse must then hold
+ * 32 floats per (row, head, partition) -- batch * hq * nparts * 32 -- one cache line per record.
+ * Same values either way. */
 int ll_flash_decoding_num_partitions(int64_t max_len);
 int ll_flash_decoding(void* out, const void* q, const void* k_cache, const void* v_cache,
                       const int32_t* table, const void* b_req_idx, const void* b_seq_len,
@@ -108,7 +113,7 @@ int ll_flash_decoding(void* out, const void* q, const void* k_cache, const void*
                       int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t,
                       int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
                       int64_t table_stride_b, int dtype, int req_width, int seq_width,
-                      void* stream);
+                      int32_t* counters, void* stream);
 
 /* ---- a6: flash_attention2_no_pad  (kernels/flashattention2_nopad.py:175-231) --
  * Varlen causal prefill over freshly projected q/k/v (exp2 softmax; sm_scale

@@ -17,6 +17,7 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define FD_PART 128  // tokens per partition (reference PARTITION_SIZE, flashdecoding.py:343)
+#define FD_LSE_PAD 32  // floats per log-sum-exp record in the one-launch form (one cache line each)
 
 struct alignas(16) Q4 {
   uint32_t x, y, z, w;
@@ -42,13 +43,18 @@ __device__ __forceinline__ int64_t fd_load_idx(const void* p, int64_t i, int w) 
 }
 
 // grid = (nparts, hkv * head_groups, batch), block = 64 (one wave)
-template <int DT, int D>
+// FUSE: the wave that finishes the LAST non-empty partition of its (row, KV head group) also does the
+// log-sum-exp merge and writes ``out`` (no second launch: a kernel boundary costs ~4.7 us in the
+// decode graph, the merge itself ~1 us).  Partials are written through (sc1), a relaxed agent-scope
+// counter orders them, the merging wave reads them with coherent (sc1) loads and zeroes the counter.
+template <int DT, int D, bool FUSE>
 __global__ __launch_bounds__(64) void fd_stage1(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     const int32_t* __restrict__ table, const void* __restrict__ b_req_idx,
     const void* __restrict__ b_seq_len, float* __restrict__ mid_o, float* __restrict__ mid_lse,
     int hq, int hkv, int nparts, float scale, int64_t q_sb, int64_t q_sh, int64_t k_st, int64_t k_sh,
-    int64_t v_st, int64_t v_sh, int64_t t_sb, int req_w, int seq_w) {
+    int64_t v_st, int64_t v_sh, int64_t t_sb, int req_w, int seq_w, uint16_t* __restrict__ out, int64_t o_sb,
+    int64_t o_sh, int32_t* __restrict__ counters) {
   constexpr int NS = D / 32;      // MFMA k-steps over the head dim
   constexpr int NT = D / 16;      // output d-tiles
   constexpr int VSTR = D + 8;     // padded LDS row stride (elements)
@@ -67,7 +73,17 @@ __global__ __launch_bounds__(64) void fd_stage1(
 
   const int64_t seq_len = fd_load_idx(b_seq_len, b, seq_w);
   const int64_t start = (int64_t)part * FD_PART;
-  if (start >= seq_len) return;  // empty partition stores nothing (flashdecoding.py:141-161)
+  if (start >= seq_len) {  // empty partition stores nothing (flashdecoding.py:141-161)
+    if constexpr (FUSE) {
+      // a zero-length row has no merging wave: its first partition writes the 0/0 the reference's
+      // stage 2 computes for it (:264-287)
+      if (part == 0 && head_ok) {
+        const float nan = __builtin_nanf("");
+        for (int dd = c; dd < D; dd += 4) out[b * o_sb + (int64_t)head * o_sh + dd] = from_f32<DT>(nan);
+      }
+    }
+    return;
+  }
   const int64_t end = seq_len < start + FD_PART ? seq_len : start + FD_PART;
   const int64_t req = fd_load_idx(b_req_idx, b, req_w);
   const int32_t* trow = table + req * t_sb;
@@ -192,16 +208,114 @@ __global__ __launch_bounds__(64) void fd_stage1(
 #undef FD_LOAD
 #undef FD_COMPUTE
 
-  if (head_ok) {
-    const float inv = 1.0f / d_i;
-    float* mo = mid_o + (((int64_t)b * hq + head) * nparts + part) * D;
+  if constexpr (!FUSE) {
+    if (head_ok) {
+      const float inv = 1.0f / d_i;
+      float* mo = mid_o + (((int64_t)b * hq + head) * nparts + part) * D;
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) {
+        f32x4 o = ot[dt];
+        o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
+        *reinterpret_cast<f32x4*>(mo + dt * 16 + 4 * c) = o;
+      }
+      if (c == 0) mid_lse[((int64_t)b * hq + head) * nparts + part] = m_i + logf(d_i);
+    }
+  } else {
+    int np = (int)((seq_len + FD_PART - 1) / FD_PART);
+    if (np > nparts) np = nparts;
+    const int64_t hrow = ((int64_t)b * hq + (head_ok ? head : 0)) * nparts;
+    if (np > 1) {
+      if (head_ok) {
+        const float inv = 1.0f / d_i;
+        float* mo = mid_o + (hrow + part) * D;
+#pragma unroll
+        for (int dt = 0; dt < NT; ++dt) {
+          f32x4 o = ot[dt];
+          o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
+          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(mo + dt * 16 + 4 * c), "v"(o) : "memory");
+        }
+        // one 128-byte line per (head, partition): a line that the merging wave's own XCD has
+        // written into (its own lse) could otherwise serve a stale copy of a neighbour's value
+        if (c == 0)
+          __hip_atomic_store(mid_lse + (hrow + part) * FD_LSE_PAD, m_i + logf(d_i), __ATOMIC_RELAXED,
+                             __HIP_MEMORY_SCOPE_AGENT);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partials are out before the counter moves
+      int32_t* ctr = counters + (int64_t)b * gridDim.y + blockIdx.y;
+      int old = 0;
+      if (lane == 0) old = __hip_atomic_fetch_add(ctr, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      old = __builtin_amdgcn_readfirstlane(old);
+      if (old != np - 1) return;
+      if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+    }
+    if (!head_ok) return;
+    uint16_t* orow = out + b * o_sb + (int64_t)head * o_sh + 4 * c;
+    if (np == 1) {
+      // single partition: stage 2 computes (0*0 + 1*(o/d)) / (0*0 + 1) -- the same value
+      const float inv = 1.0f / d_i;
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) {
+        uint16_t o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = from_f32<DT>(ot[dt][e] * inv);
+        *reinterpret_cast<uint2*>(orow + dt * 16) =
+            uint2{(uint32_t)o4[0] | ((uint32_t)o4[1] << 16), (uint32_t)o4[2] | ((uint32_t)o4[3] << 16)};
+      }
+      return;
+    }
+    // merge the np partials of this head in partition order (same recurrence as fd_stage2), two
+    // partitions' loads in flight at a time
+    float mm = -INFINITY, dd = 0.f;
+    f32x4 acc[NT];
+#pragma unroll
+    for (int dt = 0; dt < NT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
+    const float* mo0 = mid_o + hrow * D + 4 * c;
+    const float* ml0 = mid_lse + hrow * FD_LSE_PAD;
+    for (int p0 = 0; p0 < np; p0 += 2) {
+      const bool two = p0 + 1 < np;
+      const int p1 = two ? p0 + 1 : p0;
+      f32x4 va[NT], vb[NT];
+      float la, lb;
+      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(la) : "v"(ml0 + (int64_t)p0 * FD_LSE_PAD) : "memory");
+      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(lb) : "v"(ml0 + (int64_t)p1 * FD_LSE_PAD) : "memory");
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) {
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(va[dt]) : "v"(mo0 + (int64_t)p0 * D + dt * 16) : "memory");
+        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(vb[dt]) : "v"(mo0 + (int64_t)p1 * D + dt * 16) : "memory");
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      asm volatile("" : "+v"(la), "+v"(lb));
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) asm volatile("" : "+v"(va[dt]), "+v"(vb[dt]));  // uses stay below the wait
+      {
+        const float m_new = fmaxf(mm, la);
+        const float alpha = expf(mm - m_new), w = expf(la - m_new);
+#pragma unroll
+        for (int dt = 0; dt < NT; ++dt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[dt][e] = acc[dt][e] * alpha + w * va[dt][e];
+        dd = dd * alpha + w;
+        mm = m_new;
+      }
+      if (two) {
+        const float m_new = fmaxf(mm, lb);
+        const float alpha = expf(mm - m_new), w = expf(lb - m_new);
+#pragma unroll
+        for (int dt = 0; dt < NT; ++dt)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) acc[dt][e] = acc[dt][e] * alpha + w * vb[dt][e];
+        dd = dd * alpha + w;
+        mm = m_new;
+      }
+    }
 #pragma unroll
     for (int dt = 0; dt < NT; ++dt) {
-      f32x4 o = ot[dt];
-      o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
-      *reinterpret_cast<f32x4*>(mo + dt * 16 + 4 * c) = o;
+      uint16_t o4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] = from_f32<DT>(acc[dt][e] / dd);
+      *reinterpret_cast<uint2*>(orow + dt * 16) =
+          uint2{(uint32_t)o4[0] | ((uint32_t)o4[1] << 16), (uint32_t)o4[2] | ((uint32_t)o4[3] << 16)};
     }
-    if (c == 0) mid_lse[((int64_t)b * hq + head) * nparts + part] = m_i + logf(d_i);
   }
 }
 
@@ -253,25 +367,33 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
                      const void* req, const void* seq, float* mid_o, float* mid_lse, int batch, int hq,
                      int hkv, int d, int64_t max_len, float scale, int64_t q_sb, int64_t q_sh,
                      int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_sh,
-                     int64_t t_sb, int req_w, int seq_w, hipStream_t st) {
+                     int64_t t_sb, int req_w, int seq_w, int32_t* counters, hipStream_t st) {
   const int nparts = ll_flash_decoding_num_partitions(max_len);
   const int groups = hq / hkv;
   const int hgroups = (groups + 15) / 16;
   dim3 grid((unsigned)nparts, (unsigned)(hkv * hgroups), (unsigned)batch);
-#define LL_FD1(DD)                                                                                   \
-  fd_stage1<DT, DD><<<grid, 64, 0, st>>>((const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, \
-                                         table, req, seq, mid_o, mid_lse, hq, hkv, nparts, scale, q_sb, \
-                                         q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w)
+  // one launch when the caller lends a (zeroed, self-cleaning) counter vector and ``out`` takes 8-byte stores
+  const bool fuse = counters != nullptr && (o_sb % 4 == 0) && (o_sh % 4 == 0) && ((uintptr_t)out % 8 == 0);
+#define LL_FD1(DD, FU)                                                                               \
+  fd_stage1<DT, DD, FU><<<grid, 64, 0, st>>>((const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, \
+                                             table, req, seq, mid_o, mid_lse, hq, hkv, nparts, scale, q_sb, \
+                                             q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w, (uint16_t*)out, \
+                                             o_sb, o_sh, counters)
+#define LL_FD1D(DD)          \
+  if (fuse) LL_FD1(DD, true); \
+  else LL_FD1(DD, false)
   switch (d) {
-    case 32: LL_FD1(32); break;
-    case 64: LL_FD1(64); break;
-    case 128: LL_FD1(128); break;
-    case 256: LL_FD1(256); break;
+    case 32: LL_FD1D(32); break;
+    case 64: LL_FD1D(64); break;
+    case 128: LL_FD1D(128); break;
+    case 256: LL_FD1D(256); break;
     default: return LL_ERR_SHAPE;
   }
+#undef LL_FD1D
 #undef LL_FD1
-  fd_stage2<DT><<<dim3((unsigned)hq, (unsigned)batch), d, 0, st>>>((uint16_t*)out, mid_o, mid_lse, seq, hq, d,
-                                                                   nparts, o_sb, o_sh, seq_w);
+  if (!fuse)
+    fd_stage2<DT><<<dim3((unsigned)hq, (unsigned)batch), d, 0, st>>>((uint16_t*)out, mid_o, mid_lse, seq, hq, d,
+                                                                     nparts, o_sb, o_sh, seq_w);
   return LL_LAUNCH_CHECK();
 }
 
@@ -282,7 +404,7 @@ extern "C" int ll_flash_decoding(void* out, const void* q, const void* k_cache, 
                                  int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t,
                                  int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
                                  int64_t table_stride_b, int dtype, int req_width, int seq_width,
-                                 void* stream) {
+                                 int32_t* counters, void* stream) {
   if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
   if ((req_width | seq_width) & ~1) return LL_ERR_DTYPE;
   if (batch < 0 || hq <= 0 || hkv <= 0 || hq % hkv != 0 || max_len < 0) return LL_ERR_SHAPE;
@@ -296,9 +418,9 @@ extern "C" int ll_flash_decoding(void* out, const void* q, const void* k_cache, 
     return launch_fd<LL_F16>(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch,
                              hq, hkv, d, max_len, qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h,
                              v_stride_t, v_stride_h, o_stride_b, o_stride_h, table_stride_b, req_width,
-                             seq_width, st);
+                             seq_width, counters, st);
   return launch_fd<LL_BF16>(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch, hq,
                             hkv, d, max_len, qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h,
                             v_stride_t, v_stride_h, o_stride_b, o_stride_h, table_stride_b, req_width,
-                            seq_width, st);
+                            seq_width, counters, st);
 }

@@ -8,6 +8,25 @@ import torch
 from .. import _lib as L
 
 
+# zeroed, self-cleaning counters for the one-launch merge (kernels never allocate; grown outside
+# graph capture; outgrown vectors stay alive for graphs that captured their address)
+_fd_counters: dict = {}
+_fd_keepalive: list = []
+
+
+def _merge_counters(device, entries: int):
+    cur = _fd_counters.get(device)
+    if cur is not None and cur.numel() >= entries:
+        return cur
+    if torch.cuda.is_current_stream_capturing():
+        return None  # first use inside a capture: take the two-launch form this once
+    if cur is not None:
+        _fd_keepalive.append(cur)
+    cur = torch.zeros(max(entries, 4096), dtype=torch.int32, device=device)
+    _fd_counters[device] = cur
+    return cur
+
+
 @torch.no_grad()
 def flash_decoding(
     q,
@@ -38,8 +57,12 @@ def flash_decoding(
     max_len = int(max_actual_seq_len)
     nparts = L.lib().ll_flash_decoding_num_partitions(max_len)
     mid_o = torch.empty((batchs, num_heads, max(nparts, 1), head_dim), dtype=torch.float32, device=q.device)
-    mid_lse = torch.empty((batchs, num_heads, max(nparts, 1)), dtype=torch.float32, device=q.device)
     out = torch.empty_like(q, memory_format=torch.contiguous_format)
+    n_kv = k_cache.shape[1]
+    counters = _merge_counters(q.device, batchs * n_kv * ((num_heads // n_kv + 15) // 16))
+    # one-launch form: a cache line (32 floats) per log-sum-exp record
+    mid_lse = torch.empty((batchs, num_heads, max(nparts, 1), 1 if counters is None else 32), dtype=torch.float32,
+                          device=q.device)
     L.check(
         L.lib().ll_flash_decoding(
             out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(),
@@ -48,7 +71,7 @@ def flash_decoding(
             max_len, float(qk_scale), q.stride(0), q.stride(1), k_cache.stride(0), k_cache.stride(1),
             v_cache.stride(0), v_cache.stride(1), out.stride(0), out.stride(1),
             b_req_tokens_table.stride(0), L.dtype_code(q.dtype), L.index_width(b_req_idx),
-            L.index_width(b_seq_len), L.stream_ptr(),
+            L.index_width(b_seq_len), L.ptr(counters), L.stream_ptr(),
         ),
         "flash_decoding",
     )

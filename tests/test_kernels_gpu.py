@@ -277,6 +277,35 @@ def test_flash_decoding_long_finite_and_uniform_v():
     close(out, torch.full_like(out, 0.25), 1e-2)
 
 
+def test_flash_decoding_one_launch_merge_equals_two_launch(monkeypatch):
+    """The in-kernel merge (last partition's wave) is the same recurrence as the separate merge kernel:
+    bit-identical outputs, counters left at zero, zero-length rows give the reference's 0/0."""
+    import lite_llama_amd.kernels.attention as A
+
+    torch.manual_seed(11)
+    for hq, hkv, d, lens in [(28, 4, 128, [1, 127, 128, 129, 600, 333]), (8, 8, 64, [5, 256, 257]),
+                             (40, 2, 32, [700, 2])]:
+        kc = torch.randn(_MAX_TOKENS, hkv, d, device=DEV, dtype=torch.float16)
+        vc = torch.randn(_MAX_TOKENS, hkv, d, device=DEV, dtype=torch.float16)
+        q = (torch.randn(len(lens), hq, d, device=DEV) * 0.3).half()
+        table = torch.stack([torch.randperm(_MAX_TOKENS)[: max(lens)] for _ in lens]).to(torch.int32).to(DEV)
+        req = torch.arange(len(lens), dtype=torch.int32, device=DEV)
+        seq = torch.tensor(lens, dtype=torch.int32, device=DEV)
+        args = (q, kc, vc, 1.0 / d ** 0.5, table, req, seq, max(lens))
+        one = K().flash_decoding(*args)
+        ctr = A._fd_counters[q.device]
+        assert int(ctr.abs().sum()) == 0
+        again = K().flash_decoding(*args)
+        with monkeypatch.context() as m:
+            m.setattr(A, "_merge_counters", lambda device, entries: None)
+            two = K().flash_decoding(*args)
+        assert torch.equal(one, two) and torch.equal(one, again)
+    seq0 = torch.tensor([0, 40], dtype=torch.int32, device=DEV)
+    out = K().flash_decoding(q[:2], kc, vc, 0.2, table[:2], req[:2], seq0, 64)
+    assert torch.isnan(out[0]).all() and torch.isfinite(out[1]).all()
+    assert int(A._fd_counters[q.device].abs().sum()) == 0
+
+
 # ------------------------------------------------------------------------------------- #
 # w4a16 (tol 5e-2; nibble unpack bit-exact)
 # ------------------------------------------------------------------------------------- #
