@@ -115,6 +115,25 @@ int ll_flash_decoding(void* out, const void* q, const void* k_cache, const void*
                       int64_t table_stride_b, int dtype, int req_width, int seq_width,
                       int32_t* counters, void* stream);
 
+/* Decode-step attention in one launch (executor extension): rope of q and of the new token's K
+ * with position-indexed tables (kernels/rope_emb.py:86-134 arithmetic), the scatter of that K and V
+ * into pool row select_index[b] (kernels/update_kv_buffer.py:54-89) and flash_decoding, with the same
+ * values as ll_rope_kv_update followed by ll_flash_decoding.  q [batch, hq, d] is read un-rotated and
+ * not written back; kv_new [batch, 2*hkv, d] (K heads first, row stride given); cos/sin 16-bit
+ * tables [max_pos, >= d/2] of the q dtype (row stride given); positions int64 [batch].  k_cache /
+ * v_cache are the (writable) pool views.  counters / mid_lse as for ll_flash_decoding's one-launch
+ * form (required).  d >= 64 and hq/hkv <= 16, else LL_ERR_SHAPE; the select rows must be distinct
+ * and already named by the table at position b_seq_len[b]-1. */
+int ll_decode_attention(void* out, const void* q, const void* kv_new, int64_t kv_row_stride,
+                        const void* cos_t, const void* sin_t, int64_t cs_row_stride,
+                        const int64_t* positions, const void* select_index, int sel_width,
+                        void* k_cache, void* v_cache, const int32_t* table, const void* b_req_idx,
+                        const void* b_seq_len, float* mid_o, float* mid_lse, int batch, int hq, int hkv,
+                        int d, int64_t max_len, float qk_scale, int64_t q_stride_b, int64_t q_stride_h,
+                        int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
+                        int64_t o_stride_b, int64_t o_stride_h, int64_t table_stride_b, int dtype,
+                        int req_width, int seq_width, int32_t* counters, void* stream);
+
 /* ---- a6: flash_attention2_no_pad  (kernels/flashattention2_nopad.py:175-231) --
  * Varlen causal prefill over freshly projected q/k/v (exp2 softmax; sm_scale
  * already carries log2 e).  q/o [tokens, hq, d], k/v [tokens, hkv, d]. */

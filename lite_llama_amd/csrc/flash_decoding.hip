@@ -42,19 +42,38 @@ __device__ __forceinline__ int64_t fd_load_idx(const void* p, int64_t i, int w) 
   return w == LL_I32 ? (int64_t)((const int32_t*)p)[i] : ((const int64_t*)p)[i];
 }
 
+// ROPE (decode step, one launch for rope + KV scatter + attention): q arrives UN-rotated and the new
+// token's K/V in ``kv_new`` ([batch, 2*hkv, D] rows, K heads first).  Every wave rotates its q
+// fragments in registers (the rotation partner d +- D/2 sits in the same lane: fragment s +- NS/2);
+// the wave of the partition that holds the new token rotates k_new and writes K and V into pool row
+// select_index[b] before it gathers (nobody else reads that row).  Element arithmetic is the rope
+// kernel's: fp32 products of the 16-bit values, rounded once.  Needs D >= 64, one head group.
+struct FdRope {
+  const uint16_t* kv_new;
+  int64_t kv_rs;              // kv_new row stride (elements)
+  const uint16_t* cos_t;      // [max_pos, >= D/2] tables, row stride cs_rs
+  const uint16_t* sin_t;
+  int64_t cs_rs;
+  const int64_t* positions;   // [batch]
+  const void* sel;            // select_index [batch]
+  int sel_w;
+  uint16_t* pool_k;           // same storage as kc / vc, writable
+  uint16_t* pool_v;
+};
+
 // grid = (nparts, hkv * head_groups, batch), block = 64 (one wave)
 // FUSE: the wave that finishes the LAST non-empty partition of its (row, KV head group) also does the
 // log-sum-exp merge and writes ``out`` (no second launch: a kernel boundary costs ~4.7 us in the
 // decode graph, the merge itself ~1 us).  Partials are written through (sc1), a relaxed agent-scope
 // counter orders them, the merging wave reads them with coherent (sc1) loads and zeroes the counter.
-template <int DT, int D, bool FUSE>
+template <int DT, int D, bool FUSE, bool ROPE>
 __global__ __launch_bounds__(64) void fd_stage1(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     const int32_t* __restrict__ table, const void* __restrict__ b_req_idx,
     const void* __restrict__ b_seq_len, float* __restrict__ mid_o, float* __restrict__ mid_lse,
     int hq, int hkv, int nparts, float scale, int64_t q_sb, int64_t q_sh, int64_t k_st, int64_t k_sh,
     int64_t v_st, int64_t v_sh, int64_t t_sb, int req_w, int seq_w, uint16_t* __restrict__ out, int64_t o_sb,
-    int64_t o_sh, int32_t* __restrict__ counters) {
+    int64_t o_sh, int32_t* __restrict__ counters, FdRope rp) {
   constexpr int NS = D / 32;      // MFMA k-steps over the head dim
   constexpr int NT = D / 16;      // output d-tiles
   constexpr int VSTR = D + 8;     // padded LDS row stride (elements)
@@ -97,6 +116,75 @@ __global__ __launch_bounds__(64) void fd_stage1(
       qf[s] = *reinterpret_cast<const Q4*>(q + b * q_sb + (int64_t)head * q_sh + s * 32 + c * 8);
     else
       qf[s] = Q4{0, 0, 0, 0};
+  }
+
+  if constexpr (ROPE) {
+    static_assert(!ROPE || NS >= 2, "the rotation partner must be another fragment of the same lane");
+    constexpr int HS = NS / 2;
+    const int64_t crow = rp.positions[b] * rp.cs_rs;
+    Q4 cf[HS], sf[HS];
+#pragma unroll
+    for (int s = 0; s < HS; ++s) {
+      cf[s] = *reinterpret_cast<const Q4*>(rp.cos_t + crow + s * 32 + c * 8);
+      sf[s] = *reinterpret_cast<const Q4*>(rp.sin_t + crow + s * 32 + c * 8);
+    }
+    // the new token lives in the last non-empty partition; head group 0 owns the write
+    if (hg == 0 && part == (int)((seq_len - 1) / FD_PART)) {
+      const int64_t dstrow = fd_load_idx(rp.sel, b, rp.sel_w);
+      const uint16_t* kn = rp.kv_new + b * rp.kv_rs + (int64_t)kvh * D;
+      const uint16_t* vn = rp.kv_new + b * rp.kv_rs + (int64_t)(hkv + kvh) * D;
+      if (lane < D / 16) {
+        const int j = lane * 8;
+        const U16x8 k1 = *reinterpret_cast<const U16x8*>(kn + j), k2 = *reinterpret_cast<const U16x8*>(kn + D / 2 + j);
+        const U16x8 cv = *reinterpret_cast<const U16x8*>(rp.cos_t + crow + j);
+        const U16x8 sv = *reinterpret_cast<const U16x8*>(rp.sin_t + crow + j);
+        U16x8 o1, o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = to_f32<DT>(k1.v[e]), bb = to_f32<DT>(k2.v[e]);
+          const float cc = to_f32<DT>(cv.v[e]), ss = to_f32<DT>(sv.v[e]);
+          o1.v[e] = from_f32<DT>(a * cc - bb * ss);
+          o2.v[e] = from_f32<DT>(bb * cc + a * ss);
+        }
+        uint16_t* pk = rp.pool_k + dstrow * k_st + (int64_t)kvh * k_sh;
+        *reinterpret_cast<U16x8*>(pk + j) = o1;
+        *reinterpret_cast<U16x8*>(pk + D / 2 + j) = o2;
+      } else if (lane < D / 16 + D / 8) {
+        const int j = (lane - D / 16) * 8;
+        *reinterpret_cast<U16x8*>(rp.pool_v + dstrow * v_st + (int64_t)kvh * v_sh + j) =
+            *reinterpret_cast<const U16x8*>(vn + j);
+      }
+      asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row is in L2 before this wave gathers it
+    }
+    // rotate q in registers
+#pragma unroll
+    for (int s = 0; s < HS; ++s) {
+      const uint32_t* x1 = reinterpret_cast<const uint32_t*>(&qf[s]);
+      const uint32_t* x2 = reinterpret_cast<const uint32_t*>(&qf[s + HS]);
+      const uint32_t* cw = reinterpret_cast<const uint32_t*>(&cf[s]);
+      const uint32_t* sw = reinterpret_cast<const uint32_t*>(&sf[s]);
+      uint32_t r1[4], r2[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        uint16_t lo1, hi1, lo2, hi2;
+        {
+          const float a = to_f32<DT>((uint16_t)x1[w]), bb = to_f32<DT>((uint16_t)x2[w]);
+          const float cc = to_f32<DT>((uint16_t)cw[w]), ss = to_f32<DT>((uint16_t)sw[w]);
+          lo1 = from_f32<DT>(a * cc - bb * ss);
+          lo2 = from_f32<DT>(bb * cc + a * ss);
+        }
+        {
+          const float a = to_f32<DT>((uint16_t)(x1[w] >> 16)), bb = to_f32<DT>((uint16_t)(x2[w] >> 16));
+          const float cc = to_f32<DT>((uint16_t)(cw[w] >> 16)), ss = to_f32<DT>((uint16_t)(sw[w] >> 16));
+          hi1 = from_f32<DT>(a * cc - bb * ss);
+          hi2 = from_f32<DT>(bb * cc + a * ss);
+        }
+        r1[w] = (uint32_t)lo1 | ((uint32_t)hi1 << 16);
+        r2[w] = (uint32_t)lo2 | ((uint32_t)hi2 << 16);
+      }
+      qf[s] = Q4{r1[0], r1[1], r1[2], r1[3]};
+      qf[s + HS] = Q4{r2[0], r2[1], r2[2], r2[3]};
+    }
   }
 
   float m_i = -INFINITY, d_i = 0.f;
@@ -367,21 +455,25 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
                      const void* req, const void* seq, float* mid_o, float* mid_lse, int batch, int hq,
                      int hkv, int d, int64_t max_len, float scale, int64_t q_sb, int64_t q_sh,
                      int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_sh,
-                     int64_t t_sb, int req_w, int seq_w, int32_t* counters, hipStream_t st) {
+                     int64_t t_sb, int req_w, int seq_w, int32_t* counters, const FdRope* rope, hipStream_t st) {
   const int nparts = ll_flash_decoding_num_partitions(max_len);
   const int groups = hq / hkv;
   const int hgroups = (groups + 15) / 16;
   dim3 grid((unsigned)nparts, (unsigned)(hkv * hgroups), (unsigned)batch);
   // one launch when the caller lends a (zeroed, self-cleaning) counter vector and ``out`` takes 8-byte stores
   const bool fuse = counters != nullptr && (o_sb % 4 == 0) && (o_sh % 4 == 0) && ((uintptr_t)out % 8 == 0);
-#define LL_FD1(DD, FU)                                                                               \
-  fd_stage1<DT, DD, FU><<<grid, 64, 0, st>>>((const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, \
-                                             table, req, seq, mid_o, mid_lse, hq, hkv, nparts, scale, q_sb, \
-                                             q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w, (uint16_t*)out, \
-                                             o_sb, o_sh, counters)
-#define LL_FD1D(DD)          \
-  if (fuse) LL_FD1(DD, true); \
-  else LL_FD1(DD, false)
+  if (rope && (!fuse || hgroups != 1 || d < 64)) return LL_ERR_SHAPE;
+  const FdRope rp = rope ? *rope : FdRope{};
+#define LL_FD1(DD, FU, RO)                                                                           \
+  fd_stage1<DT, DD, FU, RO><<<grid, 64, 0, st>>>((const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, \
+                                                 table, req, seq, mid_o, mid_lse, hq, hkv, nparts, scale, q_sb, \
+                                                 q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w, (uint16_t*)out, \
+                                                 o_sb, o_sh, counters, rp)
+#define LL_FD1D(DD)                   \
+  if (rope) {                         \
+    if constexpr (DD >= 64) LL_FD1(DD, true, true); \
+  } else if (fuse) LL_FD1(DD, true, false);         \
+  else LL_FD1(DD, false, false)
   switch (d) {
     case 32: LL_FD1D(32); break;
     case 64: LL_FD1D(64); break;
@@ -397,14 +489,12 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
   return LL_LAUNCH_CHECK();
 }
 
-extern "C" int ll_flash_decoding(void* out, const void* q, const void* k_cache, const void* v_cache,
-                                 const int32_t* table, const void* b_req_idx, const void* b_seq_len,
-                                 float* mid_o, float* mid_lse, int batch, int hq, int hkv, int d,
-                                 int64_t max_len, float qk_scale, int64_t q_stride_b, int64_t q_stride_h,
-                                 int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t,
-                                 int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
-                                 int64_t table_stride_b, int dtype, int req_width, int seq_width,
-                                 int32_t* counters, void* stream) {
+static int fd_entry(void* out, const void* q, const void* k_cache, const void* v_cache, const int32_t* table,
+                    const void* b_req_idx, const void* b_seq_len, float* mid_o, float* mid_lse, int batch, int hq,
+                    int hkv, int d, int64_t max_len, float qk_scale, int64_t q_stride_b, int64_t q_stride_h,
+                    int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
+                    int64_t o_stride_b, int64_t o_stride_h, int64_t table_stride_b, int dtype, int req_width,
+                    int seq_width, int32_t* counters, const FdRope* rope, void* stream) {
   if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
   if ((req_width | seq_width) & ~1) return LL_ERR_DTYPE;
   if (batch < 0 || hq <= 0 || hkv <= 0 || hq % hkv != 0 || max_len < 0) return LL_ERR_SHAPE;
@@ -418,9 +508,48 @@ extern "C" int ll_flash_decoding(void* out, const void* q, const void* k_cache, 
     return launch_fd<LL_F16>(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch,
                              hq, hkv, d, max_len, qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h,
                              v_stride_t, v_stride_h, o_stride_b, o_stride_h, table_stride_b, req_width,
-                             seq_width, counters, st);
+                             seq_width, counters, rope, st);
   return launch_fd<LL_BF16>(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch, hq,
                             hkv, d, max_len, qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h,
                             v_stride_t, v_stride_h, o_stride_b, o_stride_h, table_stride_b, req_width,
-                            seq_width, counters, st);
+                            seq_width, counters, rope, st);
+}
+
+extern "C" int ll_flash_decoding(void* out, const void* q, const void* k_cache, const void* v_cache,
+                                 const int32_t* table, const void* b_req_idx, const void* b_seq_len,
+                                 float* mid_o, float* mid_lse, int batch, int hq, int hkv, int d,
+                                 int64_t max_len, float qk_scale, int64_t q_stride_b, int64_t q_stride_h,
+                                 int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t,
+                                 int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
+                                 int64_t table_stride_b, int dtype, int req_width, int seq_width,
+                                 int32_t* counters, void* stream) {
+  return fd_entry(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch, hq, hkv, d, max_len,
+                  qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_b,
+                  o_stride_h, table_stride_b, dtype, req_width, seq_width, counters, nullptr, stream);
+}
+
+// Decode-step attention in ONE launch: rope(q, k_new) + KV scatter of the new token + flash_decoding
+// (= ll_rope_kv_update with position-indexed tables, then ll_flash_decoding; same values).  q is
+// read un-rotated and NOT written back; kv_new rows are [2*hkv, d] (K heads first); the pool views
+// k_cache / v_cache are written at row select_index[b].  Requires: counters (see ll_flash_decoding),
+// d >= 64, hq/hkv <= 16, cos/sin of the q dtype, distinct select rows, and
+// table[b_req_idx[b], b_seq_len[b]-1] == select_index[b].
+extern "C" int ll_decode_attention(void* out, const void* q, const void* kv_new, int64_t kv_row_stride,
+                                   const void* cos_t, const void* sin_t, int64_t cs_row_stride,
+                                   const int64_t* positions, const void* select_index, int sel_width,
+                                   void* k_cache, void* v_cache, const int32_t* table, const void* b_req_idx,
+                                   const void* b_seq_len, float* mid_o, float* mid_lse, int batch, int hq, int hkv,
+                                   int d, int64_t max_len, float qk_scale, int64_t q_stride_b, int64_t q_stride_h,
+                                   int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
+                                   int64_t o_stride_b, int64_t o_stride_h, int64_t table_stride_b, int dtype,
+                                   int req_width, int seq_width, int32_t* counters, void* stream) {
+  if (!kv_new || !cos_t || !sin_t || !positions || !select_index || !counters) return LL_ERR_ARG;
+  if (sel_width != LL_I32 && sel_width != LL_I64) return LL_ERR_DTYPE;
+  if ((kv_row_stride | cs_row_stride) % 8 != 0 || !ll_aligned16(kv_new) || !ll_aligned16(cos_t) || !ll_aligned16(sin_t))
+    return LL_ERR_ARG;
+  const FdRope rp{(const uint16_t*)kv_new, kv_row_stride, (const uint16_t*)cos_t, (const uint16_t*)sin_t, cs_row_stride,
+                  positions, select_index, sel_width, (uint16_t*)k_cache, (uint16_t*)v_cache};
+  return fd_entry(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch, hq, hkv, d, max_len,
+                  qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_b,
+                  o_stride_h, table_stride_b, dtype, req_width, seq_width, counters, &rp, stream);
 }

@@ -78,6 +78,57 @@ def flash_decoding(
     return out
 
 
+def decode_attention_supported(q, kv, cos, n_kv_heads: int) -> bool:
+    """Shapes the one-launch decode attention serves: head_dim >= 64, at most 16 query heads per KV
+    head, dense [heads, head_dim] rows, 16-bit tables of the activation dtype."""
+    n, hq, hd = q.shape
+    return (hd >= 64 and hd % 32 == 0 and hq % n_kv_heads == 0 and hq // n_kv_heads <= 16 and q.stride(2) == 1
+            and q.stride(1) == hd and kv.stride(2) == 1 and kv.stride(1) == hd and cos.dtype == q.dtype
+            and q.dtype in (torch.float16, torch.bfloat16) and q.stride(0) % 8 == 0 and kv.stride(0) % 8 == 0)
+
+
+@torch.no_grad()
+def decode_attention(q, kv, cos_table, sin_table, positions, select_index, kv_buffer, qk_scale, b_req_tokens_table,
+                     b_req_idx, b_seq_len, max_actual_seq_len):
+    """Extension: ``rope_and_cache(q, kv, tables, positions)`` + ``flash_decoding(...)`` in ONE launch
+    (same values).  ``q [B, Hq, D]`` un-rotated (left untouched), ``kv [B, 2*Hkv, D]`` this step's K
+    heads then V heads (left untouched), ``kv_buffer [max_tokens, 2*Hkv, D]`` the layer's pool: row
+    ``select_index[b]`` receives the rotated K and the V.  Returns ``None`` when the shape is not
+    served or the merge counters cannot be set up (caller runs the two-call form)."""
+    L.require_cuda(q, kv, cos_table, sin_table, positions, select_index, kv_buffer, b_req_tokens_table, b_req_idx,
+                   b_seq_len)
+    batchs, num_heads, head_dim = q.shape
+    n_kv = kv.shape[1] // 2
+    if not decode_attention_supported(q, kv, cos_table, n_kv):
+        return None
+    counters = _merge_counters(q.device, batchs * n_kv)
+    positions = positions.reshape(-1)
+    if (counters is None or sin_table.dtype != cos_table.dtype or cos_table.dim() != 2 or cos_table.stride(1) != 1
+            or sin_table.stride(1) != 1 or cos_table.stride(0) != sin_table.stride(0) or cos_table.stride(0) % 8 != 0
+            or positions.dtype != torch.int64 or not positions.is_contiguous() or positions.shape[0] != batchs
+            or kv_buffer.stride(2) != 1 or b_req_tokens_table.dtype != torch.int32 or b_req_tokens_table.stride(1) != 1):
+        return None
+    k_cache, v_cache = kv_buffer[:, :n_kv], kv_buffer[:, n_kv:]
+    max_len = int(max_actual_seq_len)
+    nparts = L.lib().ll_flash_decoding_num_partitions(max_len)
+    mid_o = torch.empty((batchs, num_heads, max(nparts, 1), head_dim), dtype=torch.float32, device=q.device)
+    mid_lse = torch.empty((batchs, num_heads, max(nparts, 1), 32), dtype=torch.float32, device=q.device)
+    out = torch.empty((batchs, num_heads, head_dim), dtype=q.dtype, device=q.device)
+    L.check(
+        L.lib().ll_decode_attention(
+            out.data_ptr(), q.data_ptr(), kv.data_ptr(), kv.stride(0), cos_table.data_ptr(), sin_table.data_ptr(),
+            cos_table.stride(0), positions.data_ptr(), select_index.data_ptr(), L.index_width(select_index),
+            k_cache.data_ptr(), v_cache.data_ptr(), b_req_tokens_table.data_ptr(), b_req_idx.data_ptr(),
+            b_seq_len.data_ptr(), mid_o.data_ptr(), mid_lse.data_ptr(), batchs, num_heads, n_kv, head_dim, max_len,
+            float(qk_scale), q.stride(0), q.stride(1), k_cache.stride(0), k_cache.stride(1), v_cache.stride(0),
+            v_cache.stride(1), out.stride(0), out.stride(1), b_req_tokens_table.stride(0), L.dtype_code(q.dtype),
+            L.index_width(b_req_idx), L.index_width(b_seq_len), counters.data_ptr(), L.stream_ptr(),
+        ),
+        "decode_attention",
+    )
+    return out
+
+
 @torch.no_grad()
 def flash_attention2_no_pad(q, k, v, sm_scale, b_start_loc, b_seq_len, max_seq_len):
     """Varlen causal prefill attention (``sm_scale`` must already include log2(e); the

@@ -15,6 +15,7 @@ from the static table below and weights are synthetic (seeded).
 from __future__ import annotations
 
 import math
+import os
 from dataclasses import dataclass, field
 
 import torch
@@ -22,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .distributed.parallel_state import all_reduce_tp, divide, get_tp_rank, get_tp_world_size
+from .kernels.attention import decode_attention
 from .kernels.norm_act import rope_and_cache
 from .kernels import (
     flash_attention2_no_pad,
@@ -156,6 +158,10 @@ class RotaryEmbedding(nn.Module):
 # ------------------------------------------------------------------------------------- #
 # attention
 # ------------------------------------------------------------------------------------- #
+# A/B knob for measurements: keep rope + KV scatter and flash_decoding as two launches
+_TWO_CALL_ATTENTION = os.environ.get("LL_TWO_CALL_ATTENTION", "0") == "1"
+
+
 class PagedAttention(nn.Module):
     """KV scatter + phase kernel over the token-attention pool ``[max_tokens, 2*Hkv, D]``
     (K heads first, then V heads) -- base.py:50-142."""
@@ -225,8 +231,15 @@ class Attention(nn.Module):
         fused = not self.use_qk_norm and xkv.stride(1) == self.head_dim and xq.stride(1) == self.head_dim
         if tables is not None and not fused:
             position_embeddings = tables.materialise()
+        if fused and tables is not None and seq_len == 1 and not _TWO_CALL_ATTENTION:
+            # decode: rope + KV scatter + attention + partition merge in ONE launch
+            out = decode_attention(xq, xkv, tables[0], tables[1], tables[2], atten_info.cur_select_index,
+                                   atten_info.kv_buffer[layer_index], self.attn.scale, atten_info.b_req_tokens_table,
+                                   atten_info.b_req_idx, atten_info.b_seq_len, atten_info.max_actual_seq_len)
+            if out is not None:
+                return self.o_proj(out.view(batch, seq_len, self.q_size))
         if fused and tables is not None:
-            # decode: rope (position-indexed tables) + KV scatter in one launch, in place
+            # rope (position-indexed tables) + KV scatter in one launch, in place
             rope_and_cache(xq, xkv, tables[0], tables[1], batch, seq_len, atten_info.cur_select_index,
                            atten_info.kv_buffer[layer_index], positions=tables[2])
             out = self.attn(xq, xkv, atten_info, layer_index, is_prefill=seq_len > 1, cached=True)

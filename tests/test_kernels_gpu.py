@@ -306,6 +306,51 @@ def test_flash_decoding_one_launch_merge_equals_two_launch(monkeypatch):
     assert int(A._fd_counters[q.device].abs().sum()) == 0
 
 
+@pytest.mark.parametrize("hq,hkv,d,dtype", [(28, 4, 128, torch.float16), (8, 2, 64, torch.float16),
+                                              (32, 2, 128, torch.bfloat16), (4, 4, 256, torch.float16)])
+def test_decode_attention_one_launch_equals_rope_cache_then_flash_decoding(hq, hkv, d, dtype):
+    """rope + KV scatter + attention + merge in one launch == the two-call form, bit for bit: the
+    attention output AND the pool rows written; q / kv inputs are left untouched."""
+    from lite_llama_amd.kernels.attention import decode_attention
+    from lite_llama_amd.kernels.norm_act import rope_and_cache
+
+    torch.manual_seed(5)
+    lens = [1, 128, 129, 600, 333, 64, 2]
+    b = len(lens)
+    pool = torch.randn(_MAX_TOKENS + 64, 2 * hkv, d, device=DEV).to(dtype)
+    perm = torch.randperm(_MAX_TOKENS, device=DEV).to(torch.int32)
+    table = torch.zeros(b, max(lens), dtype=torch.int32, device=DEV)
+    off = 0
+    for i, n in enumerate(lens):
+        table[i, :n] = perm[off:off + n]
+        off += n
+    seq = torch.tensor(lens, dtype=torch.int64, device=DEV)
+    req = torch.arange(b, dtype=torch.int64, device=DEV)
+    sel = table[req, seq - 1].contiguous()
+    pos = (seq - 1).clone()
+    inv = 1.0 / (10000.0 ** (torch.arange(0, d, 2, device=DEV, dtype=torch.float32) / d))
+    fr = torch.arange(1024, device=DEV, dtype=torch.float32)[:, None] * inv[None, :]
+    emb = torch.cat([fr, fr], dim=-1)
+    cos, sin = emb.cos().to(dtype), emb.sin().to(dtype)
+    fusedproj = (torch.randn(b, (hq + 2 * hkv) * d, device=DEV) * 0.5).to(dtype)   # the merged q|k|v projection output
+    q = fusedproj[:, : hq * d].view(b, hq, d)
+    kv = fusedproj[:, hq * d:].view(b, 2 * hkv, d)
+    q0, kv0 = q.clone(), kv.clone()
+    pool_one = pool.clone()
+    out = decode_attention(q, kv, cos, sin, pos, sel, pool_one, 1.0 / d ** 0.5, table, req, seq, max(lens))
+    assert out is not None
+    assert torch.equal(q, q0) and torch.equal(kv, kv0)
+    # two-call form on copies (it rotates in place)
+    q2, kv2, pool_two = q0.clone(), kv0.clone(), pool.clone()
+    rope_and_cache(q2, kv2, cos, sin, b, 1, sel, pool_two, positions=pos)
+    ref = K().flash_decoding(q2, pool_two[:, :hkv], pool_two[:, hkv:], 1.0 / d ** 0.5, table, req, seq, max(lens))
+    assert torch.equal(pool_one, pool_two)
+    assert torch.equal(out.view(torch.int16), ref.view(torch.int16))
+    # shapes it does not serve are declined, not mis-served
+    assert decode_attention(q[:, :, :32].contiguous(), kv[:, :, :32].contiguous(), cos, sin, pos, sel,
+                            pool[:, :, :32].contiguous(), 0.2, table, req, seq, max(lens)) is None
+
+
 # ------------------------------------------------------------------------------------- #
 # w4a16 (tol 5e-2; nibble unpack bit-exact)
 # ------------------------------------------------------------------------------------- #
