@@ -17,6 +17,9 @@
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
 #define FD_PART 128  // tokens per partition (reference PARTITION_SIZE, flashdecoding.py:343)
+#ifndef FD_MERGE_PB4
+#define FD_MERGE_PB4 5
+#endif
 #define FD_LSE_PAD 32  // floats per log-sum-exp record in the one-launch form (one cache line each)
 
 struct alignas(16) Q4 {
@@ -66,7 +69,8 @@ struct FdRope {
 // log-sum-exp merge and writes ``out`` (no second launch: a kernel boundary costs ~4.7 us in the
 // decode graph, the merge itself ~1 us).  Partials are written through (sc1), a relaxed agent-scope
 // counter orders them, the merging wave reads them with coherent (sc1) loads and zeroes the counter.
-template <int DT, int D, bool FUSE, bool ROPE>
+// GS: upper bound (4, 8 or 16) of the query heads per KV head handled by this wave (merge layout).
+template <int DT, int D, bool FUSE, bool ROPE, int GS>
 __global__ __launch_bounds__(64) void fd_stage1(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     const int32_t* __restrict__ table, const void* __restrict__ b_req_idx,
@@ -118,11 +122,11 @@ __global__ __launch_bounds__(64) void fd_stage1(
       qf[s] = Q4{0, 0, 0, 0};
   }
 
+  constexpr int HS = ROPE ? NS / 2 : 1;
+  Q4 cf[HS], sf[HS];
   if constexpr (ROPE) {
     static_assert(!ROPE || NS >= 2, "the rotation partner must be another fragment of the same lane");
-    constexpr int HS = NS / 2;
     const int64_t crow = rp.positions[b] * rp.cs_rs;
-    Q4 cf[HS], sf[HS];
 #pragma unroll
     for (int s = 0; s < HS; ++s) {
       cf[s] = *reinterpret_cast<const Q4*>(rp.cos_t + crow + s * 32 + c * 8);
@@ -155,35 +159,6 @@ __global__ __launch_bounds__(64) void fd_stage1(
             *reinterpret_cast<const U16x8*>(vn + j);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the row is in L2 before this wave gathers it
-    }
-    // rotate q in registers
-#pragma unroll
-    for (int s = 0; s < HS; ++s) {
-      const uint32_t* x1 = reinterpret_cast<const uint32_t*>(&qf[s]);
-      const uint32_t* x2 = reinterpret_cast<const uint32_t*>(&qf[s + HS]);
-      const uint32_t* cw = reinterpret_cast<const uint32_t*>(&cf[s]);
-      const uint32_t* sw = reinterpret_cast<const uint32_t*>(&sf[s]);
-      uint32_t r1[4], r2[4];
-#pragma unroll
-      for (int w = 0; w < 4; ++w) {
-        uint16_t lo1, hi1, lo2, hi2;
-        {
-          const float a = to_f32<DT>((uint16_t)x1[w]), bb = to_f32<DT>((uint16_t)x2[w]);
-          const float cc = to_f32<DT>((uint16_t)cw[w]), ss = to_f32<DT>((uint16_t)sw[w]);
-          lo1 = from_f32<DT>(a * cc - bb * ss);
-          lo2 = from_f32<DT>(bb * cc + a * ss);
-        }
-        {
-          const float a = to_f32<DT>((uint16_t)(x1[w] >> 16)), bb = to_f32<DT>((uint16_t)(x2[w] >> 16));
-          const float cc = to_f32<DT>((uint16_t)(cw[w] >> 16)), ss = to_f32<DT>((uint16_t)(sw[w] >> 16));
-          hi1 = from_f32<DT>(a * cc - bb * ss);
-          hi2 = from_f32<DT>(bb * cc + a * ss);
-        }
-        r1[w] = (uint32_t)lo1 | ((uint32_t)hi1 << 16);
-        r2[w] = (uint32_t)lo2 | ((uint32_t)hi2 << 16);
-      }
-      qf[s] = Q4{r1[0], r1[1], r1[2], r1[3]};
-      qf[s + HS] = Q4{r2[0], r2[1], r2[2], r2[3]};
     }
   }
 
@@ -287,6 +262,37 @@ __global__ __launch_bounds__(64) void fd_stage1(
   Q4 kaA[NS], kbA[NS], vaA[NS], vbA[NS], kaB[NS], kbB[NS], vaB[NS], vbB[NS];
   FD_LOAD(A, 0)
   FD_LOAD(B, 1)
+  if constexpr (ROPE) {
+    // (after the first gathers are in flight: the rotation only has to precede the first S^T)
+#pragma unroll
+    for (int s = 0; s < HS; ++s) {
+      const uint32_t* x1 = reinterpret_cast<const uint32_t*>(&qf[s]);
+      const uint32_t* x2 = reinterpret_cast<const uint32_t*>(&qf[s + HS]);
+      const uint32_t* cw = reinterpret_cast<const uint32_t*>(&cf[s]);
+      const uint32_t* sw = reinterpret_cast<const uint32_t*>(&sf[s]);
+      uint32_t r1[4], r2[4];
+#pragma unroll
+      for (int w = 0; w < 4; ++w) {
+        uint16_t lo1, hi1, lo2, hi2;
+        {
+          const float a = to_f32<DT>((uint16_t)x1[w]), bb = to_f32<DT>((uint16_t)x2[w]);
+          const float cc = to_f32<DT>((uint16_t)cw[w]), ss = to_f32<DT>((uint16_t)sw[w]);
+          lo1 = from_f32<DT>(a * cc - bb * ss);
+          lo2 = from_f32<DT>(bb * cc + a * ss);
+        }
+        {
+          const float a = to_f32<DT>((uint16_t)(x1[w] >> 16)), bb = to_f32<DT>((uint16_t)(x2[w] >> 16));
+          const float cc = to_f32<DT>((uint16_t)(cw[w] >> 16)), ss = to_f32<DT>((uint16_t)(sw[w] >> 16));
+          hi1 = from_f32<DT>(a * cc - bb * ss);
+          hi2 = from_f32<DT>(bb * cc + a * ss);
+        }
+        r1[w] = (uint32_t)lo1 | ((uint32_t)hi1 << 16);
+        r2[w] = (uint32_t)lo2 | ((uint32_t)hi2 << 16);
+      }
+      qf[s] = Q4{r1[0], r1[1], r1[2], r1[3]};
+      qf[s + HS] = Q4{r2[0], r2[1], r2[2], r2[3]};
+    }
+    }
   FD_COMPUTE(A, 0)
   FD_LOAD(A, 2)
   if (start + 32 < end) FD_COMPUTE(B, 1)
@@ -336,10 +342,10 @@ __global__ __launch_bounds__(64) void fd_stage1(
       if (old != np - 1) return;
       if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
     }
-    if (!head_ok) return;
-    uint16_t* orow = out + b * o_sb + (int64_t)head * o_sh + 4 * c;
     if (np == 1) {
       // single partition: stage 2 computes (0*0 + 1*(o/d)) / (0*0 + 1) -- the same value
+      if (!head_ok) return;
+      uint16_t* orow = out + b * o_sb + (int64_t)head * o_sh + 4 * c;
       const float inv = 1.0f / d_i;
 #pragma unroll
       for (int dt = 0; dt < NT; ++dt) {
@@ -351,57 +357,77 @@ __global__ __launch_bounds__(64) void fd_stage1(
       }
       return;
     }
-    // merge the np partials of this head in partition order (same recurrence as fd_stage2), two
-    // partitions' loads in flight at a time
-    float mm = -INFINITY, dd = 0.f;
-    f32x4 acc[NT];
+    // Merge the np partials in partition order (the recurrence of fd_stage2, element by element).
+    // The work is re-dealt over ALL 64 lanes -- GS heads x D/4 float4 slots, NSL per lane -- instead
+    // of the MFMA layout's one head per 4 lanes (7 of 16 head columns busy at GQA 7): fewer
+    // registers per partition, so PB partitions' loads are in flight at once and a context of up
+    // to PB x 128 tokens merges in ONE memory round trip (these are coherent loads from memory).
+    constexpr int D4 = D / 4;
+    constexpr int NSL = (GS * D4 + 63) / 64;
+    constexpr int PB = NSL <= 2 ? 8 : (NSL <= 4 ? FD_MERGE_PB4 : (NSL <= 8 ? 2 : 1));
+    const int nvalid = groups - hg * 16 < 16 ? groups - hg * 16 : 16;
+    float mm[NSL], dd[NSL];
+    f32x4 acc[NSL];
+    int mo_off[NSL];  // float offsets of the slot's record of partition 0 (mid_o / mid_lse) and of its output
+    int ml_off[NSL];
+    int out_off[NSL];
+    bool ok_s[NSL];
+    const int64_t hr0 = ((int64_t)b * hq + kvh * groups + hg * 16) * nparts;  // first head of the group
+    const float* mo_g = mid_o + hr0 * D;
+    const float* ml_g = mid_lse + hr0 * FD_LSE_PAD;
+    uint16_t* out_g = out + b * o_sb + (int64_t)(kvh * groups + hg * 16) * o_sh;
 #pragma unroll
-    for (int dt = 0; dt < NT; ++dt) acc[dt] = f32x4{0.f, 0.f, 0.f, 0.f};
-    const float* mo0 = mid_o + hrow * D + 4 * c;
-    const float* ml0 = mid_lse + hrow * FD_LSE_PAD;
-    for (int p0 = 0; p0 < np; p0 += 2) {
-      const bool two = p0 + 1 < np;
-      const int p1 = two ? p0 + 1 : p0;
-      f32x4 va[NT], vb[NT];
-      float la, lb;
-      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(la) : "v"(ml0 + (int64_t)p0 * FD_LSE_PAD) : "memory");
-      asm volatile("global_load_dword %0, %1, off sc1" : "=v"(lb) : "v"(ml0 + (int64_t)p1 * FD_LSE_PAD) : "memory");
+    for (int j = 0; j < NSL; ++j) {
+      const int sidx = lane + 64 * j;
+      const int hl_s = sidx / D4, d4 = sidx % D4;
+      ok_s[j] = hl_s < nvalid;
+      const int hs = ok_s[j] ? hl_s : 0;
+      mo_off[j] = hs * nparts * D + d4 * 4;
+      ml_off[j] = hs * nparts * FD_LSE_PAD;
+      out_off[j] = (int)(hs * o_sh) + d4 * 4;
+      mm[j] = -INFINITY;
+      dd[j] = 0.f;
+      acc[j] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+    for (int p0 = 0; p0 < np; p0 += PB) {
+      f32x4 v[PB][NSL];
+      float l[PB][NSL];
 #pragma unroll
-      for (int dt = 0; dt < NT; ++dt) {
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(va[dt]) : "v"(mo0 + (int64_t)p0 * D + dt * 16) : "memory");
-        asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(vb[dt]) : "v"(mo0 + (int64_t)p1 * D + dt * 16) : "memory");
+      for (int u = 0; u < PB; ++u) {
+        const int pp = p0 + u < np ? p0 + u : np - 1;  // clamped; masked below
+#pragma unroll
+        for (int j = 0; j < NSL; ++j) {
+          asm volatile("global_load_dword %0, %1, off sc1" : "=v"(l[u][j]) : "v"(ml_g + (ml_off[j] + pp * FD_LSE_PAD)) : "memory");
+          asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(v[u][j]) : "v"(mo_g + (mo_off[j] + pp * D)) : "memory");
+        }
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-      asm volatile("" : "+v"(la), "+v"(lb));
 #pragma unroll
-      for (int dt = 0; dt < NT; ++dt) asm volatile("" : "+v"(va[dt]), "+v"(vb[dt]));  // uses stay below the wait
-      {
-        const float m_new = fmaxf(mm, la);
-        const float alpha = expf(mm - m_new), w = expf(la - m_new);
+      for (int u = 0; u < PB; ++u)
 #pragma unroll
-        for (int dt = 0; dt < NT; ++dt)
+        for (int j = 0; j < NSL; ++j) asm volatile("" : "+v"(l[u][j]), "+v"(v[u][j]));  // uses stay below the wait
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[dt][e] = acc[dt][e] * alpha + w * va[dt][e];
-        dd = dd * alpha + w;
-        mm = m_new;
-      }
-      if (two) {
-        const float m_new = fmaxf(mm, lb);
-        const float alpha = expf(mm - m_new), w = expf(lb - m_new);
+      for (int u = 0; u < PB; ++u) {
+        const bool live = p0 + u < np;  // wave-uniform
 #pragma unroll
-        for (int dt = 0; dt < NT; ++dt)
+        for (int j = 0; j < NSL; ++j) {
+          const float m_new = fmaxf(mm[j], l[u][j]);
+          const float alpha = expf(mm[j] - m_new), w = expf(l[u][j] - m_new);
 #pragma unroll
-          for (int e = 0; e < 4; ++e) acc[dt][e] = acc[dt][e] * alpha + w * vb[dt][e];
-        dd = dd * alpha + w;
-        mm = m_new;
+          for (int e = 0; e < 4; ++e) acc[j][e] = live ? acc[j][e] * alpha + w * v[u][j][e] : acc[j][e];
+          dd[j] = live ? dd[j] * alpha + w : dd[j];
+          mm[j] = live ? m_new : mm[j];
+          __builtin_amdgcn_sched_barrier(0);  // one slot's exp chain at a time: bounded temporaries
+        }
       }
     }
 #pragma unroll
-    for (int dt = 0; dt < NT; ++dt) {
+    for (int j = 0; j < NSL; ++j) {
+      if (!ok_s[j]) continue;
       uint16_t o4[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o4[e] = from_f32<DT>(acc[dt][e] / dd);
-      *reinterpret_cast<uint2*>(orow + dt * 16) =
+      for (int e = 0; e < 4; ++e) o4[e] = from_f32<DT>(acc[j][e] / dd[j]);
+      *reinterpret_cast<uint2*>(out_g + out_off[j]) =
           uint2{(uint32_t)o4[0] | ((uint32_t)o4[1] << 16), (uint32_t)o4[2] | ((uint32_t)o4[3] << 16)};
     }
   }
@@ -464,16 +490,20 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
   const bool fuse = counters != nullptr && (o_sb % 4 == 0) && (o_sh % 4 == 0) && ((uintptr_t)out % 8 == 0);
   if (rope && (!fuse || hgroups != 1 || d < 64)) return LL_ERR_SHAPE;
   const FdRope rp = rope ? *rope : FdRope{};
-#define LL_FD1(DD, FU, RO)                                                                           \
-  fd_stage1<DT, DD, FU, RO><<<grid, 64, 0, st>>>((const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, \
-                                                 table, req, seq, mid_o, mid_lse, hq, hkv, nparts, scale, q_sb, \
-                                                 q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w, (uint16_t*)out, \
-                                                 o_sb, o_sh, counters, rp)
+#define LL_FD1(DD, FU, RO, GG)                                                                       \
+  fd_stage1<DT, DD, FU, RO, GG><<<grid, 64, 0, st>>>((const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, \
+                                                     table, req, seq, mid_o, mid_lse, hq, hkv, nparts, scale, q_sb, \
+                                                     q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w, (uint16_t*)out, \
+                                                     o_sb, o_sh, counters, rp)
+#define LL_FD1G(DD, RO)                      \
+  if (groups <= 4) LL_FD1(DD, true, RO, 4);  \
+  else if (groups <= 8) LL_FD1(DD, true, RO, 8); \
+  else LL_FD1(DD, true, RO, 16)
 #define LL_FD1D(DD)                   \
   if (rope) {                         \
-    if constexpr (DD >= 64) LL_FD1(DD, true, true); \
-  } else if (fuse) LL_FD1(DD, true, false);         \
-  else LL_FD1(DD, false, false)
+    if constexpr (DD >= 64) { LL_FD1G(DD, true); } \
+  } else if (fuse) { LL_FD1G(DD, false); }         \
+  else LL_FD1(DD, false, false, 16)
   switch (d) {
     case 32: LL_FD1D(32); break;
     case 64: LL_FD1D(64); break;
@@ -482,6 +512,7 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
     default: return LL_ERR_SHAPE;
   }
 #undef LL_FD1D
+#undef LL_FD1G
 #undef LL_FD1
   if (!fuse)
     fd_stage2<DT><<<dim3((unsigned)hq, (unsigned)batch), d, 0, st>>>((uint16_t*)out, mid_o, mid_lse, seq, hq, d,
