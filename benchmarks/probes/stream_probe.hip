@@ -62,12 +62,53 @@ __global__ __launch_bounds__(256) void pat_c(const unsigned char* w, int rows, i
   }
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
 }
+// F: 8 lanes per row (one full 128-B cache line per row per instruction), 128 rows per WG-tile
+template <bool NT>
+__global__ __launch_bounds__(256) void pat_f(const unsigned char* w, int rows, int rowbytes, int* out) {
+  const int t = threadIdx.x;
+  const int nb = blockIdx.x / 4, split = blockIdx.x % 4;
+  const int units = rowbytes / 128, per = units / 4;   // 128-B units (two of the kernel's 64-B chunks)
+  i32x4 acc = {0, 0, 0, 0};
+  for (int u = split * per; u < (split + 1) * per; ++u) {
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {   // 4 instr x 32 rows = 128 rows
+      const int r = nb * 128 + i * 32 + (t >> 3);
+      const unsigned char* p = w + (size_t)r * rowbytes + u * 128 + (t & 7) * 16;
+      i32x4 a = NT ? __builtin_nontemporal_load((const i32x4*)p) : *(const i32x4*)p;
+      acc ^= a;
+    }
+  }
+  if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+}
 // D: plain linear streaming of the whole buffer (upper bound)
 __global__ __launch_bounds__(256) void pat_d(const unsigned char* w, size_t bytes, int* out) {
   i32x4 acc = {0, 0, 0, 0};
   for (size_t i = ((size_t)blockIdx.x * 256 + threadIdx.x) * 16; i < bytes; i += (size_t)gridDim.x * 256 * 16)
     acc ^= __builtin_nontemporal_load((const i32x4*)(w + i));
   if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+}
+
+// E: linear streaming with LDS-direct loads (global_load_lds_dwordx4: no VGPR destination, data lands
+// in LDS at M0-base + lane * 16).  Question: is the ~5 TB/s ceiling of plain loads (the per-CU
+// outstanding-miss budget) also the ceiling of the LDS-direct path?  QD = loads queued per wave
+// before the next batch (the wave never reads the data; the last batch is waited for at the end).
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+template <int QD>
+__global__ __launch_bounds__(256) void pat_e(const unsigned char* w, size_t bytes, int* out) {
+  extern __shared__ unsigned char lds_e[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned char* myl = lds_e + wv * (QD * 1024);
+  const size_t chunk = (size_t)QD * 1024;
+  const size_t stride = (size_t)gridDim.x * 4 * chunk;
+  for (size_t base = ((size_t)blockIdx.x * 4 + wv) * chunk; base + chunk <= bytes; base += stride) {
+#pragma unroll
+    for (int j = 0; j < QD; ++j)
+      __builtin_amdgcn_global_load_lds((glb_void*)(w + base + j * 1024 + lane * 16), (lds_void*)(myl + j * 1024), 16, 0, 0);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  __syncthreads();
+  if (lds_e[threadIdx.x] == 0x7f) out[0] = 1;
 }
 
 int main() {
@@ -95,6 +136,14 @@ int main() {
   run("B 4 lanes/row 64B", [&](unsigned char* p) { pat_b<false><<<grid, 256>>>(p, rows, rowbytes, out); });
   run("C 16 lanes/row 256B nt", [&](unsigned char* p) { pat_c<true><<<grid, 256>>>(p, rows, rowbytes, out); });
   run("C 16 lanes/row 256B", [&](unsigned char* p) { pat_c<false><<<grid, 256>>>(p, rows, rowbytes, out); });
+  run("F 8 lanes/row 128B nt", [&](unsigned char* p) { pat_f<true><<<grid, 256>>>(p, rows, rowbytes, out); });
+  run("F 8 lanes/row 128B", [&](unsigned char* p) { pat_f<false><<<grid, 256>>>(p, rows, rowbytes, out); });
   run("D linear nt 2048 WGs", [&](unsigned char* p) { pat_d<<<2048, 256>>>(p, bytes, out); });
+  run("D linear nt 512 WGs", [&](unsigned char* p) { pat_d<<<512, 256>>>(p, bytes, out); });
+  hipFuncSetAttribute((const void*)pat_e<16>, hipFuncAttributeMaxDynamicSharedMemorySize, 65536);
+  hipFuncSetAttribute((const void*)pat_e<8>, hipFuncAttributeMaxDynamicSharedMemorySize, 32768);
+  run("E lds-direct QD16 512 WGs", [&](unsigned char* p) { pat_e<16><<<512, 256, 65536>>>(p, bytes, out); });
+  run("E lds-direct QD16 256 WGs", [&](unsigned char* p) { pat_e<16><<<256, 256, 65536>>>(p, bytes, out); });
+  run("E lds-direct QD8 1024 WGs", [&](unsigned char* p) { pat_e<8><<<1024, 256, 32768>>>(p, bytes, out); });
   return 0;
 }

@@ -60,7 +60,26 @@ struct V2Params {
   int gshift;  // log2(group_size / 128) when a power of two, else -1
   int gdiv;    // group_size / 128
   int epi;     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu (ll_w4a16_gateup_swiglu)
+#ifdef V2_TIMELINE
+  unsigned long long* timeline;  // debug: [workgroup][role 3][V2_TLN] s_memrealtime stamps (benchmarks/gemm_timeline.py)
+#endif
 };
+
+// debug timeline (-DV2_TIMELINE): role 0 consumer wave 0, 1 loader wave 8, 2 producer wave 10;
+// slot 0 kernel entry, 1 prologue barrier passed, then per unit v < V2_TLU: 2+3v data ready (loader:
+// after the LDS store, i.e. after the wait for the loaded data), 3+3v arrived at the unit barrier,
+// 4+3v left it; last slot: role done
+#define V2_TLU 40
+#define V2_TLN (3 + 3 * V2_TLU)
+#ifdef V2_TIMELINE
+#define V2_TL(ROLE, IDX)                                                                                       \
+  if (p.timeline && lane == 0)                                                                                 \
+    p.timeline[((size_t)blockIdx.x * 3 + (ROLE)) * V2_TLN + (IDX)] = __builtin_amdgcn_s_memrealtime();
+#define V2_TLV(ROLE, V, K) if ((V) < V2_TLU) V2_TL(ROLE, 2 + 3 * (V) + (K))
+#else
+#define V2_TL(ROLE, IDX)
+#define V2_TLV(ROLE, V, K)
+#endif
 
 __device__ __forceinline__ uint32_t v2_pk_add(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) + __builtin_bit_cast(f16x2, b));
@@ -138,6 +157,9 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   }
   if (ub >= ue) return;
   const int cnt = ue - ub;
+  if (wv == 0) { V2_TL(0, 0) }
+  if (wv == 8) { V2_TL(1, 0) }
+  if (wv == 10) { V2_TL(2, 0) }
   const int tA = ub / chunks, cA = ub - tA * chunks;
   const int tZ = (ue - 1) / chunks, cZ = (ue - 1) - tZ * chunks;
   int LT = 0, LH = cnt;  // a range inside one tile runs as a single "head" segment
@@ -242,15 +264,19 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     V2_LOAD_X(xa)  // unit 3
     V2_LOAD_X(xb)  // unit 4
     __syncthreads();
+    if (wv == 10) { V2_TL(2, 1) }
     int wbuf = 2;
     int cv = 0;  // the unit the consumers are on (barrier schedule)
 #define V2_PRODUCER_STEP(P)                                                   \
   {                                                                           \
     const int fl_ = __builtin_amdgcn_readfirstlane(tab[cv].w);                \
     V2_STORE_X(P, wbuf) /* unit v + 2 */                                      \
+    if (wv == 10) { V2_TLV(2, cv, 0) }                                        \
     V2_LOAD_X(P)        /* unit v + 5 */                                      \
     wbuf = wbuf == V2_XR - 1 ? 0 : wbuf + 1;                                  \
+    if (wv == 10) { V2_TLV(2, cv, 1) }                                        \
     __syncthreads();                                                          \
+    if (wv == 10) { V2_TLV(2, cv, 2) }                                        \
     if (fl_ & 1) __syncthreads(); /* the consumers' k-half reduction */       \
     ++cv;                                                                     \
   }
@@ -344,15 +370,19 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     V2_STORE_W(t0, 0)
     V2_STORE_W(t1, 1)
     __syncthreads();
+    if (wv == 8) { V2_TL(1, 1) }
     int wslot = V2_D % V2_RW;
     int cv = 0;
 #define V2_LOADER_STEP(P)                                                     \
   {                                                                           \
     const int fl_ = __builtin_amdgcn_readfirstlane(tab[cv].w);                \
     V2_STORE_W(P, wslot) /* unit v + D */                                     \
+    if (wv == 8) { V2_TLV(1, cv, 0) }                                         \
     V2_LOAD_W(P)         /* unit v + D + PF */                                \
     wslot = wslot == V2_RW - 1 ? 0 : wslot + 1;                               \
+    if (wv == 8) { V2_TLV(1, cv, 1) }                                         \
     __syncthreads();                                                          \
+    if (wv == 8) { V2_TLV(1, cv, 2) }                                         \
     if (fl_ & 1) __syncthreads();                                             \
     ++cv;                                                                     \
   }
@@ -501,6 +531,7 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   int seg_lo = (fl >> 1) & 0xFFF;
   int rbuf = 0, wslot = 0;
   __syncthreads();  // prologue barrier: units 0, 1 staged
+  if (wv == 0) { V2_TL(0, 1) }
   // ALL operands of a unit are fetched ONE UNIT AHEAD, across the barrier (a unit is staged in LDS
   // two steps before it is consumed, so unit v+1 is already there while unit v is multiplied).
   // The consumers are the critical role (they wait at the barrier 20 % of the time, the loaders
@@ -569,7 +600,9 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     // bare s_barrier: __syncthreads() would first drain lgkmcnt(0), i.e. wait for the prefetched
     // reads of the next unit; the consumers have no LDS stores of their own to publish here, and the
     // slots they are reading are not rewritten before two more barriers
+    if (wv == 0) { V2_TLV(0, cv, 1) }
     __builtin_amdgcn_s_barrier();
+    if (wv == 0) { V2_TLV(0, cv, 2) }
     if (pend_ctr) post_pending();  // the previous segment's slab stores are a unit old by now
     const bool se = fl & 1;
     if (se) {
@@ -608,6 +641,7 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       for (int mt = 0; mt < MT; ++mt) af[s][mt] = an[s][mt];
   }
   if (pend_ctr) post_pending();
+  if (wv == 0) { V2_TL(0, V2_TLN - 1) }
 }
 
 // ---------------------------------------------------------------------------------- //
@@ -740,6 +774,9 @@ extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweig
   p.nblocks = pl.nblocks; p.chunks = pl.chunks; p.total_units = pl.total_units; p.upw = pl.upw; p.slots = pl.slots;
   p.gt = pl.gt; p.gbase = pl.gbase; p.grem = pl.grem; p.glead = pl.glead;
   p.epi = epilogue;
+#ifdef V2_TIMELINE
+  p.timeline = getenv("LL_GEMM_TIMELINE") ? (unsigned long long*)strtoull(getenv("LL_GEMM_TIMELINE"), nullptr, 16) : nullptr;
+#endif
   p.gdiv = group_size / 128;
   p.gshift = -1;
   if ((p.gdiv & (p.gdiv - 1)) == 0) {
