@@ -70,7 +70,7 @@ struct V2Params {
 // after the LDS store, i.e. after the wait for the loaded data), 3+3v arrived at the unit barrier,
 // 4+3v left it; last slot: role done
 #define V2_TLU 40
-#define V2_TLN (3 + 3 * V2_TLU)
+#define V2_TLN (6 + 3 * V2_TLU)  // + 3 prologue stamps per role: table built, loads issued, first data stored
 #ifdef V2_TIMELINE
 #define V2_TL(ROLE, IDX)                                                                                       \
   if (p.timeline && lane == 0)                                                                                 \
@@ -202,6 +202,9 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     tab[v] = e;
   }
   __syncthreads();
+  if (wv == 0) { V2_TL(0, 3 + 3 * V2_TLU) }
+  if (wv == 8) { V2_TL(1, 3 + 3 * V2_TLU) }
+  if (wv == 10) { V2_TL(2, 3 + 3 * V2_TLU) }
   const int last = cnt - 1;
 #define V2_ENTRY(V) tab[(V) < last ? (V) : last]  // sticks on the last unit past the end
 
@@ -259,8 +262,10 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     V2_LOAD_X(xa)  // unit 0
     V2_LOAD_X(xb)  // unit 1
     V2_LOAD_X(xc)  // unit 2
+    if (wv == 10) { V2_TL(2, 4 + 3 * V2_TLU) }
     V2_STORE_X(xa, 0)
     V2_STORE_X(xb, 1)
+    if (wv == 10) { V2_TL(2, 5 + 3 * V2_TLU) }
     V2_LOAD_X(xa)  // unit 3
     V2_LOAD_X(xb)  // unit 4
     __syncthreads();
@@ -367,8 +372,10 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     V2_LOAD_W(w3)
     V2_LOAD_W(w4)
     V2_LOAD_W(w5)
+    if (wv == 8) { V2_TL(1, 4 + 3 * V2_TLU) }
     V2_STORE_W(t0, 0)
     V2_STORE_W(t1, 1)
+    if (wv == 8) { V2_TL(1, 5 + 3 * V2_TLU) }
     __syncthreads();
     if (wv == 8) { V2_TL(1, 1) }
     int wslot = V2_D % V2_RW;
@@ -641,7 +648,7 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       for (int mt = 0; mt < MT; ++mt) af[s][mt] = an[s][mt];
   }
   if (pend_ctr) post_pending();
-  if (wv == 0) { V2_TL(0, V2_TLN - 1) }
+  if (wv == 0) { V2_TL(0, 2 + 3 * V2_TLU) }
 }
 
 // ---------------------------------------------------------------------------------- //
