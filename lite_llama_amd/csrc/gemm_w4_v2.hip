@@ -61,6 +61,7 @@ struct V2Params {
   int gdiv;    // group_size / 128
   int epi;     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu (ll_w4a16_gateup_swiglu)
 #ifdef V2_TIMELINE
+  int tlwave;                    // debug: which consumer wave (0..7) writes the role-0 stamps
   unsigned long long* timeline;  // debug: [workgroup][role 3][V2_TLN] s_memrealtime stamps (benchmarks/gemm_timeline.py)
 #endif
 };
@@ -76,9 +77,11 @@ struct V2Params {
   if (p.timeline && lane == 0)                                                                                 \
     p.timeline[((size_t)blockIdx.x * 3 + (ROLE)) * V2_TLN + (IDX)] = __builtin_amdgcn_s_memrealtime();
 #define V2_TLV(ROLE, V, K) if ((V) < V2_TLU) V2_TL(ROLE, 2 + 3 * (V) + (K))
+#define V2_TLW (wv == p.tlwave)  // the consumer wave that writes the role-0 stamps (LL_GEMM_TL_WAVE)
 #else
 #define V2_TL(ROLE, IDX)
 #define V2_TLV(ROLE, V, K)
+#define V2_TLW false
 #endif
 
 __device__ __forceinline__ uint32_t v2_pk_add(uint32_t a, uint32_t b) {
@@ -157,7 +160,7 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   }
   if (ub >= ue) return;
   const int cnt = ue - ub;
-  if (wv == 0) { V2_TL(0, 0) }
+  if (V2_TLW) { V2_TL(0, 0) }
   if (wv == 8) { V2_TL(1, 0) }
   if (wv == 10) { V2_TL(2, 0) }
   const int tA = ub / chunks, cA = ub - tA * chunks;
@@ -202,7 +205,7 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     tab[v] = e;
   }
   __syncthreads();
-  if (wv == 0) { V2_TL(0, 3 + 3 * V2_TLU) }
+  if (V2_TLW) { V2_TL(0, 3 + 3 * V2_TLU) }
   if (wv == 8) { V2_TL(1, 3 + 3 * V2_TLU) }
   if (wv == 10) { V2_TL(2, 3 + 3 * V2_TLU) }
   const int last = cnt - 1;
@@ -538,7 +541,7 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   int seg_lo = (fl >> 1) & 0xFFF;
   int rbuf = 0, wslot = 0;
   __syncthreads();  // prologue barrier: units 0, 1 staged
-  if (wv == 0) { V2_TL(0, 1) }
+  if (V2_TLW) { V2_TL(0, 1) }
   // ALL operands of a unit are fetched ONE UNIT AHEAD, across the barrier (a unit is staged in LDS
   // two steps before it is consumed, so unit v+1 is already there while unit v is multiplied).
   // The consumers are the critical role (they wait at the barrier 20 % of the time, the loaders
@@ -607,9 +610,9 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     // bare s_barrier: __syncthreads() would first drain lgkmcnt(0), i.e. wait for the prefetched
     // reads of the next unit; the consumers have no LDS stores of their own to publish here, and the
     // slots they are reading are not rewritten before two more barriers
-    if (wv == 0) { V2_TLV(0, cv, 1) }
+    if (V2_TLW) { V2_TLV(0, cv, 1) }
     __builtin_amdgcn_s_barrier();
-    if (wv == 0) { V2_TLV(0, cv, 2) }
+    if (V2_TLW) { V2_TLV(0, cv, 2) }
     if (pend_ctr) post_pending();  // the previous segment's slab stores are a unit old by now
     const bool se = fl & 1;
     if (se) {
@@ -648,7 +651,7 @@ __global__ __launch_bounds__(V2_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       for (int mt = 0; mt < MT; ++mt) af[s][mt] = an[s][mt];
   }
   if (pend_ctr) post_pending();
-  if (wv == 0) { V2_TL(0, 2 + 3 * V2_TLU) }
+  if (V2_TLW) { V2_TL(0, 2 + 3 * V2_TLU) }
 }
 
 // ---------------------------------------------------------------------------------- //
@@ -782,6 +785,7 @@ extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweig
   p.gt = pl.gt; p.gbase = pl.gbase; p.grem = pl.grem; p.glead = pl.glead;
   p.epi = epilogue;
 #ifdef V2_TIMELINE
+  p.tlwave = getenv("LL_GEMM_TL_WAVE") ? atoi(getenv("LL_GEMM_TL_WAVE")) : 0;
   p.timeline = getenv("LL_GEMM_TIMELINE") ? (unsigned long long*)strtoull(getenv("LL_GEMM_TIMELINE"), nullptr, 16) : nullptr;
 #endif
   p.gdiv = group_size / 128;
