@@ -54,8 +54,17 @@ def parse():
 def algorithmic_bytes(geo, quant, batch, ctx, tp):
     """weight bytes (reference storage format) + fp16 lm_head + K/V bytes, per step, per rank."""
     per_w = {"int4": 0.5 + 8.0 / 128, "int8": 1.0, "smoothquant": 1.0, "fp8": 1.0, "none": 2.0}[quant]
-    lin = geo.num_layers * (geo.hidden_size * geo.q_size * 2 + geo.hidden_size * 2 * geo.kv_size +
-                            3 * geo.hidden_size * geo.intermediate_size)
+    attn = geo.hidden_size * geo.q_size * 2 + geo.hidden_size * 2 * geo.kv_size
+    if geo.num_experts:
+        # routed experts: only the experts hit by the batch are read (in expectation, uniform routing:
+        # n_e = E (1 - (1 - 1/E)^(top_k * batch))), plus the fp16 router -- SURVEY 8(d) config 5
+        e, k = geo.num_experts, geo.num_experts_per_tok
+        n_e = e * (1.0 - (1.0 - 1.0 / e) ** (k * batch))
+        mlp = n_e * 3 * geo.hidden_size * geo.moe_intermediate_size
+        router = e * geo.hidden_size * 2 / per_w  # fp16, replicated (divided back below)
+        lin = geo.num_layers * (attn + mlp + router)
+    else:
+        lin = geo.num_layers * (attn + 3 * geo.hidden_size * geo.intermediate_size)
     w_lin = lin * per_w / tp
     w_head = geo.vocab_size * geo.hidden_size * 2
     kv_tok = geo.num_layers * 2 * geo.kv_size * 2 / tp
@@ -260,7 +269,10 @@ def main():
         else f"decode tokens/s ({args.model} {args.quant}, batch {args.batch})",
         "value": round(tokens / elapsed, 1), "unit": "tokens/s", "n_gpus": world, "steps": args.steps,
         "warmup": args.warmup, "ms_per_step": round(ms_per_step, 4), "higher_is_better": True,
-        "scaling": "strong" if dp == 1 else "weak", "vs_baseline": None, "dtype": "f16 (int4 weights, fp32 accumulate)",
+        "scaling": "strong" if dp == 1 else "weak", "vs_baseline": None,
+        "dtype": {"int4": "f16 (int4 weights, fp32 accumulate)", "int8": "f16 (int8 weights, fp32 accumulate)",
+                  "fp8": "f16 (fp8-e4m3 weights, fp32 accumulate)", "smoothquant": "int8 (int32 accumulate, f16 epilogue)",
+                  "none": "f16 (fp32 accumulate)"}[args.quant],
         "data": "synthetic",
         "config": {"workload": f"{args.model} {args.quant} decode, batch {args.batch}/replica, ctx {args.ctx}->"
                                f"{args.ctx + total}, {graph_note}", "global_batch": global_batch,

@@ -28,16 +28,21 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const void* __restrict_
                                                          int32_t* __restrict__ sorted_ids,
                                                          int32_t* __restrict__ expert_ids,
                                                          int32_t* __restrict__ num_post, int max_padded,
-                                                         int max_blocks) {
+                                                         int max_blocks, int stage_ids) {
   extern __shared__ int sm[];  // counts[E], starts[E], block_ends[E]
   int* counts = sm;
   int* starts = sm + num_experts;
   int* bends = sm + 2 * num_experts;
+  int* ids_lds = stage_ids ? sm + 3 * num_experts : nullptr;
   const int tid = threadIdx.x;
   for (int i = tid; i < max_padded; i += 1024) sorted_ids[i] = num_slots;  // sentinel
   for (int e = tid; e < num_experts; e += 1024) counts[e] = 0;
   __syncthreads();
-  for (int i = tid; i < num_slots; i += 1024) atomicAdd(&counts[(int)moe_load_idx(topk_ids, i, ids_w)], 1);
+  for (int i = tid; i < num_slots; i += 1024) {
+    const int e = (int)moe_load_idx(topk_ids, i, ids_w);
+    if (ids_lds) ids_lds[i] = e;
+    atomicAdd(&counts[e], 1);
+  }
   __syncthreads();
   if (tid == 0) {
     int pos = 0, blk = 0;
@@ -51,12 +56,25 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const void* __restrict_
     num_post[0] = pos;
   }
   __syncthreads();
-  // stable placement: expert e walks the slots in order (keeps token order inside each expert)
-  for (int e = tid; e < num_experts; e += 1024) {
-    if (counts[e] == 0) continue;
-    int dst = starts[e];
-    for (int i = 0; i < num_slots; ++i)
-      if ((int)moe_load_idx(topk_ids, i, ids_w) == e) sorted_ids[dst++] = i;
+  // stable placement (token order kept inside each expert)
+  if (ids_lds) {
+    // decode-sized batches: the ids sit in LDS and every SLOT finds its rank among the earlier slots of
+    // the same expert (all lanes read the same word per step: an LDS broadcast) -- num_slots short
+    // iterations instead of one thread per expert walking global memory (57 us -> a few us at 512 slots)
+    for (int i = tid; i < num_slots; i += 1024) {
+      const int e = ids_lds[i];
+      int rank = 0;
+      for (int j = 0; j < i; ++j) rank += ids_lds[j] == e;
+      sorted_ids[starts[e] + rank] = i;
+    }
+  } else {
+    // any size: expert e walks the slots in order
+    for (int e = tid; e < num_experts; e += 1024) {
+      if (counts[e] == 0) continue;
+      int dst = starts[e];
+      for (int i = 0; i < num_slots; ++i)
+        if ((int)moe_load_idx(topk_ids, i, ids_w) == e) sorted_ids[dst++] = i;
+    }
   }
   // expert_ids[b] = searchsorted(block_ends, b, right=True) clamped to E-1
   for (int b = tid; b < max_blocks; b += 1024) {
@@ -76,9 +94,10 @@ extern "C" int ll_moe_align_block_size(const void* topk_ids, int ids_width, int6
   if (num_slots < 0 || num_experts <= 0 || block_size <= 0 || num_experts > 8192) return LL_ERR_SHAPE;
   const int max_padded = (int)num_slots + num_experts * (block_size - 1);
   const int max_blocks = (max_padded + block_size - 1) / block_size;
-  moe_align_kernel<<<1, 1024, 3 * num_experts * sizeof(int), (hipStream_t)stream>>>(
+  const int stage_ids = num_slots <= 4096 ? 1 : 0;  // the rank scan is quadratic: decode-sized batches only
+  moe_align_kernel<<<1, 1024, (3 * num_experts + (stage_ids ? (int)num_slots : 0)) * sizeof(int), (hipStream_t)stream>>>(
       topk_ids, ids_width, (int)num_slots, num_experts, block_size, sorted_ids, expert_ids, num_post, max_padded,
-      max_blocks);
+      max_blocks, stage_ids);
   return LL_LAUNCH_CHECK();
 }
 

@@ -596,7 +596,8 @@ def test_moe_align_protocol():
     ids = torch.full((4, 2), 5, device=DEV, dtype=torch.int64)
     s, e, n = K().moe_align_block_size(ids, 4, 8)
     assert int(n.item()) == 8 and s[:8].max() < 8 and e[:2].tolist() == [5, 5]
-    for t, topk, ne, bm in [(37, 2, 8, 32), (128, 8, 128, 64), (1, 8, 128, 16), (300, 4, 16, 64)]:
+    for t, topk, ne, bm in [(37, 2, 8, 32), (128, 8, 128, 64), (1, 8, 128, 16), (300, 4, 16, 64), (512, 8, 128, 64),
+                            (1100, 8, 64, 64)]:  # the last one takes the any-size placement path (> 4096 slots)
         ids = torch.randint(0, ne, (t, topk), dtype=torch.int32)
         so, eo, no = O.moe_align_block_size(ids, bm, ne)
         s, e, n = K().moe_align_block_size(ids.to(DEV), bm, ne)
