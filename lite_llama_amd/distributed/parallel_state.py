@@ -33,6 +33,11 @@ def grid_coordinates(global_rank: int, tp_size: int, dp_size: int) -> tuple[int,
 
 
 def _backend() -> str:
+    # LL_DIST_BACKEND=gloo: test knob -- several ranks on ONE GPU (RCCL refuses that), collectives staged
+    # through the host; the sharded kernels still run on the device
+    forced = os.environ.get("LL_DIST_BACKEND")
+    if forced:
+        return forced
     return "nccl" if torch.cuda.is_available() else "gloo"
 
 
@@ -50,7 +55,7 @@ def init_parallel(global_rank: int = 0, tp_size: int = 1, dp_size: int = 1, mast
     os.environ.setdefault("MASTER_PORT", str(master_port))
     if not dist.is_initialized():
         kw = {}
-        if torch.cuda.is_available():
+        if torch.cuda.is_available() and _backend() == "nccl":
             kw["device_id"] = torch.device("cuda", torch.cuda.current_device())
         dist.init_process_group(backend=_backend(), rank=global_rank, world_size=world, **kw)
         _OWNS_PG = True
