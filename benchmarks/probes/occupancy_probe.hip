@@ -36,6 +36,9 @@ __global__ __launch_bounds__(NW * 64) void k(int iters, float* out, unsigned lon
   if (PRIO == 2 && wv < NW / 2) __builtin_amdgcn_s_setprio(1);
   const unsigned long long t0 = __builtin_amdgcn_s_memtime();
   const bool rot = ROT == 1 ? wv >= NW / 2 : (ROT == 2 ? (wv & 1) : false);
+  f16x8 xq[ST];
+#pragma unroll
+  for (int st = 0; st < ST; ++st) { xq[st][0] = v0[0]; xq[st][1] = v1[1]; xq[st][2] = v2[0]; xq[st][3] = v3[1]; xq[st][4] = v0[1]; xq[st][5] = v1[0]; xq[st][6] = v2[1]; xq[st][7] = v3[0]; }
   f16x8 xpre;
   xpre[0] = v0[0]; xpre[1] = v0[1]; xpre[2] = v1[0]; xpre[3] = v1[1]; xpre[4] = v2[0]; xpre[5] = v2[1]; xpre[6] = v3[0]; xpre[7] = v3[1];
 #define DEQ(X)                                                                                                \
@@ -60,7 +63,25 @@ __global__ __launch_bounds__(NW * 64) void k(int iters, float* out, unsigned lon
       if (st == 0) { NXT[2 * ST] = CUR[2 * ST]; NXT[2 * ST + 1] = CUR[2 * ST + 1]; }                          \
     }
 #define HALF(CUR, NXT, PAR)                                                                                   \
-  if (ROT && rot) {                                                                                           \
+  if (ROT == 3) {                                                                                             \
+    if (wv >= NW / 2) {                                                                                       \
+      _Pragma("unroll") for (int st = 0; st < ST; ++st) {                                                     \
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xq[st], __builtin_bit_cast(f16x8, CUR[2 * st]), a0, 0, 0, 0); \
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xq[st], __builtin_bit_cast(f16x8, CUR[2 * st + 1]), a1, 0, 0, 0); \
+        RD(CUR, NXT, PAR, st)                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+      }                                                                                                       \
+      _Pragma("unroll") for (int st = 0; st < ST; ++st) { DEQ(xq[st]) __builtin_amdgcn_sched_barrier(0); }    \
+    } else {                                                                                                  \
+      _Pragma("unroll") for (int st = 0; st < ST; ++st) { DEQ(xq[st]) __builtin_amdgcn_sched_barrier(0); }    \
+      _Pragma("unroll") for (int st = 0; st < ST; ++st) {                                                     \
+        a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xq[st], __builtin_bit_cast(f16x8, CUR[2 * st]), a0, 0, 0, 0); \
+        a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xq[st], __builtin_bit_cast(f16x8, CUR[2 * st + 1]), a1, 0, 0, 0); \
+        RD(CUR, NXT, PAR, st)                                                                                 \
+        __builtin_amdgcn_sched_barrier(0);                                                                    \
+      }                                                                                                       \
+    }                                                                                                         \
+  } else if (ROT && rot) {                                                                                           \
     _Pragma("unroll") for (int st = 0; st < ST; ++st) {                                                       \
       a0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xpre, __builtin_bit_cast(f16x8, CUR[2 * st]), a0, 0, 0, 0); \
       a1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(xpre, __builtin_bit_cast(f16x8, CUR[2 * st + 1]), a1, 0, 0, 0); \
@@ -123,7 +144,9 @@ int main() {
     kern<<<256, nw * 64, 100 * 1024>>>(iters, out, cyc);
     (void)hipDeviceSynchronize();
     (void)hipMemcpy(h, cyc, sizeof(h), hipMemcpyDeviceToHost);
-    printf("%-58s %.1f cycles per unit\n", name, (double)h[0] / iters);
+    unsigned long long mx = 0, mn = ~0ull;
+    for (int w = 0; w < nw; ++w) { if (h[w] > mx) mx = h[w]; if (h[w] < mn) mn = h[w]; }
+    printf("%-58s %.1f cycles per unit (slowest wave; fastest %.1f)\n", name, (double)mx / iters, (double)mn / iters);
   };
   run("2/SIMD: arithmetic only (no reads, no barrier)", k<8, false, false, true>, 8);
   run("2/SIMD: + barrier", k<8, false, true, true>, 8);
@@ -144,6 +167,9 @@ int main() {
   run("2/SIMD: reads, no barrier, younger wave rotated", k<8, true, false, true, 0, false, 1, 1>, 8);
   run("4/SIMD: reads + barrier, odd waves rotated", k<16, true, true, true, 0, false, 1, 2>, 16);
   run("4/SIMD: reads + barrier, younger half rotated", k<16, true, true, true, 0, false, 1, 1>, 16);
+  run("2/SIMD: reads + barrier, BLOCK anti-phase (A: dequant-all then MFMA-all, B: reverse)", k<8, true, true, true, 0, false, 1, 3>, 8);
+  run("2/SIMD: barrier, no reads, block anti-phase", k<8, false, true, true, 0, false, 1, 3>, 8);
+  run("4/SIMD: reads + barrier, block anti-phase", k<16, true, true, true, 0, false, 1, 3>, 16);
   run("bare s_barrier loop,  4 waves (1/SIMD)", kbar<4>, 4);
   run("bare s_barrier loop,  8 waves (2/SIMD)", kbar<8>, 8);
   run("bare s_barrier loop, 12 waves (3/SIMD)", kbar<12>, 12);
