@@ -46,6 +46,7 @@ def parse():
     ap.add_argument("--ctx", type=int, default=512, help="context tokens per sequence when decoding starts")
     ap.add_argument("--quant", default="int4", choices=["int4", "int8", "smoothquant", "fp8", "none"])
     ap.add_argument("--no-graph", action="store_true")
+    ap.add_argument("--scattered", action="store_true", help="context rows in random pool order (gather cost)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=2, help="decoder layers in the CPU oracle sample")
     return ap.parse_args()
@@ -223,7 +224,7 @@ def main():
 
     total = args.warmup + args.steps
     engine = DecodeEngine(model, max_batch=args.batch, max_seq_len=args.ctx + total + 8, device=dev)
-    first = engine.synthetic_context(args.batch, args.ctx, seed=1 + ps.get_dp_rank())
+    first = engine.synthetic_context(args.batch, args.ctx, seed=1 + ps.get_dp_rank(), scattered=args.scattered)
 
     marks = {}
 
@@ -247,7 +248,7 @@ def main():
             raise
         graph_note = f"eager (graph capture failed: {type(exc).__name__})"
         engine = DecodeEngine(model, max_batch=args.batch, max_seq_len=args.ctx + total + 8, device=dev)
-        first = engine.synthetic_context(args.batch, args.ctx, seed=1 + ps.get_dp_rank())
+        first = engine.synthetic_context(args.batch, args.ctx, seed=1 + ps.get_dp_rank(), scattered=args.scattered)
         out = engine.decode(first, total, use_graph=False, on_step=on_step)
     barrier()
     elapsed = time.perf_counter() - marks["t0"]
@@ -275,7 +276,8 @@ def main():
                   "none": "f16 (fp32 accumulate)"}[args.quant],
         "data": "synthetic",
         "config": {"workload": f"{args.model} {args.quant} decode, batch {args.batch}/replica, ctx {args.ctx}->"
-                               f"{args.ctx + total}, {graph_note}", "global_batch": global_batch,
+                               f"{args.ctx + total}, {graph_note}" + (", scattered KV rows" if args.scattered else ""),
+                   "global_batch": global_batch,
                    "parallelism": f"dp{dp}xtp{tp}", "build_seconds": round(t_build, 1)},
         "step_roofline": {"algorithmic_bytes_per_step_per_gpu": int(step_bytes),
                           "achieved_GBps_per_gpu": round(step_bytes / (elapsed / args.steps) / 1e9, 1),

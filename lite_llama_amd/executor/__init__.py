@@ -133,10 +133,12 @@ class DecodeEngine:
         return greedy_argmax(last)
 
     @torch.no_grad()
-    def synthetic_context(self, batch: int, ctx_len: int, seed: int = 0) -> torch.Tensor:
+    def synthetic_context(self, batch: int, ctx_len: int, seed: int = 0, scattered: bool = False) -> torch.Tensor:
         """Benchmark helper: instead of running a prefill, fill the first ``ctx_len`` cache rows of
         every sequence with seeded random K/V (synthetic data of the prefill's shape) and return
-        random first tokens.  Metadata ends up exactly as after ``prefill``."""
+        random first tokens.  Metadata ends up exactly as after ``prefill``.  ``scattered``: the
+        table names the context rows in a random permutation (the fragmented-pool case: every K/V
+        row of a sequence sits somewhere else) instead of one contiguous run per sequence."""
         dev = self.device
         self.pool.reset()
         info = self.info
@@ -144,6 +146,8 @@ class DecodeEngine:
         g.manual_seed(seed)
         info.b_req_idx = torch.arange(batch, dtype=torch.int32, device=dev)
         rows = self.pool.alloc(batch * ctx_len)
+        if scattered:
+            rows = rows[torch.randperm(batch * ctx_len, generator=g, device=dev)]
         info.b_req_tokens_table[:batch, :ctx_len] = rows.view(batch, ctx_len)
         for kv in self.pool.kv_buffer:
             kv[: batch * ctx_len].copy_(
