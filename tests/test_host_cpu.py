@@ -113,3 +113,24 @@ def test_model_skeleton_and_tp_rules():
     assert (g.q_size, g.kv_size, g.intermediate_size) == (3584, 512, 18944)
     moe = CausalLM(tiny_geometry(num_experts=4, num_experts_per_tok=2, moe_intermediate_size=128))
     assert moe.layers[0].mlp.experts["gate_up_proj"].shape == (4, 256, 256)
+
+
+def test_decode_attention_shape_gate():
+    """Which shapes the one-launch decode attention accepts is decided on the host, from shapes, strides
+    and dtypes only (no launch): head_dim >= 64, <= 16 query heads per KV head, dense head rows, 16-bit
+    tables of the activation dtype."""
+    from lite_llama_amd.kernels.attention import decode_attention_supported as ok
+
+    def qkv(hq, hkv, d, dt=torch.float16):
+        fused = torch.zeros(3, (hq + 2 * hkv) * d, dtype=dt)
+        return fused[:, : hq * d].view(3, hq, d), fused[:, hq * d:].view(3, 2 * hkv, d)
+
+    cos = torch.zeros(16, 128, dtype=torch.float16)
+    q, kv = qkv(28, 4, 128)
+    assert ok(q, kv, cos, 4)
+    assert not ok(*qkv(28, 4, 32), cos, 4)                      # rotation partner would sit in another lane
+    assert not ok(*qkv(34, 2, 64), cos, 2)                      # 17 query heads per KV head: two head groups
+    assert not ok(q, kv, cos.float(), 4)                        # fp32 tables
+    assert not ok(q.transpose(0, 1), kv, cos, 4)                # head rows not dense
+    qb, kvb = qkv(8, 2, 64, torch.bfloat16)
+    assert ok(qb, kvb, cos.bfloat16(), 2) and not ok(qb, kvb, cos, 2)
