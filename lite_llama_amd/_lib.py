@@ -13,7 +13,7 @@ from ctypes import c_float, c_int, c_int64, c_void_p
 import torch
 
 _HERE = os.path.dirname(os.path.abspath(__file__))
-LIB_PATH = os.path.join(_HERE, "lib", "liblite_llama_amd.so")
+LIB_PATH = os.environ.get("LL_LIB_OVERRIDE") or os.path.join(_HERE, "lib", "liblite_llama_amd.so")  # override: A/B builds
 
 LL_F16, LL_BF16, LL_F32 = 0, 1, 2
 LL_I32, LL_I64 = 0, 1
