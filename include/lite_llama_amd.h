@@ -11,9 +11,13 @@
  *   - plain pointers are DEVICE pointers unless the name says host;
  *   - strides are in ELEMENTS, sizes in elements unless suffixed _bytes;
  *   - `stream` is a hipStream_t (torch.cuda.current_stream().cuda_stream);
- *   - asynchronous, re-entrant, no global mutable state, NO allocation and no
- *     device synchronisation -> every call is hipGraph-capturable; scratch is
- *     passed in by the caller (sizes from the *_workspace helpers);
+ *   - asynchronous, NO allocation and no device synchronisation -> every call is
+ *     hipGraph-capturable; the library keeps no mutable state of its own: scratch
+ *     (`workspace`, `counters`) is passed in by the caller (sizes from the
+ *     *_workspace helpers).  Calls are re-entrant as long as two calls that may be
+ *     in flight at the same time (different streams / threads) are given DIFFERENT
+ *     scratch buffers: the split-K slabs and merge counters are written by the
+ *     kernels.  The Python mirror keeps one scratch set per (device, stream);
  *   - return 0 on success, a negative LL_ERR_* code on an argument error (the
  *     Python mirror raises the same exception types the reference raises);
  *     kernels themselves never report errors (same as the reference).
@@ -182,6 +186,21 @@ int ll_w4a16_gateup_swiglu(void* out, const void* x, const int32_t* qweight, con
                            const float* zeros, const void* packed_sz, int64_t m, int64_t n, int64_t k,
                            int group_size, int64_t x_stride_m, int64_t qw_stride_n,
                            int64_t s_stride_n, float* workspace, int32_t* counters, void* stream);
+
+/* Load-time weight layout of the decode engine (no reference counterpart; the reference reserves
+ * lite_llama/models/quantization/_layout/__init__.py:1-6 for exactly this): a bit-exact permutation of
+ * qweight [N, K/8] into the order the M <= 64 kernel streams it (per (128-row tile, 128-k chunk) 8 KB =
+ * [wave 8][lane 64] x 16 B; inside a word even nibbles first).  packed: n * k / 2 bytes, n % 128 == 0,
+ * k % 128 == 0.  ll_w4a16_matmul_prepacked consumes it together with ll_w4a16_pack_scales' output
+ * (group_size = 128 * 2^j); epilogue 0 = w4a16_matmul, 1 = the gate/up + swiglu fusion above.  Same
+ * arithmetic as ll_w4a16_matmul (only the fp32 summation order differs). */
+int ll_w4a16_pack_weights(void* packed, const int32_t* qweight, int64_t n, int64_t k, int64_t qw_stride_n,
+                          void* stream);
+int ll_w4a16_prepacked_supported(int64_t m, int64_t n, int64_t k, int group_size); /* 1 / 0 */
+int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* wpacked, const void* spacked,
+                              const void* bias, int64_t m, int64_t n, int64_t k, int group_size,
+                              int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,
+                              void* stream);
 
 /* ---- a9: w8a16_matmul  (kernels/quantization/w8a16.py:155-216) ---------------
  * qweight [N,K] uint8 (fp8-e4m3 bits) or int8; scales fp32 [ceil(N/gn), ceil(K/gk)]. */

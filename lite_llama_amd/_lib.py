@@ -42,6 +42,9 @@ SIGNATURES = {
     "ll_w4a16_decode_supported": [L, L, L, I],
     "ll_w4a16_gateup_swiglu": [P, P, P, P, P, P, L, L, L, I, L, L, L, P, P, P],
     "ll_w4a16_matmul_packed": [P, P, P, P, P, P, P, L, L, L, I, L, L, L, P, P, P],
+    "ll_w4a16_pack_weights": [P, P, L, L, L, P],
+    "ll_w4a16_prepacked_supported": [L, L, L, I],
+    "ll_w4a16_matmul_prepacked": [P, P, P, P, P, L, L, L, I, L, P, P, I, P],
     "ll_w8a16_matmul": [P, P, P, P, P, L, L, L, I, L, I, L, L, L, L, P, P, P],
     "ll_quantize_activations_int8": [P, P, P, L, L, L, P],
     "ll_w8a8_matmul": [P, P, P, P, P, P, L, L, L, L, P, P, P, P],
@@ -130,31 +133,46 @@ def ptr(t) -> int:
 
 
 # --------------------------------------------------------------------------- #
-# split-K scratch for the streaming GEMMs: one persistent buffer per device, grown on
-# demand OUTSIDE graph capture (kernels never allocate; counters stay zero between calls).
+# Scratch the kernels WRITE (split-K slabs / merge counters, flash-decoding merge counters): one set per
+# (device, stream) for eager calls and one per device for graph captures, grown on demand OUTSIDE capture
+# (kernels never allocate; counters are zero between calls).  Two eager streams never share a set, and an
+# eager call never shares one with a replaying graph.  Graphs captured through this module share the
+# device's capture set: replay them on one stream at a time (what DecodeEngine / SlotRunner do).
 # --------------------------------------------------------------------------- #
 _gemm_ws: dict = {}
-_gemm_ws_keepalive: list = []  # captured hipGraphs may still point at outgrown buffers
+_scratch_keepalive: list = []  # captured hipGraphs may still point at outgrown buffers
 
 
-def gemm_workspace(device: torch.device, m: int, n: int, k: int):
-    floats, ints = c_int64(0), c_int64(0)
-    lib().ll_gemm_workspace(m, n, k, ctypes.byref(floats), ctypes.byref(ints))
-    # one scratch per device: the decode path is single-stream (a side-stream warm-up and the
-    # capture that follows are ordered by stream fences), so concurrent use never happens
-    key = (device.type, device.index)
+def scratch_keys(device: torch.device):
+    """(key to use now, key of the capture set)."""
+    cap = (device.type, device.index, "capture")
+    if torch.cuda.is_current_stream_capturing():
+        return cap, cap
+    return (device.type, device.index, torch.cuda.current_stream(device).cuda_stream), cap
+
+
+def _grow_gemm_ws(key, device, floats: int, ints: int):
     ws = _gemm_ws.get(key)
-    if ws is None or ws[0].numel() < floats.value or ws[1].numel() < ints.value:
+    if ws is None or ws[0].numel() < floats or ws[1].numel() < ints:
         if torch.cuda.is_current_stream_capturing():
             raise RuntimeError(
                 "GEMM split-K workspace must be sized before graph capture (run one eager warm-up step)"
             )
-        nf = max(floats.value, ws[0].numel() if ws else 0)
-        ni = max(ints.value, ws[1].numel() if ws else 0, 4096)
+        nf = max(floats, ws[0].numel() if ws else 0)
+        ni = max(ints, ws[1].numel() if ws else 0, 4096)
         ws = (
             torch.empty(nf, dtype=torch.float32, device=device),
             torch.zeros(ni, dtype=torch.int32, device=device),
         )
         _gemm_ws[key] = ws
-        _gemm_ws_keepalive.append(ws)
+        _scratch_keepalive.append(ws)
     return ws
+
+
+def gemm_workspace(device: torch.device, m: int, n: int, k: int):
+    floats, ints = c_int64(0), c_int64(0)
+    lib().ll_gemm_workspace(m, n, k, ctypes.byref(floats), ctypes.byref(ints))
+    key, cap = scratch_keys(device)
+    if key != cap:  # every shape warmed up eagerly is capturable afterwards
+        _grow_gemm_ws(cap, device, floats.value, ints.value)
+    return _grow_gemm_ws(key, device, floats.value, ints.value)

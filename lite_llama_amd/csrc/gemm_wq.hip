@@ -646,6 +646,7 @@ static Plan make_plan(int64_t m, int64_t n, int64_t k) {
 // second-generation W4A16 engine (gemm_w4_v2.hip)
 extern "C" int ll_w4a16_v2_workspace(int64_t m, int64_t n, int64_t k, int64_t* floats, int64_t* ints);
 extern "C" int ll_w4a16_v2_supported(int64_t m, int64_t n, int64_t k, int group_size);
+extern "C" int ll_w4a16_v3_workspace(int64_t m, int64_t n, int64_t k, int64_t* floats, int64_t* ints);  // gemm_w4_v3.hip
 extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweight, const float* scales,
                                   const float* zeros, const void* packed, const void* bias, int64_t m, int64_t n, int64_t k,
                                   int group_size, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
@@ -657,6 +658,9 @@ extern "C" int ll_gemm_workspace(int64_t m, int64_t n, int64_t k, int64_t* works
   const int64_t tiles = (int64_t)pl.mblocks * pl.nblocks;
   int64_t f = tiles * pl.slots * GEMM_SLAB, c = tiles * 4, f2 = 0, c2 = 0;
   ll_w4a16_v2_workspace(m, n, k, &f2, &c2);  // the scratch must fit whichever engine is dispatched
+  if (f2 > f) f = f2;
+  if (c2 > c) c = c2;
+  ll_w4a16_v3_workspace(m, n, k, &f2, &c2);
   if (workspace_floats) *workspace_floats = f > f2 ? f : f2;
   if (counter_ints) *counter_ints = c > c2 ? c : c2;
   return LL_OK;

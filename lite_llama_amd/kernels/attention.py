@@ -8,14 +8,15 @@ import torch
 from .. import _lib as L
 
 
-# zeroed, self-cleaning counters for the one-launch merge (kernels never allocate; grown outside
-# graph capture; outgrown vectors stay alive for graphs that captured their address)
+# zeroed, self-cleaning counters for the one-launch merge (kernels never allocate; grown outside graph
+# capture; outgrown vectors stay alive for graphs that captured their address).  One vector per
+# (device, stream) for eager calls, one per device for captures -- see _lib.scratch_keys.
 _fd_counters: dict = {}
 _fd_keepalive: list = []
 
 
-def _merge_counters(device, entries: int):
-    cur = _fd_counters.get(device)
+def _grow_counters(key, device, entries: int):
+    cur = _fd_counters.get(key)
     if cur is not None and cur.numel() >= entries:
         return cur
     if torch.cuda.is_current_stream_capturing():
@@ -23,8 +24,15 @@ def _merge_counters(device, entries: int):
     if cur is not None:
         _fd_keepalive.append(cur)
     cur = torch.zeros(max(entries, 4096), dtype=torch.int32, device=device)
-    _fd_counters[device] = cur
+    _fd_counters[key] = cur
     return cur
+
+
+def _merge_counters(device, entries: int):
+    key, cap = L.scratch_keys(device)
+    if key != cap:
+        _grow_counters(cap, device, entries)
+    return _grow_counters(key, device, entries)
 
 
 @torch.no_grad()

@@ -118,6 +118,65 @@ def pack_w4a16_scales(scales: torch.Tensor, zeros: torch.Tensor) -> torch.Tensor
     return packed
 
 
+def pack_w4a16_weights(qweight: torch.Tensor) -> torch.Tensor:
+    """Load-time companion of :func:`w4a16_matmul_prepacked` (the layout slot the reference reserves in
+    ``models/quantization/_layout``): a bit-exact permutation of ``qweight [N, K/8]`` into the order the
+    decode engine streams it -- per (128-row tile, 128-k chunk) one 8-KB block ``[wave 8][lane 64] x 16 B``,
+    even nibbles of every word first.  ``N`` and ``K`` must be multiples of 128."""
+    L.require_cuda(qweight)
+    if qweight.dtype != torch.int32 or qweight.dim() != 2:
+        raise ValueError("qweight must be int32 [N, K/8]")
+    n, kp = qweight.shape
+    k = kp * 8
+    if n % 128 or k % 128:
+        raise ValueError(f"pack_w4a16_weights needs N and K multiples of 128, got {n} x {k}")
+    if qweight.stride(1) != 1 or qweight.stride(0) % 4 or qweight.data_ptr() % 16:
+        qweight = qweight.contiguous()
+    packed = torch.empty((n // 128, k // 128, 8, 64, 4), dtype=torch.int32, device=qweight.device)
+    L.check(L.lib().ll_w4a16_pack_weights(packed.data_ptr(), qweight.data_ptr(), n, k, qweight.stride(0),
+                                          L.stream_ptr()), "pack_w4a16_weights")
+    return packed
+
+
+def w4a16_prepacked_supported(m: int, n: int, k: int, group_size: int) -> bool:
+    return bool(L.lib().ll_w4a16_prepacked_supported(m, n, k, int(group_size)))
+
+
+def w4a16_matmul_prepacked(x, packed_weight, packed_scales, *, group_size: int = 128, bias=None, gate_up_swiglu=False):
+    """Decode-engine form of :func:`w4a16_matmul` over the load-time layouts (``pack_w4a16_weights`` /
+    ``pack_w4a16_scales``); at most 64 rows.  ``gate_up_swiglu`` applies the fused epilogue of
+    :func:`w4a16_gate_up_swiglu` (rows interleaved gate/up).  Same arithmetic as ``w4a16_matmul``."""
+    if x.dtype != torch.float16:
+        raise ValueError(f"w4a16 activations must be fp16, got {x.dtype}")
+    L.require_cuda(x, packed_weight, packed_scales, bias)
+    if packed_weight.dtype != torch.int32 or packed_weight.dim() != 5 or not packed_weight.is_contiguous():
+        raise ValueError("packed_weight must be the int32 [N/128, K/128, 8, 64, 4] tensor made by pack_w4a16_weights")
+    n, k = packed_weight.shape[0] * 128, packed_weight.shape[1] * 128
+    if x.shape[-1] != k:
+        raise ValueError(f"x has {x.shape[-1]} cols but weight expects {k}")
+    if tuple(packed_scales.shape) != (k // group_size, n, 2) or packed_scales.dtype != torch.int32 \
+            or not packed_scales.is_contiguous():
+        raise ValueError("packed_scales must be the int32 [K/g, N, 2] tensor made by pack_w4a16_scales")
+    leading = x.shape[:-1]
+    a = _flatten(x, k)
+    m = a.shape[0]
+    if not w4a16_prepacked_supported(max(m, 1), n, k, group_size):
+        raise ValueError(f"w4a16_matmul_prepacked: shape M={m} N={n} K={k} g={group_size} is outside the decode engine")
+    if bias is not None and bias.dtype != torch.float16:
+        bias = bias.half()
+    n_out = n // 2 if gate_up_swiglu else n
+    out = torch.empty((m, n_out), dtype=x.dtype, device=x.device)
+    ws, cnt = L.gemm_workspace(x.device, m, n, k)
+    L.check(
+        L.lib().ll_w4a16_matmul_prepacked(
+            out.data_ptr(), a.data_ptr(), packed_weight.data_ptr(), packed_scales.data_ptr(), L.ptr(bias), m, n, k,
+            int(group_size), a.stride(0), ws.data_ptr(), cnt.data_ptr(), 1 if gate_up_swiglu else 0, L.stream_ptr(),
+        ),
+        "w4a16_matmul_prepacked",
+    )
+    return out.reshape(*leading, n_out)
+
+
 def w8a16_matmul(
     x: torch.Tensor,
     qweight: torch.Tensor,

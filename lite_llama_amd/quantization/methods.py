@@ -7,6 +7,7 @@ layer's parameters to the HIP kernels; parameter names/dtypes are the reference'
 
 from __future__ import annotations
 
+import os
 from abc import ABC, abstractmethod
 
 import torch
@@ -14,7 +15,8 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..kernels import fused_moe, smoothquant_matmul, w4a16_matmul, w8a16_matmul
-from ..kernels.quantization import pack_w4a16_scales, w4a16_gate_up_swiglu
+from ..kernels.quantization import (pack_w4a16_scales, pack_w4a16_weights, w4a16_gate_up_swiglu,
+                                    w4a16_matmul_prepacked, w4a16_prepacked_supported)
 from .config import FP8, INT4, INT8, SMOOTHQUANT, QuantConfig
 from .params import (
     quantize_fp8_per_channel,
@@ -71,6 +73,9 @@ class W4A16LinearMethod(LinearQuantMethod):
         layer.weight_zeros = RawParameter(torch.empty(*q.scale_shape(output_size, input_size), dtype=torch.float32))
 
     def apply(self, layer, x):
+        pre = self._prepacked(layer, x)
+        if pre is not None:
+            return w4a16_matmul_prepacked(x, pre, self._packed(layer), group_size=layer.quant.group_k, bias=layer.bias)
         return w4a16_matmul(x, layer.weight, layer.weight_scale, layer.weight_zeros,
                             group_size=layer.quant.group_k, bias=layer.bias,
                             packed_scales=self._packed(layer))
@@ -80,6 +85,10 @@ class W4A16LinearMethod(LinearQuantMethod):
         both projections and the activation; ``None`` -> the caller falls back to the two-step form."""
         if layer.bias is not None:
             return None
+        pre = self._prepacked(layer, x)
+        if pre is not None:
+            return w4a16_matmul_prepacked(x, pre, self._packed(layer), group_size=layer.quant.group_k,
+                                          gate_up_swiglu=True)
         return w4a16_gate_up_swiglu(x, layer.weight, layer.weight_scale, layer.weight_zeros,
                                     group_size=layer.quant.group_k, packed_scales=self._packed(layer))
 
@@ -97,6 +106,26 @@ class W4A16LinearMethod(LinearQuantMethod):
         packed = pack_w4a16_scales(layer.weight_scale.data, layer.weight_zeros.data)
         layer._w4_packed = (key, packed)
         return packed
+
+    def _prepacked(self, layer, x):
+        """Decode-shaped calls (<= 64 rows) stream the weights from their load-time layout
+        (``pack_w4a16_weights``; cached on the layer next to the reference-format parameter, which stays
+        the checkpoint-facing tensor and serves every other shape).  ``None`` -> reference-format path."""
+        n, kp = layer.weight.shape
+        m = x.numel() // x.shape[-1] if x.shape[-1] else 0
+        if m < 1 or m > 64 or not layer.weight.is_cuda or os.environ.get("LL_W4_NO_PREPACK"):
+            return None
+        if not w4a16_prepacked_supported(m, n, kp * 8, layer.quant.group_k):
+            return None
+        key = (layer.weight.data_ptr(), layer.weight._version)
+        cached = getattr(layer, "_w4_prepacked", None)
+        if cached is not None and cached[0] == key:
+            return cached[1] if self._packed(layer) is not None else None
+        if torch.cuda.is_current_stream_capturing() or self._packed(layer) is None:
+            return None
+        pre = pack_w4a16_weights(layer.weight.data)
+        layer._w4_prepacked = (key, pre)
+        return pre
 
     def convert_from_fp16(self, layer, quant):
         qw, sc, zr = quantize_int4_groupwise(layer.weight.data, quant.group_k)

@@ -14,6 +14,7 @@ import torch
 
 from oracle import oracle as O
 from tests import _golden as G
+import lite_llama_amd._lib as L_
 
 pytestmark = pytest.mark.gpu
 
@@ -293,7 +294,7 @@ def test_flash_decoding_one_launch_merge_equals_two_launch(monkeypatch):
         seq = torch.tensor(lens, dtype=torch.int32, device=DEV)
         args = (q, kc, vc, 1.0 / d ** 0.5, table, req, seq, max(lens))
         one = K().flash_decoding(*args)
-        ctr = A._fd_counters[q.device]
+        ctr = A._fd_counters[L_.scratch_keys(q.device)[0]]
         assert int(ctr.abs().sum()) == 0
         again = K().flash_decoding(*args)
         with monkeypatch.context() as m:
@@ -303,7 +304,7 @@ def test_flash_decoding_one_launch_merge_equals_two_launch(monkeypatch):
     seq0 = torch.tensor([0, 40], dtype=torch.int32, device=DEV)
     out = K().flash_decoding(q[:2], kc, vc, 0.2, table[:2], req[:2], seq0, 64)
     assert torch.isnan(out[0]).all() and torch.isfinite(out[1]).all()
-    assert int(A._fd_counters[q.device].abs().sum()) == 0
+    assert int(A._fd_counters[L_.scratch_keys(q.device)[0]].abs().sum()) == 0
 
 
 @pytest.mark.parametrize("hq,hkv,d,dtype", [(28, 4, 128, torch.float16), (8, 2, 64, torch.float16),

@@ -1,0 +1,159 @@
+"""GPU parity tests of the third-generation W4A16 decode engine (csrc/gemm_w4_v3.hip): weights streamed
+from their load-time layout (``pack_w4a16_weights``).  Same contract as ``w4a16_matmul``
+(lite_llama/kernels/quantization/w4a16.py:152-207): nibble unpack bit-exact, results within the
+reference's tolerance (5e-2) -- checked at 1e-2 -- of the CPU oracle, on the real Qwen2.5-7B shapes
+(every split the host plan can produce) and on a randomised shape sweep against the reference-format
+engine."""
+
+import random
+
+import pytest
+import torch
+
+from oracle import oracle as O
+from tests import _golden as G
+
+pytestmark = pytest.mark.gpu
+DEV = "cuda"
+
+
+def Q():
+    import lite_llama_amd.kernels.quantization as q
+
+    return q
+
+
+def close(a, b, tol):
+    torch.testing.assert_close(a.float().cpu(), b.float().cpu(), rtol=tol, atol=tol)
+
+
+def expected_pack(qw: torch.Tensor) -> torch.Tensor:
+    """CPU restatement of the packer: block (tile, chunk) = [wave 8][lane 64][4 words]; wave (ng = w & 3,
+    kh = w >> 2), lane (nl = l & 31, h = l >> 5) holds source words chunk*16 + kh*8 + h*4 + 0..3 of row
+    tile*128 + ng*32 + nl; inside a word the even nibbles move to positions 0..3, the odd ones to 4..7."""
+    n, kp = qw.shape
+    nib = O.unpack_int4(qw).to(torch.int64)  # [N, K] natural order
+    k = kp * 8
+    oct_ = nib.reshape(n, k // 8, 8)
+    order = [0, 2, 4, 6, 1, 3, 5, 7]
+    words = sum(oct_[:, :, order[i]] << (4 * i) for i in range(8))  # [N, K/8] permuted words (as int64)
+    words = words.reshape(n // 128, 4, 32, k // 128, 2, 2, 4)  # tile, ng, nl, chunk, kh, h, j
+    words = words.permute(0, 3, 4, 1, 5, 2, 6)  # tile, chunk, kh, ng, h, nl, j
+    words = words.reshape(n // 128, k // 128, 8, 64, 4)
+    return (words & 0xFFFFFFFF).to(torch.int64)
+
+
+def test_pack_weights_bit_exact():
+    g = torch.Generator().manual_seed(5)
+    qw = torch.randint(-(2**31), 2**31 - 1, (384, 64), dtype=torch.int64, generator=g).to(torch.int32)
+    got = Q().pack_w4a16_weights(qw.to(DEV)).cpu().to(torch.int64) & 0xFFFFFFFF
+    assert torch.equal(got, expected_pack(qw))
+    with pytest.raises(ValueError):
+        Q().pack_w4a16_weights(qw[:100].to(DEV))
+
+
+def test_prepacked_unpack_bit_exact():
+    """x = one-hot rows, scale 1, zero 0: the GEMM output IS the nibble matrix (every k position)."""
+    n, k = 256, 256
+    qw = torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64).to(torch.int32)
+    sc, zr = torch.ones(n, k // 128), torch.zeros(n, k // 128)
+    pw = Q().pack_w4a16_weights(qw.to(DEV))
+    ps = Q().pack_w4a16_scales(sc.to(DEV), zr.to(DEV))
+    nib = O.unpack_int4(qw).float()
+    for base in range(0, k, 64):
+        x = torch.eye(k, dtype=torch.float16)[base:base + 64]
+        y = Q().w4a16_matmul_prepacked(x.to(DEV), pw, ps, group_size=128)
+        assert torch.equal(y.float().cpu(), nib[:, base:base + 64].T)
+
+
+@pytest.mark.parametrize("name", G.names("w4a16_"))
+def test_prepacked_golden(name):
+    d = G.load(name)
+    n, kp = d["qweight"].shape
+    gs = int(d["group_size"])
+    if n % 128 or (kp * 8) % 128 or gs % 128 or d["x"].reshape(-1, kp * 8).shape[0] > 64:
+        pytest.skip("fixture shape is outside the decode engine (served by the reference-format engine)")
+    pw = Q().pack_w4a16_weights(d["qweight"].to(DEV))
+    ps = Q().pack_w4a16_scales(d["scales"].to(DEV), d["zeros"].to(DEV))
+    bias = d.get("bias")
+    y = Q().w4a16_matmul_prepacked(d["x"].to(DEV), pw, ps, group_size=gs, bias=None if bias is None else bias.to(DEV))
+    close(y, d["y"], 1e-2)
+
+
+@pytest.mark.parametrize("M,N,K_,gs", [(64, 37888, 3584, 128), (64, 3584, 18944, 128), (64, 4608, 3584, 128),
+                                       (64, 3584, 3584, 128), (17, 1024, 3584, 128), (64, 4608, 3584, 256),
+                                       (1, 128, 512, 128), (32, 18944, 3584, 128), (64, 128, 128, 128)])
+def test_prepacked_qwen_shapes_vs_oracle(M, N, K_, gs):
+    g = torch.Generator().manual_seed(N + K_ + M)
+    x = torch.randn(M, K_, dtype=torch.float16, generator=g) * 0.5
+    qw = torch.randint(-(2**31), 2**31 - 1, (N, K_ // 8), dtype=torch.int64, generator=g).to(torch.int32)
+    sc = torch.rand(N, K_ // gs, generator=g) * 0.01 + 0.005
+    zr = torch.randint(0, 16, (N, K_ // gs), generator=g).float()
+    bias = (torch.randn(N, generator=g) * 0.1).half()
+    pw = Q().pack_w4a16_weights(qw.to(DEV))
+    ps = Q().pack_w4a16_scales(sc.to(DEV), zr.to(DEV))
+    xd = x.to(DEV)
+    y0 = Q().w4a16_matmul_prepacked(xd, pw, ps, group_size=gs, bias=bias.to(DEV))
+    for _ in range(3):  # repeated launches reuse the split-K scratch (counters must come back to zero)
+        assert torch.equal(y0, Q().w4a16_matmul_prepacked(xd, pw, ps, group_size=gs, bias=bias.to(DEV)))
+    rows = torch.randperm(N, generator=g)[:256].sort().values
+    ref = O.w4a16_matmul(x, qw[rows], sc[rows], zr[rows], group_size=gs, bias=bias[rows])
+    close(y0[:, rows.to(DEV)], ref, 1e-2)
+
+
+def test_prepacked_float_zero_points_at_1e2():
+    g = torch.Generator().manual_seed(3)
+    x = torch.randn(8, 512, dtype=torch.float16, generator=g)
+    qw = torch.randint(-(2**31), 2**31 - 1, (256, 64), dtype=torch.int64, generator=g).to(torch.int32)
+    sc = torch.rand(256, 4, generator=g) * 0.02 + 0.01
+    zr = torch.rand(256, 4, generator=g) * 15  # the format stores zeros as floats: non-integers must work
+    ref = O.w4a16_matmul(x, qw, sc, zr, group_size=128)
+    y = Q().w4a16_matmul_prepacked(x.to(DEV), Q().pack_w4a16_weights(qw.to(DEV)),
+                                   Q().pack_w4a16_scales(sc.to(DEV), zr.to(DEV)), group_size=128)
+    close(y, ref, 1e-2)
+    y2 = Q().w4a16_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), zr.to(DEV), group_size=128)
+    close(y2, ref, 1e-2)
+
+
+def test_prepacked_gate_up_swiglu_equals_two_step():
+    """The fused epilogue on rows interleaved gate/up == swiglu(matmul(gate), matmul(up)) of the same engine."""
+    import lite_llama_amd.kernels as K
+    g = torch.Generator().manual_seed(9)
+    i_sz, k = 1024, 1536
+    x = (torch.randn(64, k, generator=g) * 0.5).half().to(DEV)
+    qw = torch.randint(-(2**31), 2**31 - 1, (2 * i_sz, k // 8), dtype=torch.int64, generator=g).to(torch.int32).to(DEV)
+    sc = (torch.rand(2 * i_sz, k // 128, generator=g) * 0.01 + 0.005).to(DEV)
+    zr = torch.randint(0, 16, (2 * i_sz, k // 128), generator=g).float().to(DEV)
+    fused = Q().w4a16_matmul_prepacked(x, Q().pack_w4a16_weights(qw), Q().pack_w4a16_scales(sc, zr), gate_up_swiglu=True)
+    gate = Q().w4a16_matmul_prepacked(x, Q().pack_w4a16_weights(qw[0::2].contiguous()),
+                                      Q().pack_w4a16_scales(sc[0::2].contiguous(), zr[0::2].contiguous()))
+    up = Q().w4a16_matmul_prepacked(x, Q().pack_w4a16_weights(qw[1::2].contiguous()),
+                                    Q().pack_w4a16_scales(sc[1::2].contiguous(), zr[1::2].contiguous()))
+    two = K.swiglu_forward(gate, up)
+    close(fused, two, 2e-3)  # same rounding points; only the fp32 summation order of the split can differ
+
+
+def test_prepacked_random_shapes_match_reference_format_engine():
+    """Plan edge cases (stream-K vs tile groups, 1..12 contributors per tile, M = 1..64, K/N from one unit to
+    hundreds): equal to the reference-format engines up to the fp32 summation order; repeated launches
+    bit-identical."""
+    import lite_llama_amd.kernels as K
+    rnd = random.Random(13)
+    for it in range(40):
+        m = rnd.choice([1, 2, 7, 16, 31, 32, 33, 48, 63, 64])
+        n = 128 * rnd.choice([1, 2, 3, 5, 8, 9, 17, 28, 36, 61, 148, 255, 256, 257, 300])
+        k = 128 * rnd.choice([1, 2, 3, 4, 5, 7, 8, 13, 28, 29, 37, 64, 148])
+        gs = rnd.choice([128, 128, 256]) if k % 256 == 0 else 128
+        g = torch.Generator(device=DEV).manual_seed(it)
+        x = (torch.randn(m, k, generator=g, device=DEV) * 0.5).half()
+        qw = torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64, generator=g, device=DEV).to(torch.int32)
+        sc = torch.rand(n, k // gs, generator=g, device=DEV) * 0.01 + 0.005
+        zr = torch.randint(0, 16, (n, k // gs), generator=g, device=DEV).float()
+        bias = (torch.randn(n, generator=g, device=DEV) * 0.1).half() if it % 3 == 0 else None
+        pw, ps = Q().pack_w4a16_weights(qw), Q().pack_w4a16_scales(sc, zr)
+        y3 = Q().w4a16_matmul_prepacked(x, pw, ps, group_size=gs, bias=bias)
+        y3b = Q().w4a16_matmul_prepacked(x, pw, ps, group_size=gs, bias=bias)
+        y2 = K.w4a16_matmul(x, qw, sc, zr, group_size=gs, bias=bias)
+        scale = y2.float().abs().max().item() + 1e-6
+        assert torch.equal(y3, y3b), (m, n, k, gs)
+        assert (y3.float() - y2.float()).abs().max().item() <= 2e-3 * scale + 2e-3, (m, n, k, gs)
