@@ -1,0 +1,57 @@
+"""In-kernel timeline of wgemm3_kernel (needs a -DV3_TIMELINE build of gemm_w4_v3.hip; LL_LIB_OVERRIDE points at it).
+Stamps are s_memrealtime (100 MHz); printed in us relative to the earliest workgroup entry."""
+import os, sys, torch
+sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
+import lite_llama_amd.kernels.quantization as Q
+
+dev = "cuda"
+shapes = [("qkv", 4608, 3584, 0), ("o", 3584, 3584, 0), ("gate|up", 37888, 3584, 1), ("down", 3584, 18944, 0)]
+for name, n, k, epi in shapes:
+    copies = 3
+    ws = [(torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64, device=dev).to(torch.int32),
+           torch.rand(n, k // 128, device=dev) * 0.01 + 0.005,
+           torch.randint(0, 16, (n, k // 128), device=dev).float()) for _ in range(copies)]
+    x = torch.randn(64, k, device=dev, dtype=torch.float16)
+    ps = [Q.pack_w4a16_scales(w[1], w[2]) for w in ws]
+    pw = [Q.pack_w4a16_weights(w[0]) for w in ws]
+    tl = torch.zeros(1024 * 64, dtype=torch.int64, device=dev)
+    for wave in (0, 4):
+        os.environ["LL_GEMM3_TL_WAVE"] = str(wave)
+        os.environ.pop("LL_GEMM3_TIMELINE", None)
+        for i in range(copies):
+            Q.w4a16_matmul_prepacked(x, pw[i], ps[i], group_size=128, gate_up_swiglu=bool(epi))
+        torch.cuda.synchronize()
+        tl.zero_()
+        os.environ["LL_GEMM3_TIMELINE"] = hex(tl.data_ptr())
+        Q.w4a16_matmul_prepacked(x, pw[0], ps[0], group_size=128, gate_up_swiglu=bool(epi))
+        torch.cuda.synchronize()
+        os.environ.pop("LL_GEMM3_TIMELINE", None)
+        t = tl.view(1024, 64).cpu().double()
+        live = t[:, 0] > 0
+        t = t[live]
+        t0 = t[:, 0].min()
+
+        def stat(col, rel_entry=False):
+            v = t[:, col]
+            m = v > 0
+            if m.sum() == 0:
+                return "      -      "
+            base = t[m, 0] if rel_entry else t0
+            d = (v[m] - base) / 100.0
+            return f"{d.median():6.2f}/{d.max():6.2f}"
+
+        print(f"== {name} wave {wave}: {int(live.sum())} workgroups; us after the first entry (median/max over workgroups)")
+        print(f"  entry spread {stat(0)} | decoded {stat(1, True)} (after own entry) | loads issued {stat(2, True)} | first barrier {stat(3, True)}")
+        units = [c for c in range(4, 44) if (t[:, c] > 0).any()]
+        per = []
+        for c in units[:12]:
+            per.append(stat(c, True))
+        print("  unit barriers (after own entry):", " ".join(per))
+        nun = (t[:, 4:44] > 0).sum(1)
+        # steady period: (last unit stamp - first unit stamp) / (n - 1)
+        rows = nun > 2
+        if rows.any():
+            last = torch.gather(t[:, 4:44], 1, (nun.clamp(min=1) - 1).long().unsqueeze(1)).squeeze(1)
+            period = ((last - t[:, 4]) / (nun - 1).clamp(min=1) / 100.0)[rows]
+            print(f"  units/workgroup {int(nun.min())}..{int(nun.max())}; unit period median {period.median():.3f} us (min {period.min():.3f}, max {period.max():.3f})")
+        print(f"  last segment end: begin {stat(50)} exchanged {stat(51)} counter seen {stat(52)} merged {stat(53)} | wave done {stat(60)}")

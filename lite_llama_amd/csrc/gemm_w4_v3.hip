@@ -3,28 +3,31 @@
 // lite_llama/models/quantization/_layout/__init__.py:1-6.  Semantics: lite_llama/kernels/quantization/w4a16.py:28-207
 // (out[m, n] = sum_k x[m, k] * (nib(n, k) - z[n, k/g]) * s[n, k/g] (+ bias), fp32 accumulation, fp16 out).
 //
-// What round 1 measured on the second-generation engine (gemm_w4_v2.hip) and what this one
-// changes:
-//   * the loop was paced by the consumer waves at 0.8 us per 8-KB unit (matrix-pipe floor 0.30), with four
-//     memory waves (loaders: global -> registers -> swizzled LDS ring; producers: x through v_perm) sharing
-//     the consumers' SIMDs and one workgroup-wide barrier tying twelve waves together -> here there are NO
-//     memory roles: the weights are stored in the order the MFMA wants them, so every consumer wave streams
-//     ITS OWN weight words (one contiguous KB per wave and unit) and scale pairs straight from global memory
-//     into a register ring V3_R units deep, and stages its eighth of the activation tile; nothing is
-//     permuted on the way (the nibble order inside a word is arranged by the packer so that the dequantised
-//     pairs come out in natural k order);
-//   * 5 us of prologue (unit table in LDS, a barrier, then a 112-KB request burst per CU) -> the unit sequence
-//     is three scalar segments (tail, full tiles, head) walked by two scalar cursors; the first loads leave
-//     before anything else happens;
-//   * every global access is a raw buffer load: one scalar offset per unit, fixed per-lane offsets, rows
-//     >= M and units past the end of the range read as zeros without touching memory (null descriptor).
-// Kept from v2: the unit (128 weight rows x 128 k), the 4 row groups x 2 k-halves consumer shape, the exact
-// nibble unpack + fp16 affine map (13 VALU per 8 weights), stream-K with static tile ownership (tail segment
-// first, head segment last; contributors park partials in slabs with write-through stores and post a
-// counter, the owner merges with coherent loads; waits only point at lower-numbered workgroups) and the
-// tile-group split with an owner lead for shapes with few tiles.  New in the merge: after the k-half
-// reduction each of the two waves of a row group finishes ONE 32-row half of the batch (flush, merge and
-// epilogue are split two ways instead of idling the k-half-1 wave).
+// Structure (what round 2 measured is in DESIGN.md 4.1; short form):
+//   * unit = 128 weight rows x 128 k; stream-K / tile-group split with static tile ownership as in
+//     gemm_w4_v2.hip (tail segment first, head segment last; write-through slabs + counters; waits only
+//     point at lower-numbered workgroups);
+//   * 12 waves per workgroup, one workgroup per CU.  Waves 8-11 are LOADERS and do nothing but LDS-DMA
+//     (global_load_lds: no registers, no ds_write, no permutes): waves 8/9 copy a unit's 8 KB of packed
+//     weights + 1 KB of (s, -z*s) pairs into a 6-slot ring five units ahead, waves 10/11 its [64 x 128]
+//     activation tile into a 4-slot ring three units ahead (XOR-swizzled through the per-lane SOURCE
+//     address so that the consumers' 16-byte fragment reads are bank-conflict free).  The two streams live
+//     in different waves on purpose: a wave's memory operations return in order, so L2-resident
+//     activations queued behind HBM weight loads in one wave inherit the HBM latency (measured with the
+//     self-loading variant of this kernel: compute 0.69 us/unit, memory 0.48, together 1.0 -- a wave blocked
+//     on a full memory queue cannot issue its MFMAs);
+//   * waves 0-7 are CONSUMERS (4 row groups x 2 k-halves): 10 LDS reads, the exact nibble unpack + fp16
+//     affine map (13 VALU per 8 weights) and 8 MFMA 32x32x16 per unit, no global memory instruction at all
+//     in the loop.  The weights are stored in the order the MFMA wants them (the packer arranges the
+//     nibbles so that the dequantised pairs come out in natural k order): one contiguous KB per wave and
+//     unit, nothing is permuted on the way.  All operands of unit u+1 are read into a second register set
+//     while unit u is multiplied (bare s_barrier, reads stay in flight across it);
+//   * no unit table, no prologue barrier before the first loads: the unit sequence is three scalar
+//     segments walked by scalar cursors;
+//   * one s_barrier per unit for all twelve waves; the loaders wait (counted vmcnt) for unit u+2 before
+//     barrier u, so everything a consumer touches after a barrier has landed;
+//   * after the k-half reduction each of the two waves of a row group finishes ONE 32-row half of the
+//     batch (flush, merge and epilogue split two ways).
 #include <stdlib.h>
 
 #include "common.h"
@@ -32,15 +35,19 @@
 #define V3_BN 128
 #define V3_BM 64
 #define V3_CK 128
-#define V3_THREADS 512
-#define V3_R 5  // register ring: a unit's operands are requested V3_R units before they are used
+#define V3_THREADS 768
+#define V3_RW 6  // weight + scale ring slots (LDS), filled V3_DW units ahead
+#define V3_DW 5
+#define V3_RX 4  // activation ring slots, filled V3_DX units ahead
+#define V3_DX 3
 #define V3_MAX_SLOTS 12
 #define V3_FRAG 1024                  // floats of one (row group, batch half) partial: 16 per lane
 #define V3_SLAB (V3_BN * V3_BM)       // floats per (tile, contributor)
-#define V3_A_ROW 272                  // padded x-tile row (conflict-free ds_read_b128 across 16 rows)
-#define V3_A_TILE (V3_BM * V3_A_ROW)  // 17408
-#define V3_OFF_A 0                    // two x tiles
-#define V3_OFF_R (2 * V3_A_TILE)      // k-half exchange: 4 row groups x 2 batch halves x 4 KB
+#define V3_W_SLOT 9216                // 8 KB of packed weights (one KB per consumer wave) + 1 KB of scale pairs
+#define V3_X_SLOT 16384               // [64 rows][16 x 16 B], slot j of row r stored at j ^ (r & 15)
+#define V3_OFF_W 0
+#define V3_OFF_X (V3_RW * V3_W_SLOT)
+#define V3_OFF_R (V3_OFF_X + V3_RX * V3_X_SLOT)  // k-half exchange: 4 row groups x 2 batch halves x 4 KB
 #define V3_LDS_BYTES (V3_OFF_R + 8 * 4096)
 #define V3_SPIN_LIMIT (1 << 18)
 
@@ -62,7 +69,20 @@ struct V3Params {
   int gt, gbase, grem, glead;  // tile-group split, see v3_plan
   int gshift;                  // log2(group_size / 128)
   int epi;                     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu
+#ifdef V3_TIMELINE
+  unsigned long long* tl;  // debug: [workgroup][64] s_memrealtime stamps of wave LL_GEMM3_TL_WAVE (benchmarks/gemm3_timeline.py)
+  int tlwave;
+#endif
 };
+
+// debug timeline (-DV3_TIMELINE): 0 entry, 1 ranges decoded, 2 prologue loads issued, 3 first x tile staged + barrier,
+// 4 + u: barrier that ends unit u (u < 40), 50..55 last segment end: begin / exchanged / counter seen / slabs added /
+// stores issued / -, 60 wave done
+#ifdef V3_TIMELINE
+#define V3_TL(IDX) if (p.tl && lane == 0 && wv == p.tlwave) p.tl[(size_t)blockIdx.x * 64 + (IDX)] = __builtin_amdgcn_s_memrealtime();
+#else
+#define V3_TL(IDX)
+#endif
 
 __device__ __forceinline__ uint32_t v3_pk_add(uint32_t a, uint32_t b) {
   return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) + __builtin_bit_cast(f16x2, b));
@@ -100,23 +120,146 @@ __device__ __forceinline__ f16x8 v3_dequant(uint32_t w, uint32_t s, uint32_t nzs
   return __builtin_bit_cast(f16x8, o);
 }
 
-__device__ __forceinline__ __amdgpu_buffer_rsrc_t v3_rsrc(const void* p, uint32_t bytes) {
-  return __builtin_amdgcn_make_buffer_rsrc(const_cast<void*>(p), (short)0, (int)bytes, 0x00020000);
-}
 
 // Scalar cursor over the workgroup's unit sequence: up to three segments (tail of the last tile, the
 // full tiles, head of the first tile), each a run of consecutive chunks that wraps into the next tile.
 struct V3Cur {
   int t, c, left, seg;
 };
+struct V3Seq {
+  int chunks;
+  int t0, c0, n0, t1, c1, n1, t2, c2, n2;
+};
+__device__ __forceinline__ void v3_advance(V3Cur& cu, const V3Seq& q) {  // selects only
+  const int c1 = cu.c + 1;
+  const bool wrap = c1 == q.chunks;
+  const int left = cu.left - 1;
+  const bool nextseg = left == 0;
+  const int s = cu.seg + (nextseg ? 1 : 0);
+  const int nt = s == 1 ? q.t1 : q.t2, nc = s == 1 ? q.c1 : (s == 2 ? q.c2 : 0);
+  const int nn = s == 1 ? q.n1 : (s == 2 ? q.n2 : 0);
+  cu.t = nextseg ? nt : (wrap ? cu.t + 1 : cu.t);
+  cu.c = nextseg ? nc : (wrap ? 0 : c1);
+  cu.left = nextseg ? (nn == 0 ? 0x40000000 : nn) : left;  // past the end: stays there
+  cu.seg = s;
+}
+
+// LDS-DMA: 64 lanes x 16 B (or 4 B) from saddr + voff to the wave-uniform LDS byte address lds_dst + lane * size.
+// M0 carries the LDS address and is compiler-reserved: saved and restored inside the statement.
+__device__ __forceinline__ const void* v3_uniform_ptr(const void* p) {  // provably wave-uniform for the "s" constraint
+  const uint64_t a = (uint64_t)p;
+  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
+  return (const void*)(((uint64_t)hi << 32) | lo);
+}
+__device__ __forceinline__ void v3_dma16(uint32_t lds_dst, const void* sbase, uint32_t voff) {
+  uint32_t keep;
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  sbase = v3_uniform_ptr(sbase);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
+__device__ __forceinline__ void v3_dma4(uint32_t lds_dst, const void* sbase, uint32_t voff) {
+  uint32_t keep;
+  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
+  sbase = v3_uniform_ptr(sbase);
+  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+               : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+}
+template <int N>
+__device__ __forceinline__ void v3_vmcnt() {
+  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
+}
+// at most k units of OPS memory operations each may still be in flight
+template <int OPS>
+__device__ __forceinline__ void v3_wait_units(int k) {
+  if (k <= 0) v3_vmcnt<0>();
+  else if (k == 1) v3_vmcnt<OPS>();
+  else if (k == 2) v3_vmcnt<2 * OPS>();
+  else v3_vmcnt<3 * OPS>();
+}
+__device__ __forceinline__ void v3_barrier() { asm volatile("s_barrier" ::: "memory"); }
+
+// One loader wave.  KIND 0: weight pieces 4L..4L+3 (1 KB each) + scale quarters 2L, 2L+1 (256 B each) of every
+// unit, V3_DW units ahead into a V3_RW-slot ring.  KIND 1: activation pieces 8L..8L+7 (4 rows x 256 B each),
+// V3_DX units ahead into a V3_RX-slot ring; LDS image row r, 16-B slot j <- source slot j ^ (r & 15).
+template <int KIND>
+__device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int cnt, int lane, int L) {
+  constexpr int OPS = KIND == 0 ? 6 : 8;
+  constexpr int D = KIND == 0 ? V3_DW : V3_DX;
+  constexpr int R = KIND == 0 ? V3_RW : V3_RX;
+  static_assert(D - 2 <= 3 && D <= R - 1, "ring depth");
+  uint32_t voff[8];
+  if constexpr (KIND == 0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) voff[j] = (uint32_t)(lane * 16 + (4 * L + j) * 1024);
+#pragma unroll
+    for (int j = 0; j < 2; ++j) voff[4 + j] = (uint32_t)(lane * 4 + (2 * L + j) * 256);
+    voff[6] = voff[7] = 0;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 8; ++j) {
+      int64_t r = (8 * L + j) * 4 + (lane >> 4);
+      const int slot = (lane & 15) ^ (int)(r & 15);
+      if (r >= p.m) r = p.m - 1;  // rows >= M feed only unstored outputs
+      voff[j] = (uint32_t)(r * p.x_stride * 2 + slot * 16);
+    }
+  }
+  V3Cur lc{q.t0, q.c0, q.n0, 0};
+  int issued = 0, slot = 0;
+  auto issue = [&]() {
+    if constexpr (KIND == 0) {
+      const uint32_t dst = (uint32_t)(V3_OFF_W + slot * V3_W_SLOT);
+      const char* wb = (const char*)p.wp + (size_t)(uint32_t)((lc.t * q.chunks + lc.c) * (V3_BN * V3_CK / 2));
+      const char* sb = (const char*)p.sp + (size_t)(uint32_t)(((lc.c >> p.gshift) * (int)p.n + lc.t * V3_BN) * 8);
+#if !(defined(V3_ABLATE) && (V3_ABLATE & 2))
+#pragma unroll
+      for (int j = 0; j < 4; ++j) v3_dma16(dst + (4 * L + j) * 1024, wb, voff[j]);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) v3_dma4(dst + 8192 + (2 * L + j) * 256, sb, voff[4 + j]);
+#endif
+    } else {
+      const uint32_t dst = (uint32_t)(V3_OFF_X + slot * V3_X_SLOT);
+      const char* xb = (const char*)p.x + (size_t)(uint32_t)(lc.c * (V3_CK * 2));
+#if !(defined(V3_ABLATE) && (V3_ABLATE & 1))
+#pragma unroll
+      for (int j = 0; j < 8; ++j) v3_dma16(dst + (8 * L + j) * 1024, xb, voff[j]);
+#endif
+    }
+    v3_advance(lc, q);
+    ++issued;
+    slot = slot + 1 == R ? 0 : slot + 1;
+  };
+  const int pre = cnt < D ? cnt : D;
+  for (int i = 0; i < pre; ++i) issue();
+  v3_wait_units<OPS>(issued - (cnt < 2 ? cnt : 2));  // units 0 and 1 have landed
+  v3_barrier();
+  V3Cur cc{q.t0, q.c0, q.n0, 0};
+  for (int u = 0; u < cnt; ++u) {
+    if (issued < cnt) issue();
+    const int need = cnt < u + 3 ? cnt : u + 3;  // after barrier u the consumers may touch units <= u + 2
+    v3_wait_units<OPS>(issued - need);
+    v3_barrier();
+    const bool se = (cc.c == q.chunks - 1) | (cc.left == 1);
+    if (se) v3_barrier();  // the consumers' k-half exchange
+    v3_advance(cc, q);
+  }
+}
 
 template <int MT>
-__global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgemm3_kernel(const V3Params p) {
+struct V3Ops {  // everything a consumer wave needs for one unit
+  u32x4 w;
+  u32x2 s;
+  f16x8 a[4][MT];
+};
+
+template <int MT>
+__global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgemm3_kernel(const V3Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
   const int lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chunks = p.chunks;
+  V3_TL(0)
   int ub, ue;
   if (p.gt) {
     const int gtile = (int)blockIdx.x / p.gt, j = (int)blockIdx.x - gtile * p.gt;
@@ -130,8 +273,8 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   }
   if (ub >= ue) return;
   const int cnt = ue - ub;
-  const int tA = ub / chunks, cA = ub - tA * chunks;
-  const int tZ = (ue - 1) / chunks, cZ = (ue - 1) - tZ * chunks;
+  const int tA = (int)((uint32_t)ub / (uint32_t)chunks), cA = ub - tA * chunks;
+  const int tZ = (int)((uint32_t)(ue - 1) / (uint32_t)chunks), cZ = (ue - 1) - tZ * chunks;
   int LT = 0, LH = cnt;  // a range inside one tile runs as a single "head" segment
   if (tA != tZ) {
     LT = (cZ != chunks - 1) ? cZ + 1 : 0;
@@ -141,75 +284,28 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   const int tF = tA + ((LH > 0 && tA != tZ) ? 1 : 0);
   // segments in execution order, empty ones squeezed out (selects only: a runtime-indexed array would live in scratch)
   const bool hasT = LT > 0, hasF = NF > 0;
-  const int sg_t0 = hasT ? tZ : (hasF ? tF : tA), sg_c0 = hasT ? 0 : (hasF ? 0 : cA), sg_n0 = hasT ? LT : (hasF ? NF : LH);
-  const int sg_t1 = (hasT && hasF) ? tF : tA, sg_c1 = (hasT && hasF) ? 0 : cA;
-  const int sg_n1 = hasT ? (hasF ? NF : LH) : (hasF ? LH : 0);
-  const int sg_t2 = tA, sg_c2 = cA, sg_n2 = (hasT && hasF) ? LH : 0;
-  auto cur_advance = [&](V3Cur& cu) {  // selects only (scalar ALU, no branches between the loads)
-    const int c1 = cu.c + 1;
-    const bool wrap = c1 == chunks;
-    const int left = cu.left - 1;
-    const bool nextseg = left == 0;
-    const int s = cu.seg + (nextseg ? 1 : 0);
-    const int nt = s == 1 ? sg_t1 : sg_t2, nc = s == 1 ? sg_c1 : (s == 2 ? sg_c2 : 0);
-    const int nn = s == 1 ? sg_n1 : (s == 2 ? sg_n2 : 0);
-    cu.t = nextseg ? nt : (wrap ? cu.t + 1 : cu.t);
-    cu.c = nextseg ? nc : (wrap ? 0 : c1);
-    cu.left = nextseg ? (nn == 0 ? 0x40000000 : nn) : left;  // past the end: stays there
-    cu.seg = s;
-  };
+  V3Seq q;
+  q.chunks = chunks;
+  q.t0 = hasT ? tZ : (hasF ? tF : tA); q.c0 = hasT ? 0 : (hasF ? 0 : cA); q.n0 = hasT ? LT : (hasF ? NF : LH);
+  q.t1 = (hasT && hasF) ? tF : tA; q.c1 = (hasT && hasF) ? 0 : cA; q.n1 = hasT ? (hasF ? NF : LH) : (hasF ? LH : 0);
+  q.t2 = tA; q.c2 = cA; q.n2 = (hasT && hasF) ? LH : 0;
+  V3_TL(1)
 
+  if (wv >= 8) {
+    // ======================================== loaders ======================================== //
+    if (wv < 10) v3_loader<0>(p, q, cnt, lane, wv - 8);
+    else v3_loader<1>(p, q, cnt, lane, wv - 10);
+    return;
+  }
+
+  // ======================================= consumers ======================================= //
   const int ng = wv & 3, kh = wv >> 2;
   const int nl = lane & 31, h = lane >> 5;
-
-  // fixed per-lane byte offsets of the three streams
-  const int w_voff = (wv * 64 + lane) * 16;
-  const int s_voff = (ng * 32 + nl) * 8;
-  int x_voff[2];
+  const int w_off = wv * 1024 + lane * 16;
+  const int s_off = 8192 + (ng * 32 + nl) * 8;
+  int x_off[4];
 #pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int64_t row = (wv * 2 + j) * 4 + (lane >> 4);
-    x_voff[j] = row < p.m ? (int)(row * p.x_stride * 2 + (lane & 15) * 16) : 0x7FFFFFF0;  // rows >= M read as zeros
-  }
-  const int x_lds = ((wv * 2) * 4 + (lane >> 4)) * V3_A_ROW + (lane & 15) * 16;  // + j * 4 rows
-
-  // register ring
-  u32x4 rW[V3_R];
-  u32x2 rS[V3_R];
-  u32x4 rX[V3_R][2];
-
-  V3Cur lc{sg_t0, sg_c0, sg_n0, 0};  // load cursor
-  int lleft = cnt;                         // units the load cursor still has to request
-  auto load_x = [&](int i) {
-    const bool live = lleft > 0;
-    const __amdgpu_buffer_rsrc_t rx = v3_rsrc(p.x, live ? p.x_bytes : 0u);
-    const int so = live ? lc.c * (V3_CK * 2) : 0;
-    rX[i][0] = __builtin_amdgcn_raw_buffer_load_b128(rx, x_voff[0], so, 0);
-    rX[i][1] = __builtin_amdgcn_raw_buffer_load_b128(rx, x_voff[1], so, 0);
-  };
-  auto load_w = [&](int i) {
-    const bool live = lleft > 0;
-    const __amdgpu_buffer_rsrc_t rw = v3_rsrc(p.wp, live ? p.w_bytes : 0u);
-    const __amdgpu_buffer_rsrc_t rs = v3_rsrc(p.sp, live ? p.s_bytes : 0u);
-    const int wo = live ? (lc.t * chunks + lc.c) * (V3_BN * V3_CK / 2) : 0;
-    const int so = live ? ((lc.c >> p.gshift) * (int)p.n + lc.t * V3_BN) * 8 : 0;
-    rW[i] = __builtin_amdgcn_raw_buffer_load_b128(rw, w_voff, wo, 0);
-    rS[i] = __builtin_amdgcn_raw_buffer_load_b64(rs, s_voff, so, 0);
-    cur_advance(lc);
-    lleft -= 1;
-  };
-  auto stage_x = [&](int i, int slot) {
-    unsigned char* dst = lds + V3_OFF_A + slot * V3_A_TILE + x_lds;
-    *reinterpret_cast<u32x4*>(dst) = rX[i][0];
-    *reinterpret_cast<u32x4*>(dst + 4 * V3_A_ROW) = rX[i][1];
-  };
-
-  // ------------------------------ prologue: V3_R units requested at once ------------------------------ //
-#pragma unroll
-  for (int i = 0; i < V3_R; ++i) {
-    load_x(i);
-    load_w(i);
-  }
+  for (int j = 0; j < 4; ++j) x_off[j] = nl * 256 + (((kh * 8 + h * 4 + j) ^ (nl & 15)) * 16);
 
   uint32_t magic = 0x64006400u;
   asm volatile("" : "+v"(magic));
@@ -219,9 +315,9 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
   };
   zero_acc();
-  const int aoff = nl * V3_A_ROW + kh * 128 + h * 64;
 
   // contribution counter of a parked partial, posted once its write-through stores have landed
+  // (the consumers have no other memory operation in flight: vmcnt(0) waits for exactly those stores)
   int32_t* pend_ctr = nullptr;
   int pend_val = 0;
   auto post_pending = [&]() {
@@ -241,9 +337,9 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       float* ws = p.workspace + ((((int64_t)t * p.slots + slot) * 4 + ng) * 2 + mt) * V3_FRAG;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 q = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+        const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
         float* dst = ws + (g * 64 + lane) * 4;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(q) : "memory");
+        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(o) : "memory");
       }
       pend_ctr = ctr;
       pend_val = c_hi - c_lo + 1;
@@ -257,33 +353,35 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
         __builtin_amdgcn_s_sleep(4);
       }
       if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      V3_TL(52)
       // slabs were written through (sc1) before their counter: coherent (sc1) loads, no acquire fence.
       // Four slabs in flight per round trip; the tail of the last round is masked to +0.
       for (int sl = 0; sl < slot; sl += 4) {
         i32x4 va[4][4];
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int sq = sl + q < slot ? sl + q : sl;
+        for (int j = 0; j < 4; ++j) {
+          const int sq = sl + j < slot ? sl + j : sl;
           const float* src = p.workspace + ((((int64_t)t * p.slots + sq) * 4 + ng) * 2 + mt) * V3_FRAG + lane * 4;
 #pragma unroll
           for (int g = 0; g < 4; ++g)
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(va[q][g]) : "v"(src + g * 256) : "memory");
+            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(va[j][g]) : "v"(src + g * 256) : "memory");
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int q = 0; q < 4; ++q)
+        for (int j = 0; j < 4; ++j)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(va[q][g]));  // uses stay below the wait
+          for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(va[j][g]));  // uses stay below the wait
 #pragma unroll
-        for (int q = 0; q < 4; ++q) {
-          const int keep = sl + q < slot ? -1 : 0;
+        for (int j = 0; j < 4; ++j) {
+          const int keep = sl + j < slot ? -1 : 0;
 #pragma unroll
           for (int g = 0; g < 4; ++g)
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * g + e] += __int_as_float(va[q][g][e] & keep);
+            for (int e = 0; e < 4; ++e) v[4 * g + e] += __int_as_float(va[j][g][e] & keep);
         }
       }
     }
+    V3_TL(53)
     const int64_t mrow = nl + mt * 32;
     if (mrow >= p.m) return;
     const bool has_bias = p.bias != nullptr;
@@ -318,6 +416,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   // that wave kh ends up with the complete sums of batch half kh (MT = 2), or kh = 0 with everything (MT = 1).
   auto segment_end = [&](int t, int c_lo, int c_hi) {
     float* red = reinterpret_cast<float*>(lds + V3_OFF_R) + ng * (2 * V3_FRAG);
+    V3_TL(50)
     auto put = [&](const f32x16& a, int half) {
 #pragma unroll
       for (int g = 0; g < 4; ++g)
@@ -327,9 +426,9 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     auto get_add = [&](f32x16& a, int half) {
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const f32x4 q = *reinterpret_cast<const f32x4*>(red + half * V3_FRAG + (g * 64 + lane) * 4);
+        const f32x4 o = *reinterpret_cast<const f32x4*>(red + half * V3_FRAG + (g * 64 + lane) * 4);
 #pragma unroll
-        for (int e = 0; e < 4; ++e) a[4 * g + e] += q[e];
+        for (int e = 0; e < 4; ++e) a[4 * g + e] += o[e];
       }
     };
     if constexpr (MT == 2) {
@@ -341,6 +440,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
       }
       put(give, 1 - kh);
       asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+      V3_TL(51)
       get_add(v, kh);
       flush(v, kh, t, c_lo, c_hi);
     } else {
@@ -354,60 +454,67 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     zero_acc();
   };
 
-  auto compute = [&](int i, int slot) {
-    const unsigned char* ab = lds + V3_OFF_A + slot * V3_A_TILE + aoff;
-    f16x8 af[4][MT];
+  auto read_ops = [&](V3Ops<MT>& o, int wslot, int xslot) {
+    const unsigned char* wb = lds + V3_OFF_W + wslot * V3_W_SLOT;
+    const unsigned char* xb = lds + V3_OFF_X + xslot * V3_X_SLOT;
+    o.w = *reinterpret_cast<const u32x4*>(wb + w_off);
+    o.s = *reinterpret_cast<const u32x2*>(wb + s_off);
 #pragma unroll
-    for (int s = 0; s < 4; ++s)
+    for (int j = 0; j < 4; ++j)
 #pragma unroll
-      for (int mt = 0; mt < MT; ++mt) af[s][mt] = *reinterpret_cast<const f16x8*>(ab + mt * 32 * V3_A_ROW + s * 16);
-    __builtin_amdgcn_sched_barrier(0);  // all fragment reads in flight before the first dequant (hipcc sinks them to their use otherwise)
+      for (int mt = 0; mt < MT; ++mt) o.a[j][mt] = *reinterpret_cast<const f16x8*>(xb + x_off[j] + mt * 32 * 256);
+  };
+  auto compute = [&](const V3Ops<MT>& o) {
+#if defined(V3_ABLATE) && (V3_ABLATE & 4)
+    asm volatile("" ::"v"(o.a[0][0]), "v"(o.a[3][MT - 1]), "v"(o.w), "v"(o.s));
+    return;
+#endif
 #pragma unroll
-    for (int s = 0; s < 4; ++s) {
-      const uint32_t word = s == 0 ? rW[i].x : s == 1 ? rW[i].y : s == 2 ? rW[i].z : rW[i].w;
-      const f16x8 wfrag = v3_dequant(word, rS[i].x, rS[i].y, magic);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, af[s][0], acc0, 0, 0, 0);
-      if constexpr (MT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, af[s][1], acc1, 0, 0, 0);
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t word = j == 0 ? o.w.x : j == 1 ? o.w.y : j == 2 ? o.w.z : o.w.w;
+      const f16x8 wfrag = v3_dequant(word, o.s.x, o.s.y, magic);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, o.a[j][0], acc0, 0, 0, 0);
+      if constexpr (MT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, o.a[j][1], acc1, 0, 0, 0);
     }
   };
 
-  V3Cur cc{sg_t0, sg_c0, sg_n0, 0};  // compute cursor
+  V3Cur cc{q.t0, q.c0, q.n0, 0};
   int seg_lo = cc.c;
-  int slot = 0;
   int done = 0;
-  stage_x(0, 0);
-  __syncthreads();
+  int wslot = 1, xslot = 1;  // ring slots of unit done + 1
+  V3Ops<MT> opA, opB;
+  v3_barrier();  // units 0 and 1 have landed
+  V3_TL(3)
+  read_ops(opA, 0, 0);
 
-  // One unit.  Ring set I holds unit `done`; set (I + 1) % R the next unit, whose x eighth is staged now
-  // into the other LDS tile (every wave left that tile at the barrier that ended the previous unit).
-#define V3_STEP(I)                                                                          \
+  // One unit: the operands of unit `done` are in CUR (read during the previous unit); the operands of the next
+  // unit are read into NXT first -- they landed before the barrier that ended the previous unit -- and stay in
+  // flight across this unit's barrier.
+#define V3_STEP(CUR, NXT)                                                                   \
   {                                                                                         \
-    stage_x(((I) + 1) % V3_R, slot ^ 1);                                                    \
-    load_x(I);                                                                              \
-    compute(I, slot);                                                                       \
-    load_w(I);                                                                              \
-    asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");                         \
+    read_ops(NXT, wslot, xslot);                                                            \
+    __builtin_amdgcn_sched_barrier(0); /* keep the reads up here (hipcc sinks them to their use otherwise) */ \
+    wslot = wslot + 1 == V3_RW ? 0 : wslot + 1;                                             \
+    xslot = xslot + 1 == V3_RX ? 0 : xslot + 1;                                             \
+    compute(CUR);                                                                           \
+    v3_barrier();                                                                           \
+    if (done < 40) { V3_TL(4 + done) }                                                      \
     if (pend_ctr) post_pending(); /* the previous segment's slab stores are a unit old */   \
     const bool se_ = (cc.c == chunks - 1) | (cc.left == 1);                                 \
     if (se_) segment_end(cc.t, seg_lo, cc.c);                                               \
-    cur_advance(cc);                                                                        \
+    v3_advance(cc, q);                                                                      \
     if (se_) seg_lo = cc.c;                                                                 \
-    slot ^= 1;                                                                              \
     ++done;                                                                                 \
   }
-  for (int it = cnt / V3_R; it > 0; --it) {
-    V3_STEP(0)
-    V3_STEP(1)
-    V3_STEP(2)
-    V3_STEP(3)
-    V3_STEP(4)
+  for (;;) {
+    V3_STEP(opA, opB)
+    if (done >= cnt) break;
+    V3_STEP(opB, opA)
+    if (done >= cnt) break;
   }
-  if (done < cnt) V3_STEP(0)
-  if (done < cnt) V3_STEP(1)
-  if (done < cnt) V3_STEP(2)
-  if (done < cnt) V3_STEP(3)
 #undef V3_STEP
   if (pend_ctr) post_pending();
+  V3_TL(60)
 }
 
 // ---------------------------------------------------------------------------------- //
@@ -568,6 +675,10 @@ extern "C" int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* w
   p.nblocks = pl.nblocks; p.chunks = pl.chunks; p.total_units = pl.total_units; p.upw = pl.upw; p.slots = pl.slots;
   p.gt = pl.gt; p.gbase = pl.gbase; p.grem = pl.grem; p.glead = pl.glead;
   p.epi = epilogue;
+#ifdef V3_TIMELINE
+  p.tlwave = getenv("LL_GEMM3_TL_WAVE") ? atoi(getenv("LL_GEMM3_TL_WAVE")) : 0;
+  p.tl = getenv("LL_GEMM3_TIMELINE") ? (unsigned long long*)strtoull(getenv("LL_GEMM3_TIMELINE"), nullptr, 16) : nullptr;
+#endif
   int sh = 0;
   while ((128 << sh) < group_size) ++sh;
   p.gshift = sh;
