@@ -24,8 +24,9 @@ for name, n, k, epi in shapes:
     pw = [Q.pack_w4a16_weights(w[0]) for w in ws]
 
     def call(eng, i):
-        if eng == "v3":
-            return Q.w4a16_matmul_prepacked(x, pw[i], ps[i], group_size=128, gate_up_swiglu=bool(epi))
+        if eng.startswith("v3"):  # v3 = host plan, v3a / v3b = 128- / 256-row tiles forced
+            tb = {"v3": 0, "v3a": 1, "v3b": 2}[eng]
+            return Q.w4a16_matmul_prepacked(x, pw[i], ps[i], group_size=128, gate_up_swiglu=bool(epi), _tile_blocks=tb)
         if epi:
             return Q.w4a16_gate_up_swiglu(x, *ws[i], group_size=128, packed_scales=ps[i])
         return K.w4a16_matmul(x, *ws[i], group_size=128, packed_scales=ps[i])

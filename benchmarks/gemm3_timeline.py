@@ -54,4 +54,14 @@ for name, n, k, epi in shapes:
             last = torch.gather(t[:, 4:44], 1, (nun.clamp(min=1) - 1).long().unsqueeze(1)).squeeze(1)
             period = ((last - t[:, 4]) / (nun - 1).clamp(min=1) / 100.0)[rows]
             print(f"  units/workgroup {int(nun.min())}..{int(nun.max())}; unit period median {period.median():.3f} us (min {period.min():.3f}, max {period.max():.3f})")
+        cyc = (t[:, 62] - t[:, 61]); rt = (t[:, 60] - t[:, 0]) / 100.0
+        ok = (t[:, 62] > 0) & (rt > 0)
+        if ok.any():
+            print(f"  shader clock over the wave's life: median {(cyc[ok] / rt[ok]).median() / 1e3:.2f} GHz")
+        c = t[:, 44:49]
+        m = (c > 0).all(1)
+        if m.any():
+            d = (c[m, 1:] - c[m, :-1])
+            print("  unit 3, shader cycles (median): reads issued %d | compute issued %d | barrier %d | bookkeeping %d | step total %d" % (
+                d[:, 0].median(), d[:, 1].median(), d[:, 2].median(), d[:, 3].median(), (c[m, 4] - c[m, 0]).median()))
         print(f"  last segment end: begin {stat(50)} exchanged {stat(51)} counter seen {stat(52)} merged {stat(53)} | wave done {stat(60)}")

@@ -192,8 +192,9 @@ int ll_w4a16_gateup_swiglu(void* out, const void* x, const int32_t* qweight, con
  * qweight [N, K/8] into the order the M <= 64 kernel streams it (per (128-row tile, 128-k chunk) 8 KB =
  * [wave 8][lane 64] x 16 B; inside a word even nibbles first).  packed: n * k / 2 bytes, n % 128 == 0,
  * k % 128 == 0.  ll_w4a16_matmul_prepacked consumes it together with ll_w4a16_pack_scales' output
- * (group_size = 128 * 2^j); epilogue 0 = w4a16_matmul, 1 = the gate/up + swiglu fusion above.  Same
- * arithmetic as ll_w4a16_matmul (only the fp32 summation order differs). */
+ * (group_size = 128 * 2^j); epilogue bit 0: 0 = w4a16_matmul, 1 = the gate/up + swiglu fusion above; bits 8-9
+ * (tests / tuning): 0 = tile width chosen by the host plan, 1 / 2 = force 128- / 256-row tiles (256 needs
+ * n % 256 == 0).  Same arithmetic as ll_w4a16_matmul (only the fp32 summation order differs). */
 int ll_w4a16_pack_weights(void* packed, const int32_t* qweight, int64_t n, int64_t k, int64_t qw_stride_n,
                           void* stream);
 int ll_w4a16_prepacked_supported(int64_t m, int64_t n, int64_t k, int group_size); /* 1 / 0 */

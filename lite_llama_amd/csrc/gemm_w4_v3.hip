@@ -36,19 +36,27 @@
 #define V3_BM 64
 #define V3_CK 128
 #define V3_THREADS 768
-#define V3_RW 6  // weight + scale ring slots (LDS), filled V3_DW units ahead
-#define V3_DW 5
-#define V3_RX 4  // activation ring slots, filled V3_DX units ahead
-#define V3_DX 3
+// LDS rings per tile width (NF = 128-row blocks per tile).  NF = 1: weights + scales 6 slots filled 5 units
+// ahead, activations 4 slots / 3 ahead, consumers read one unit ahead of their MFMAs.  NF = 2 (256-row tiles,
+// one activation tile feeds two weight blocks): weights 4 slots / 3 ahead, activations 3 slots / 2 ahead, the
+// consumers read a unit's operands at its start (a step is twice as long, the LDS latency is paid once).
+template <int NF> struct V3Ring;
+template <> struct V3Ring<1> { static constexpr int RW = 6, DW = 5, RX = 4, DX = 3, RA = 1; };
+template <> struct V3Ring<2> { static constexpr int RW = 4, DW = 3, RX = 3, DX = 2, RA = 0; };
 #define V3_MAX_SLOTS 12
 #define V3_FRAG 1024                  // floats of one (row group, batch half) partial: 16 per lane
 #define V3_SLAB (V3_BN * V3_BM)       // floats per (tile, contributor)
-#define V3_W_SLOT 9216                // 8 KB of packed weights (one KB per consumer wave) + 1 KB of scale pairs
+#define V3_W_BLOCK 9216               // 8 KB of packed weights (one KB per consumer wave) + 1 KB of scale pairs
 #define V3_X_SLOT 16384               // [64 rows][16 x 16 B], slot j of row r stored at j ^ (r & 15)
-#define V3_OFF_W 0
-#define V3_OFF_X (V3_RW * V3_W_SLOT)
-#define V3_OFF_R (V3_OFF_X + V3_RX * V3_X_SLOT)  // k-half exchange: 4 row groups x 2 batch halves x 4 KB
-#define V3_LDS_BYTES (V3_OFF_R + 8 * 4096)
+template <int NF>
+struct V3Lds {
+  static constexpr int W_SLOT = NF * V3_W_BLOCK;
+  static constexpr int OFF_W = 0;
+  static constexpr int OFF_X = V3Ring<NF>::RW * W_SLOT;
+  static constexpr int OFF_R = OFF_X + V3Ring<NF>::RX * V3_X_SLOT;  // k-half exchange: 4 row groups x 2 batch halves x 4 KB
+  static constexpr int BYTES = OFF_R + 8 * 4096;
+  static_assert(BYTES <= 160 * 1024, "LDS");
+};
 #define V3_SPIN_LIMIT (1 << 18)
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
@@ -80,8 +88,10 @@ struct V3Params {
 // stores issued / -, 60 wave done
 #ifdef V3_TIMELINE
 #define V3_TL(IDX) if (p.tl && lane == 0 && wv == p.tlwave) p.tl[(size_t)blockIdx.x * 64 + (IDX)] = __builtin_amdgcn_s_memrealtime();
+#define V3_TLC(IDX) if (p.tl && lane == 0 && wv == p.tlwave) p.tl[(size_t)blockIdx.x * 64 + (IDX)] = __builtin_amdgcn_s_memtime();
 #else
 #define V3_TL(IDX)
+#define V3_TLC(IDX)
 #endif
 
 __device__ __forceinline__ uint32_t v3_pk_add(uint32_t a, uint32_t b) {
@@ -121,27 +131,39 @@ __device__ __forceinline__ f16x8 v3_dequant(uint32_t w, uint32_t s, uint32_t nzs
 }
 
 
-// Scalar cursor over the workgroup's unit sequence: up to three segments (tail of the last tile, the
-// full tiles, head of the first tile), each a run of consecutive chunks that wraps into the next tile.
-struct V3Cur {
-  int t, c, left, seg;
-};
+// The workgroup's unit sequence: up to three segments (tail of the last tile, the full tiles, head of the
+// first tile), each a run of consecutive chunks that wraps into the next tile.  A walker keeps (tile, chunk)
+// and two countdowns; the per-unit path is three scalar adds and two compares, the fix-up at the end of a tile
+// or segment is a (rare) branch.
 struct V3Seq {
   int chunks;
   int t0, c0, n0, t1, c1, n1, t2, c2, n2;
 };
-__device__ __forceinline__ void v3_advance(V3Cur& cu, const V3Seq& q) {  // selects only
-  const int c1 = cu.c + 1;
-  const bool wrap = c1 == q.chunks;
-  const int left = cu.left - 1;
-  const bool nextseg = left == 0;
-  const int s = cu.seg + (nextseg ? 1 : 0);
-  const int nt = s == 1 ? q.t1 : q.t2, nc = s == 1 ? q.c1 : (s == 2 ? q.c2 : 0);
-  const int nn = s == 1 ? q.n1 : (s == 2 ? q.n2 : 0);
-  cu.t = nextseg ? nt : (wrap ? cu.t + 1 : cu.t);
-  cu.c = nextseg ? nc : (wrap ? 0 : c1);
-  cu.left = nextseg ? (nn == 0 ? 0x40000000 : nn) : left;  // past the end: stays there
-  cu.seg = s;
+struct V3Walk {
+  int t, c, seg_left, tile_left, seg;
+};
+__device__ __forceinline__ V3Walk v3_walk_begin(const V3Seq& q) { return V3Walk{q.t0, q.c0, q.n0, q.chunks - q.c0, 0}; }
+// true when the unit the walker stands on ends a tile segment (last chunk of the tile or of the segment)
+__device__ __forceinline__ bool v3_walk_ends(const V3Walk& w) { return (w.tile_left == 1) | (w.seg_left == 1); }
+__device__ __forceinline__ void v3_walk_next(V3Walk& w, const V3Seq& q) {
+  const bool ends = v3_walk_ends(w);
+  w.c += 1;
+  w.tile_left -= 1;
+  w.seg_left -= 1;
+  if (ends) {
+    if (w.seg_left == 0) {
+      w.seg += 1;
+      const int s = w.seg;
+      w.t = s == 1 ? q.t1 : q.t2;
+      w.c = s == 1 ? q.c1 : (s == 2 ? q.c2 : 0);
+      const int n = s == 1 ? q.n1 : (s == 2 ? q.n2 : 0);
+      w.seg_left = n == 0 ? 0x40000000 : n;  // past the end: stays there
+    } else {
+      w.t += 1;
+      w.c = 0;
+    }
+    w.tile_left = q.chunks - w.c;
+  }
 }
 
 // LDS-DMA: 64 lanes x 16 B (or 4 B) from saddr + voff to the wave-uniform LDS byte address lds_dst + lane * size.
@@ -177,17 +199,24 @@ __device__ __forceinline__ void v3_wait_units(int k) {
   else if (k == 2) v3_vmcnt<2 * OPS>();
   else v3_vmcnt<3 * OPS>();
 }
+#if defined(V3_ABLATE) && (V3_ABLATE & 64)
+__device__ __forceinline__ void v3_barrier() { asm volatile("" ::: "memory"); }  // debug: no unit barriers
+#else
 __device__ __forceinline__ void v3_barrier() { asm volatile("s_barrier" ::: "memory"); }
+#endif
 
 // One loader wave.  KIND 0: weight pieces 4L..4L+3 (1 KB each) + scale quarters 2L, 2L+1 (256 B each) of every
 // unit, V3_DW units ahead into a V3_RW-slot ring.  KIND 1: activation pieces 8L..8L+7 (4 rows x 256 B each),
 // V3_DX units ahead into a V3_RX-slot ring; LDS image row r, 16-B slot j <- source slot j ^ (r & 15).
-template <int KIND>
+template <int KIND, int NF>
 __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int cnt, int lane, int L) {
-  constexpr int OPS = KIND == 0 ? 6 : 8;
-  constexpr int D = KIND == 0 ? V3_DW : V3_DX;
-  constexpr int R = KIND == 0 ? V3_RW : V3_RX;
-  static_assert(D - 2 <= 3 && D <= R - 1, "ring depth");
+  using RG = V3Ring<NF>;
+  using LD = V3Lds<NF>;
+  constexpr int OPS = KIND == 0 ? 6 * NF : 8;
+  constexpr int D = KIND == 0 ? RG::DW : RG::DX;
+  constexpr int R = KIND == 0 ? RG::RW : RG::RX;
+  constexpr int AHEAD = 1 + RG::RA;  // after barrier u the consumers may touch units <= u + AHEAD
+  static_assert(D - AHEAD <= 3 && D - AHEAD >= 1 && D <= R - 1 && 3 * OPS <= 63, "ring depth");
   uint32_t voff[8];
   if constexpr (KIND == 0) {
 #pragma unroll
@@ -204,55 +233,61 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
       voff[j] = (uint32_t)(r * p.x_stride * 2 + slot * 16);
     }
   }
-  V3Cur lc{q.t0, q.c0, q.n0, 0};
-  int issued = 0, slot = 0;
+  V3Walk lc = v3_walk_begin(q);
+  int issued = 0;
+  uint32_t dst = KIND == 0 ? LD::OFF_W : LD::OFF_X;  // ring slot the next unit goes to
   auto issue = [&]() {
     if constexpr (KIND == 0) {
-      const uint32_t dst = (uint32_t)(V3_OFF_W + slot * V3_W_SLOT);
-      const char* wb = (const char*)p.wp + (size_t)(uint32_t)((lc.t * q.chunks + lc.c) * (V3_BN * V3_CK / 2));
-      const char* sb = (const char*)p.sp + (size_t)(uint32_t)(((lc.c >> p.gshift) * (int)p.n + lc.t * V3_BN) * 8);
 #if !(defined(V3_ABLATE) && (V3_ABLATE & 2))
 #pragma unroll
-      for (int j = 0; j < 4; ++j) v3_dma16(dst + (4 * L + j) * 1024, wb, voff[j]);
+      for (int f = 0; f < NF; ++f) {  // the tile's 128-row blocks lc.t * NF + f
+        const int blk = lc.t * NF + f;
+        const char* wb = (const char*)p.wp + (size_t)(uint32_t)((blk * q.chunks + lc.c) * (V3_BN * V3_CK / 2));
+        const char* sb = (const char*)p.sp + (size_t)(uint32_t)(((lc.c >> p.gshift) * (int)p.n + blk * V3_BN) * 8);
 #pragma unroll
-      for (int j = 0; j < 2; ++j) v3_dma4(dst + 8192 + (2 * L + j) * 256, sb, voff[4 + j]);
+        for (int j = 0; j < 4; ++j) v3_dma16(dst + f * V3_W_BLOCK + (4 * L + j) * 1024, wb, voff[j]);
+#pragma unroll
+        for (int j = 0; j < 2; ++j) v3_dma4(dst + f * V3_W_BLOCK + 8192 + (2 * L + j) * 256, sb, voff[4 + j]);
+      }
 #endif
     } else {
-      const uint32_t dst = (uint32_t)(V3_OFF_X + slot * V3_X_SLOT);
       const char* xb = (const char*)p.x + (size_t)(uint32_t)(lc.c * (V3_CK * 2));
 #if !(defined(V3_ABLATE) && (V3_ABLATE & 1))
 #pragma unroll
       for (int j = 0; j < 8; ++j) v3_dma16(dst + (8 * L + j) * 1024, xb, voff[j]);
 #endif
     }
-    v3_advance(lc, q);
+    v3_walk_next(lc, q);
     ++issued;
-    slot = slot + 1 == R ? 0 : slot + 1;
+    if constexpr (KIND == 0) dst = dst + LD::W_SLOT == LD::OFF_W + R * LD::W_SLOT ? LD::OFF_W : dst + LD::W_SLOT;
+    else dst = dst + V3_X_SLOT == LD::OFF_X + R * V3_X_SLOT ? LD::OFF_X : dst + V3_X_SLOT;
   };
   const int pre = cnt < D ? cnt : D;
   for (int i = 0; i < pre; ++i) issue();
-  v3_wait_units<OPS>(issued - (cnt < 2 ? cnt : 2));  // units 0 and 1 have landed
+  v3_wait_units<OPS>(issued - (cnt < AHEAD ? cnt : AHEAD));  // units < AHEAD have landed
   v3_barrier();
-  V3Cur cc{q.t0, q.c0, q.n0, 0};
+  V3Walk cc = v3_walk_begin(q);
   for (int u = 0; u < cnt; ++u) {
     if (issued < cnt) issue();
-    const int need = cnt < u + 3 ? cnt : u + 3;  // after barrier u the consumers may touch units <= u + 2
+    const int need = cnt < u + 1 + AHEAD ? cnt : u + 1 + AHEAD;
     v3_wait_units<OPS>(issued - need);
     v3_barrier();
-    const bool se = (cc.c == q.chunks - 1) | (cc.left == 1);
-    if (se) v3_barrier();  // the consumers' k-half exchange
-    v3_advance(cc, q);
+    if (v3_walk_ends(cc)) {  // the consumers' k-half exchange, one round per 128-row block
+#pragma unroll
+      for (int f = 0; f < NF; ++f) v3_barrier();
+    }
+    v3_walk_next(cc, q);
   }
 }
 
-template <int MT>
+template <int MT, int NF>
 struct V3Ops {  // everything a consumer wave needs for one unit
-  u32x4 w;
-  u32x2 s;
+  u32x4 w[NF];
+  u32x2 s[NF];
   f16x8 a[4][MT];
 };
 
-template <int MT>
+template <int MT, int NF>
 __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgemm3_kernel(const V3Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
@@ -260,6 +295,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int chunks = p.chunks;
   V3_TL(0)
+  V3_TLC(61)
   int ub, ue;
   if (p.gt) {
     const int gtile = (int)blockIdx.x / p.gt, j = (int)blockIdx.x - gtile * p.gt;
@@ -280,25 +316,27 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     LT = (cZ != chunks - 1) ? cZ + 1 : 0;
     LH = (cA != 0) ? chunks - cA : 0;
   }
-  const int NF = cnt - LT - LH;
+  const int NFU = cnt - LT - LH;  // units of whole tiles
   const int tF = tA + ((LH > 0 && tA != tZ) ? 1 : 0);
   // segments in execution order, empty ones squeezed out (selects only: a runtime-indexed array would live in scratch)
-  const bool hasT = LT > 0, hasF = NF > 0;
+  const bool hasT = LT > 0, hasF = NFU > 0;
   V3Seq q;
   q.chunks = chunks;
-  q.t0 = hasT ? tZ : (hasF ? tF : tA); q.c0 = hasT ? 0 : (hasF ? 0 : cA); q.n0 = hasT ? LT : (hasF ? NF : LH);
-  q.t1 = (hasT && hasF) ? tF : tA; q.c1 = (hasT && hasF) ? 0 : cA; q.n1 = hasT ? (hasF ? NF : LH) : (hasF ? LH : 0);
+  q.t0 = hasT ? tZ : (hasF ? tF : tA); q.c0 = hasT ? 0 : (hasF ? 0 : cA); q.n0 = hasT ? LT : (hasF ? NFU : LH);
+  q.t1 = (hasT && hasF) ? tF : tA; q.c1 = (hasT && hasF) ? 0 : cA; q.n1 = hasT ? (hasF ? NFU : LH) : (hasF ? LH : 0);
   q.t2 = tA; q.c2 = cA; q.n2 = (hasT && hasF) ? LH : 0;
   V3_TL(1)
 
   if (wv >= 8) {
     // ======================================== loaders ======================================== //
-    if (wv < 10) v3_loader<0>(p, q, cnt, lane, wv - 8);
-    else v3_loader<1>(p, q, cnt, lane, wv - 10);
+    if (wv < 10) v3_loader<0, NF>(p, q, cnt, lane, wv - 8);
+    else v3_loader<1, NF>(p, q, cnt, lane, wv - 10);
     return;
   }
 
   // ======================================= consumers ======================================= //
+  using RG = V3Ring<NF>;
+  using LD = V3Lds<NF>;
   const int ng = wv & 3, kh = wv >> 2;
   const int nl = lane & 31, h = lane >> 5;
   const int w_off = wv * 1024 + lane * 16;
@@ -309,10 +347,12 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 
   uint32_t magic = 0x64006400u;
   asm volatile("" : "+v"(magic));
-  f32x16 acc0, acc1;  // two values, not an array: a wave-uniform choice between them must stay a select
+  // (128-row block f, batch half mt) -> acc{2f + mt}.  Separate values, not an array: a wave-uniform choice
+  // between them must stay a select (a runtime-indexed array would live in scratch)
+  f32x16 acc0, acc1, acc2, acc3;
   auto zero_acc = [&]() {
 #pragma unroll
-    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = 0.f;
+    for (int r = 0; r < 16; ++r) acc0[r] = acc1[r] = acc2[r] = acc3[r] = 0.f;
   };
   zero_acc();
 
@@ -320,29 +360,32 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   // (the consumers have no other memory operation in flight: vmcnt(0) waits for exactly those stores)
   int32_t* pend_ctr = nullptr;
   int pend_val = 0;
+  int pending = 0;
   auto post_pending = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane == 0) __hip_atomic_fetch_add(pend_ctr, pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    pend_ctr = nullptr;
+    if (lane < NF) __hip_atomic_fetch_add(pend_ctr + lane * 8, pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    pending = 0;
   };
 
   // Finish one 32-row batch half `mt` of row group ng for tile t, whose chunks [c_lo, c_hi] this workgroup
   // has just summed into v (k-halves already added).
-  auto flush = [&](f32x16& v, int mt, int t, int c_lo, int c_hi) {
+  auto flush = [&](f32x16& v, int mt, int t, int f, int c_lo, int c_hi) {
     const int w0 = p.gt ? t * p.gt : (int)((uint32_t)(t * chunks) / (uint32_t)p.upw);  // first contributor of the tile
     const int slot = (int)blockIdx.x - w0;
-    int32_t* ctr = &p.counters[(t * 4 + ng) * 2 + mt];
+    const int blk = t * NF + f;  // 128-row block
+    int32_t* ctr = &p.counters[(blk * 4 + ng) * 2 + mt];
     if (c_hi != chunks - 1) {
       // contributor: park the partial in this workgroup's slab (counter follows, see post_pending)
-      float* ws = p.workspace + ((((int64_t)t * p.slots + slot) * 4 + ng) * 2 + mt) * V3_FRAG;
+      float* ws = p.workspace + ((((int64_t)blk * p.slots + slot) * 4 + ng) * 2 + mt) * V3_FRAG;
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
         float* dst = ws + (g * 64 + lane) * 4;
         asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(o) : "memory");
       }
-      pend_ctr = ctr;
+      if (f == 0) pend_ctr = ctr;  // block f's counter is NF * 8 further... see post_pending
       pend_val = c_hi - c_lo + 1;
+      pending = 1;
       return;
     }
     if (c_lo != 0) {
@@ -361,7 +404,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
           const int sq = sl + j < slot ? sl + j : sl;
-          const float* src = p.workspace + ((((int64_t)t * p.slots + sq) * 4 + ng) * 2 + mt) * V3_FRAG + lane * 4;
+          const float* src = p.workspace + ((((int64_t)blk * p.slots + sq) * 4 + ng) * 2 + mt) * V3_FRAG + lane * 4;
 #pragma unroll
           for (int g = 0; g < 4; ++g)
             asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(va[j][g]) : "v"(src + g * 256) : "memory");
@@ -387,7 +430,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     const bool has_bias = p.bias != nullptr;
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      const int64_t nn = (int64_t)t * V3_BN + ng * 32 + 8 * g + 4 * h;
+      const int64_t nn = (int64_t)blk * V3_BN + ng * 32 + 8 * g + 4 * h;
       uint16_t o[4];
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
@@ -415,7 +458,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   // End of a tile segment: the two k-halves of a row group exchange one batch half each through LDS, so
   // that wave kh ends up with the complete sums of batch half kh (MT = 2), or kh = 0 with everything (MT = 1).
   auto segment_end = [&](int t, int c_lo, int c_hi) {
-    float* red = reinterpret_cast<float*>(lds + V3_OFF_R) + ng * (2 * V3_FRAG);
+    float* red = reinterpret_cast<float*>(lds + LD::OFF_R) + ng * (2 * V3_FRAG);
     V3_TL(50)
     auto put = [&](const f32x16& a, int half) {
 #pragma unroll
@@ -431,90 +474,124 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         for (int e = 0; e < 4; ++e) a[4 * g + e] += o[e];
       }
     };
-    if constexpr (MT == 2) {
-      f32x16 give, v;  // one copy of the exchange / flush code for both waves of the row group
+    auto round = [&](f32x16& a0, f32x16& a1, int f) {  // one 128-row block: a0 / a1 = batch halves 0 / 1
+      if constexpr (MT == 2) {
+        f32x16 give, v;  // one copy of the exchange / flush code for both waves of the row group
 #pragma unroll
-      for (int r = 0; r < 16; ++r) {
-        give[r] = kh == 0 ? acc1[r] : acc0[r];
-        v[r] = kh == 0 ? acc0[r] : acc1[r];
+        for (int r = 0; r < 16; ++r) {
+          give[r] = kh == 0 ? a1[r] : a0[r];
+          v[r] = kh == 0 ? a0[r] : a1[r];
+        }
+        put(give, 1 - kh);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        V3_TL(51)
+        get_add(v, kh);
+        flush(v, kh, t, f, c_lo, c_hi);
+      } else {
+        if (kh == 1) put(a0, 0);
+        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kh == 0) {
+          get_add(a0, 0);
+          flush(a0, 0, t, f, c_lo, c_hi);
+        }
       }
-      put(give, 1 - kh);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      V3_TL(51)
-      get_add(v, kh);
-      flush(v, kh, t, c_lo, c_hi);
-    } else {
-      if (kh == 1) put(acc0, 0);
-      asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
-      if (kh == 0) {
-        get_add(acc0, 0);
-        flush(acc0, 0, t, c_lo, c_hi);
-      }
+    };
+    round(acc0, acc1, 0);
+    if constexpr (NF == 2) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // block 0's exchange reads are done before the buffer is rewritten
+      round(acc2, acc3, 1);
     }
     zero_acc();
   };
 
-  auto read_ops = [&](V3Ops<MT>& o, int wslot, int xslot) {
-    const unsigned char* wb = lds + V3_OFF_W + wslot * V3_W_SLOT;
-    const unsigned char* xb = lds + V3_OFF_X + xslot * V3_X_SLOT;
-    o.w = *reinterpret_cast<const u32x4*>(wb + w_off);
-    o.s = *reinterpret_cast<const u32x2*>(wb + s_off);
+  int done = 0;
+  auto read_ops = [&](V3Ops<MT, NF>& o, int wbase, int xbase) {  // ring slot byte offsets
+    const unsigned char* wb = lds + wbase;
+    const unsigned char* xb = lds + xbase;
+#pragma unroll
+    for (int f = 0; f < NF; ++f) {
+      o.w[f] = *reinterpret_cast<const u32x4*>(wb + f * V3_W_BLOCK + w_off);
+      o.s[f] = *reinterpret_cast<const u32x2*>(wb + f * V3_W_BLOCK + s_off);
+    }
+#if defined(V3_ABLATE) && (V3_ABLATE & 32)
+    if (done > 0) return;  // debug: fragments read once
+#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) o.a[j][mt] = *reinterpret_cast<const f16x8*>(xb + x_off[j] + mt * 32 * 256);
   };
-  auto compute = [&](const V3Ops<MT>& o) {
+  auto compute = [&](const V3Ops<MT, NF>& o) {
 #if defined(V3_ABLATE) && (V3_ABLATE & 4)
-    asm volatile("" ::"v"(o.a[0][0]), "v"(o.a[3][MT - 1]), "v"(o.w), "v"(o.s));
+    asm volatile("" ::"v"(o.a[0][0]), "v"(o.a[3][MT - 1]), "v"(o.w[0]), "v"(o.s[0]), "v"(o.w[NF - 1]));
     return;
 #endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
-      const uint32_t word = j == 0 ? o.w.x : j == 1 ? o.w.y : j == 2 ? o.w.z : o.w.w;
-      const f16x8 wfrag = v3_dequant(word, o.s.x, o.s.y, magic);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, o.a[j][0], acc0, 0, 0, 0);
-      if constexpr (MT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, o.a[j][1], acc1, 0, 0, 0);
+#pragma unroll
+      for (int f = 0; f < NF; ++f) {
+        const uint32_t word = j == 0 ? o.w[f].x : j == 1 ? o.w[f].y : j == 2 ? o.w[f].z : o.w[f].w;
+#if defined(V3_ABLATE) && (V3_ABLATE & 8)
+        const f16x8 wfrag = __builtin_bit_cast(f16x8, u32x4{word, word ^ o.s[f].x, word ^ o.s[f].y, word + magic});  // debug: no dequant
+#else
+        const f16x8 wfrag = v3_dequant(word, o.s[f].x, o.s[f].y, magic);
+#endif
+#if defined(V3_ABLATE) && (V3_ABLATE & 16)
+        asm volatile("" ::"v"(wfrag), "v"(o.a[j][0]), "v"(o.a[j][MT - 1]));  // debug: no MFMA
+#else
+        if (f == 0) {
+          acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, o.a[j][0], acc0, 0, 0, 0);
+          if constexpr (MT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, o.a[j][1], acc1, 0, 0, 0);
+        } else {
+          acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, o.a[j][0], acc2, 0, 0, 0);
+          if constexpr (MT == 2) acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, o.a[j][1], acc3, 0, 0, 0);
+        }
+#endif
+      }
     }
   };
 
-  V3Cur cc{q.t0, q.c0, q.n0, 0};
+  V3Walk cc = v3_walk_begin(q);
   int seg_lo = cc.c;
-  int done = 0;
-  int wslot = 1, xslot = 1;  // ring slots of unit done + 1
-  V3Ops<MT> opA, opB;
-  v3_barrier();  // units 0 and 1 have landed
+  int wnext = LD::OFF_W + RG::RA * LD::W_SLOT, xnext = LD::OFF_X + RG::RA * V3_X_SLOT;  // ring slots of the next unit to READ
+  V3Ops<MT, NF> opA, opB;
+  v3_barrier();  // the first units have landed
   V3_TL(3)
-  read_ops(opA, 0, 0);
+  if constexpr (RG::RA) read_ops(opA, LD::OFF_W, LD::OFF_X);
 
-  // One unit: the operands of unit `done` are in CUR (read during the previous unit); the operands of the next
-  // unit are read into NXT first -- they landed before the barrier that ended the previous unit -- and stay in
-  // flight across this unit's barrier.
+  // One unit.  RA = 1 (128-row tiles): the operands of unit `done` are in CUR (read during the previous unit); the
+  // operands of the next unit are read into NXT first -- they landed before the barrier that ended the previous
+  // unit -- and stay in flight across this unit's barrier.  RA = 0 (256-row tiles): a unit's operands are read at
+  // its start.
 #define V3_STEP(CUR, NXT)                                                                   \
   {                                                                                         \
-    read_ops(NXT, wslot, xslot);                                                            \
+    read_ops(RG::RA ? NXT : CUR, wnext, xnext);                                             \
     __builtin_amdgcn_sched_barrier(0); /* keep the reads up here (hipcc sinks them to their use otherwise) */ \
-    wslot = wslot + 1 == V3_RW ? 0 : wslot + 1;                                             \
-    xslot = xslot + 1 == V3_RX ? 0 : xslot + 1;                                             \
+    wnext = wnext + LD::W_SLOT == LD::OFF_W + RG::RW * LD::W_SLOT ? LD::OFF_W : wnext + LD::W_SLOT; \
+    xnext = xnext + V3_X_SLOT == LD::OFF_X + RG::RX * V3_X_SLOT ? LD::OFF_X : xnext + V3_X_SLOT; \
     compute(CUR);                                                                           \
+    if constexpr (!RG::RA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the slot is free once the barrier is passed */ \
     v3_barrier();                                                                           \
     if (done < 40) { V3_TL(4 + done) }                                                      \
-    if (pend_ctr) post_pending(); /* the previous segment's slab stores are a unit old */   \
-    const bool se_ = (cc.c == chunks - 1) | (cc.left == 1);                                 \
+    if (pending) post_pending(); /* the previous segment's slab stores are a unit old */    \
+    const bool se_ = v3_walk_ends(cc);                                                      \
     if (se_) segment_end(cc.t, seg_lo, cc.c);                                               \
-    v3_advance(cc, q);                                                                      \
+    v3_walk_next(cc, q);                                                                    \
     if (se_) seg_lo = cc.c;                                                                 \
     ++done;                                                                                 \
   }
   for (;;) {
     V3_STEP(opA, opB)
     if (done >= cnt) break;
-    V3_STEP(opB, opA)
-    if (done >= cnt) break;
+    if constexpr (RG::RA) {
+      V3_STEP(opB, opA)
+      if (done >= cnt) break;
+    }
   }
 #undef V3_STEP
-  if (pend_ctr) post_pending();
+  if (pending) post_pending();
   V3_TL(60)
+  V3_TLC(62)
 }
 
 // ---------------------------------------------------------------------------------- //
@@ -566,17 +643,19 @@ extern "C" int ll_w4a16_pack_weights(void* packed, const int32_t* qweight, int64
 // host side
 // ---------------------------------------------------------------------------------- //
 struct V3Plan {
+  int nf;  // 128-row blocks per tile
   int nblocks, chunks, total_units, upw, grid, slots;
   int gt, gbase, grem, glead;
 };
 
 struct V3Knobs {
-  int wgs = 0, lead = 4, gt_cap_div = 5, gt_cap = -1;
+  int wgs = 0, lead = 4, gt_cap_div = 5, gt_cap = -1, nf = 0;
   V3Knobs() {
     if (const char* e = getenv("LL_GEMM3_WGS")) wgs = atoi(e);
     if (const char* e = getenv("LL_GEMM3_LEAD")) lead = atoi(e);
     if (const char* e = getenv("LL_GEMM3_GT")) gt_cap = atoi(e);
     if (const char* e = getenv("LL_GEMM3_GTDIV")) gt_cap_div = atoi(e) > 0 ? atoi(e) : 5;
+    if (const char* e = getenv("LL_GEMM3_NF")) nf = atoi(e);
   }
 };
 static const V3Knobs& v3_knobs() {
@@ -595,13 +674,18 @@ static int v3_num_cus() {
   return cus[dev];
 }
 
-static V3Plan v3_plan(int64_t n, int64_t k) {
+static V3Plan v3_plan(int64_t n, int64_t k, int nf_force = 0) {
   const V3Knobs& kn = v3_knobs();
   V3Plan pl;
-  pl.nblocks = (int)(n / V3_BN);
+  const int target = kn.wgs > 0 ? kn.wgs : v3_num_cus();  // one persistent 12-wave workgroup per CU
+  // 256-row tiles (one activation tile feeds two weight blocks: half the activation traffic and half the
+  // per-unit overhead per weight byte) when there are enough of them to keep the split coarse; 128 otherwise
+  pl.nf = (n % (2 * V3_BN) == 0 && n / (2 * V3_BN) >= target / 2) ? 2 : 1;
+  if (kn.nf == 1 || (kn.nf == 2 && n % (2 * V3_BN) == 0)) pl.nf = kn.nf;
+  if (nf_force == 1 || (nf_force == 2 && n % (2 * V3_BN) == 0)) pl.nf = nf_force;
+  pl.nblocks = (int)(n / (V3_BN * pl.nf));
   pl.chunks = (int)(k / V3_CK);
   pl.total_units = pl.nblocks * pl.chunks;
-  const int target = kn.wgs > 0 ? kn.wgs : v3_num_cus();  // one persistent 8-wave workgroup per CU
   pl.gt = pl.gbase = pl.grem = pl.glead = 0;
   // Few tiles: every tile is shared by gt workgroups; the last one (the owner) runs `lead` chunks longer
   // than the contributors, so their slabs and counters have landed by the time it merges.
@@ -648,9 +732,13 @@ extern "C" int ll_w4a16_v3_workspace(int64_t m, int64_t n, int64_t k, int64_t* f
   if (floats) *floats = 0;
   if (ints) *ints = 0;
   if (!v3_shape_ok(m, n, k)) return LL_OK;
-  const V3Plan pl = v3_plan(n, k);
-  if (floats) *floats = (int64_t)pl.nblocks * pl.slots * V3_SLAB;
-  if (ints) *ints = (int64_t)pl.nblocks * 8;
+  if (floats) *floats = 0;
+  for (int nf = 0; nf <= 2; ++nf) {  // the scratch fits whichever tile width a call asks for
+    const V3Plan pl = v3_plan(n, k, nf);
+    const int64_t f = (int64_t)pl.nblocks * pl.nf * pl.slots * V3_SLAB;
+    if (floats && f > *floats) *floats = f;
+  }
+  if (ints) *ints = n / V3_BN * 8;
   return LL_OK;
 }
 
@@ -660,11 +748,12 @@ extern "C" int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* w
                                          void* stream) {
   if (m < 0 || n <= 0 || k <= 0 || group_size <= 0) return LL_ERR_SHAPE;
   if (m == 0) return LL_OK;
-  if (!ll_w4a16_prepacked_supported(m, n, k, group_size) || x_stride_m % 8 != 0 || (epilogue && (n & 1))) return LL_ERR_SHAPE;
+  if (!ll_w4a16_prepacked_supported(m, n, k, group_size) || x_stride_m % 8 != 0 || ((epilogue & 1) && (n & 1))) return LL_ERR_SHAPE;
   if (!out || !x || !wpacked || !spacked || !workspace || !counters) return LL_ERR_ARG;
   if (!ll_aligned16(x) || !ll_aligned16(wpacked) || !ll_aligned16(spacked)) return LL_ERR_ARG;
   if ((m - 1) * x_stride_m * 2 + k * 2 >= (1ll << 31)) return LL_ERR_SHAPE;
-  const V3Plan pl = v3_plan(n, k);
+  const V3Plan pl = v3_plan(n, k, (epilogue >> 8) & 3);
+  epilogue &= 1;
   V3Params p{};
   p.out = (uint16_t*)out; p.x = (const uint16_t*)x; p.wp = wpacked; p.sp = spacked; p.bias = (const uint16_t*)bias;
   p.workspace = workspace; p.counters = counters;
@@ -687,13 +776,19 @@ extern "C" int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* w
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
-    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, V3_LDS_BYTES);
+    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<1, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<1>::BYTES);
+    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<1>::BYTES);
+    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<2>::BYTES);
+    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<2>::BYTES);
     attr_set[dev] = true;
   }
-  if (m <= 32)
-    wgemm3_kernel<1><<<dim3((unsigned)pl.grid), V3_THREADS, V3_LDS_BYTES, st>>>(p);
-  else
-    wgemm3_kernel<2><<<dim3((unsigned)pl.grid), V3_THREADS, V3_LDS_BYTES, st>>>(p);
+  const dim3 grid((unsigned)pl.grid);
+  if (pl.nf == 2) {
+    if (m <= 32) wgemm3_kernel<1, 2><<<grid, V3_THREADS, V3Lds<2>::BYTES, st>>>(p);
+    else wgemm3_kernel<2, 2><<<grid, V3_THREADS, V3Lds<2>::BYTES, st>>>(p);
+  } else {
+    if (m <= 32) wgemm3_kernel<1, 1><<<grid, V3_THREADS, V3Lds<1>::BYTES, st>>>(p);
+    else wgemm3_kernel<2, 1><<<grid, V3_THREADS, V3Lds<1>::BYTES, st>>>(p);
+  }
   return LL_LAUNCH_CHECK();
 }

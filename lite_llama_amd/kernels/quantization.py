@@ -142,10 +142,12 @@ def w4a16_prepacked_supported(m: int, n: int, k: int, group_size: int) -> bool:
     return bool(L.lib().ll_w4a16_prepacked_supported(m, n, k, int(group_size)))
 
 
-def w4a16_matmul_prepacked(x, packed_weight, packed_scales, *, group_size: int = 128, bias=None, gate_up_swiglu=False):
+def w4a16_matmul_prepacked(x, packed_weight, packed_scales, *, group_size: int = 128, bias=None, gate_up_swiglu=False,
+                           _tile_blocks: int = 0):
     """Decode-engine form of :func:`w4a16_matmul` over the load-time layouts (``pack_w4a16_weights`` /
     ``pack_w4a16_scales``); at most 64 rows.  ``gate_up_swiglu`` applies the fused epilogue of
-    :func:`w4a16_gate_up_swiglu` (rows interleaved gate/up).  Same arithmetic as ``w4a16_matmul``."""
+    :func:`w4a16_gate_up_swiglu` (rows interleaved gate/up).  Same arithmetic as ``w4a16_matmul``.
+    ``_tile_blocks`` (tests / tuning): 0 = tile width chosen by the host plan, 1 / 2 = 128- / 256-row tiles."""
     if x.dtype != torch.float16:
         raise ValueError(f"w4a16 activations must be fp16, got {x.dtype}")
     L.require_cuda(x, packed_weight, packed_scales, bias)
@@ -170,7 +172,8 @@ def w4a16_matmul_prepacked(x, packed_weight, packed_scales, *, group_size: int =
     L.check(
         L.lib().ll_w4a16_matmul_prepacked(
             out.data_ptr(), a.data_ptr(), packed_weight.data_ptr(), packed_scales.data_ptr(), L.ptr(bias), m, n, k,
-            int(group_size), a.stride(0), ws.data_ptr(), cnt.data_ptr(), 1 if gate_up_swiglu else 0, L.stream_ptr(),
+            int(group_size), a.stride(0), ws.data_ptr(), cnt.data_ptr(),
+            (1 if gate_up_swiglu else 0) | ((int(_tile_blocks) & 3) << 8), L.stream_ptr(),
         ),
         "w4a16_matmul_prepacked",
     )
