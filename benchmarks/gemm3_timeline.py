@@ -15,6 +15,27 @@ for name, n, k, epi in shapes:
     ps = [Q.pack_w4a16_scales(w[1], w[2]) for w in ws]
     pw = [Q.pack_w4a16_weights(w[0]) for w in ws]
     tl = torch.zeros(1024 * 64, dtype=torch.int64, device=dev)
+    for wave in (8, 10):  # loader waves: 8 = weights + scales, 10 = activations
+        os.environ["LL_GEMM3_TL_WAVE"] = str(wave)
+        os.environ.pop("LL_GEMM3_TIMELINE", None)
+        for i in range(copies):
+            Q.w4a16_matmul_prepacked(x, pw[i], ps[i], group_size=128, gate_up_swiglu=bool(epi))
+        torch.cuda.synchronize()
+        tl.zero_()
+        os.environ["LL_GEMM3_TIMELINE"] = hex(tl.data_ptr())
+        Q.w4a16_matmul_prepacked(x, pw[0], ps[0], group_size=128, gate_up_swiglu=bool(epi))
+        torch.cuda.synchronize()
+        os.environ.pop("LL_GEMM3_TIMELINE", None)
+        t = tl.view(1024, 64).cpu().double()
+        t = t[t[:, 0] > 0]
+        rel = lambda c: ((t[:, c] - t[:, 0]) / 100.0)[t[:, c] > 0]
+        line = []
+        for u in range(2, 10):
+            a, b, c0, prev = t[:, 4 + 3 * u], t[:, 5 + 3 * u], t[:, 6 + 3 * u], t[:, 6 + 3 * (u - 1)]
+            m = (a > 0) & (b > 0) & (c0 > 0) & (prev > 0)
+            if m.any():
+                line.append("u%d %.2f/%.2f/%.2f" % (u, ((a - prev)[m] / 100).median(), ((b - a)[m] / 100).median(), ((c0 - b)[m] / 100).median()))
+        print(f"== {name} loader wave {wave}: prologue issued {rel(2).median():.2f} us, first barrier {rel(3).median():.2f}; per unit issue/wait/barrier us: " + " ".join(line))
     for wave in (0, 4):
         os.environ["LL_GEMM3_TL_WAVE"] = str(wave)
         os.environ.pop("LL_GEMM3_TIMELINE", None)

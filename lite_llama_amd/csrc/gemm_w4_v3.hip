@@ -262,16 +262,23 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
     if constexpr (KIND == 0) dst = dst + LD::W_SLOT == LD::OFF_W + R * LD::W_SLOT ? LD::OFF_W : dst + LD::W_SLOT;
     else dst = dst + V3_X_SLOT == LD::OFF_X + R * V3_X_SLOT ? LD::OFF_X : dst + V3_X_SLOT;
   };
+  const int wv = KIND == 0 ? 8 + L : 10 + L;  // (timeline builds)
+  (void)wv;
   const int pre = cnt < D ? cnt : D;
   for (int i = 0; i < pre; ++i) issue();
+  V3_TL(2)
   v3_wait_units<OPS>(issued - (cnt < AHEAD ? cnt : AHEAD));  // units < AHEAD have landed
   v3_barrier();
+  V3_TL(3)
   V3Walk cc = v3_walk_begin(q);
   for (int u = 0; u < cnt; ++u) {
     if (issued < cnt) issue();
+    if (u < 12) { V3_TL(4 + 3 * u) }
     const int need = cnt < u + 1 + AHEAD ? cnt : u + 1 + AHEAD;
     v3_wait_units<OPS>(issued - need);
+    if (u < 12) { V3_TL(5 + 3 * u) }
     v3_barrier();
+    if (u < 12) { V3_TL(6 + 3 * u) }
     if (v3_walk_ends(cc)) {  // the consumers' k-half exchange, one round per 128-row block
 #pragma unroll
       for (int f = 0; f < NF; ++f) v3_barrier();
