@@ -149,6 +149,12 @@ int ll_flash_attention_nopad(void* out, const void* q, const void* k, const void
                              int64_t o_stride_t, int64_t o_stride_h, int dtype, int start_width,
                              int seq_width, void* stream);
 
+/* skip_rmsnorm over a projection left as S fp32 split-K partials [S][rows][n] (see ll_w4a16_partials_count):
+ * x = fp16(sum_s partials[s]) -- the value the projection would have stored -- then exactly ll_skip_rmsnorm
+ * with that x (residual required, updated in place). */
+int ll_skip_rmsnorm_partials(void* y, const float* partials, int s_count, void* residual, const void* weight,
+                             int64_t rows, int64_t n, float eps, int dtype, void* stream);
+
 /* ---- a8: w4a16_matmul  (kernels/quantization/w4a16.py:152-207) ---------------
  * out[m,n] = sum_k x[m,k] * ((nib(qweight[n,k/8],k%8) - zeros[n,k/g]) * scales[n,k/g]) (+bias)
  * x fp16 [M,K] (row stride given), qweight int32 [N,K/8], scales/zeros fp32
@@ -198,6 +204,11 @@ int ll_w4a16_gateup_swiglu(void* out, const void* x, const int32_t* qweight, con
 int ll_w4a16_pack_weights(void* packed, const int32_t* qweight, int64_t n, int64_t k, int64_t qw_stride_n,
                           void* stream);
 int ll_w4a16_prepacked_supported(int64_t m, int64_t n, int64_t k, int group_size); /* 1 / 0 */
+/* epilogue 2 of ll_w4a16_matmul_prepacked = split-K partial mode (decode-step fusion, no reference counterpart):
+ * `out` is an fp32 [S][M][N] buffer, S = ll_w4a16_partials_count(...) (0 = shape not served: use epilogue 0);
+ * the S partial sums are added by the consumer of the projection, ll_skip_rmsnorm_partials below -- the
+ * GEMM then has no cross-workgroup merge at all (bias must be NULL). */
+int ll_w4a16_partials_count(int64_t m, int64_t n, int64_t k, int group_size);
 int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* wpacked, const void* spacked,
                               const void* bias, int64_t m, int64_t n, int64_t k, int group_size,
                               int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,

@@ -76,7 +76,7 @@ struct V3Params {
   int nblocks, chunks, total_units, upw, slots;
   int gt, gbase, grem, glead;  // tile-group split, see v3_plan
   int gshift;                  // log2(group_size / 128)
-  int epi;                     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu
+  int epi;                     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu;  2: fp32 split-K partials [slot][m][n]
 #ifdef V3_TIMELINE
   unsigned long long* tl;  // debug: [workgroup][64] s_memrealtime stamps of wave LL_GEMM3_TL_WAVE (benchmarks/gemm3_timeline.py)
   int tlwave;
@@ -380,6 +380,18 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     const int w0 = p.gt ? t * p.gt : (int)((uint32_t)(t * chunks) / (uint32_t)p.upw);  // first contributor of the tile
     const int slot = (int)blockIdx.x - w0;
     const int blk = t * NF + f;  // 128-row block
+    if (p.epi == 2) {
+      // split-K partial mode: every workgroup of the tile group leaves its fp32 partial [slot][m][n] for the
+      // consumer kernel (ll_skip_rmsnorm_partials) to add up -- no counters, no polling, no owner
+      const int64_t mrow = nl + mt * 32;
+      if (mrow < p.m) {
+        float* dst = reinterpret_cast<float*>(p.out) + ((int64_t)slot * p.m + mrow) * p.n + (int64_t)blk * V3_BN + ng * 32 + 4 * h;
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          *reinterpret_cast<f32x4*>(dst + 8 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+      }
+      return;
+    }
     int32_t* ctr = &p.counters[(blk * 4 + ng) * 2 + mt];
     if (c_hi != chunks - 1) {
       // contributor: park the partial in this workgroup's slab (counter follows, see post_pending)
@@ -681,7 +693,7 @@ static int v3_num_cus() {
   return cus[dev];
 }
 
-static V3Plan v3_plan(int64_t n, int64_t k, int nf_force = 0) {
+static V3Plan v3_plan(int64_t n, int64_t k, int nf_force = 0, bool partials = false) {
   const V3Knobs& kn = v3_knobs();
   V3Plan pl;
   const int target = kn.wgs > 0 ? kn.wgs : v3_num_cus();  // one persistent 12-wave workgroup per CU
@@ -690,18 +702,20 @@ static V3Plan v3_plan(int64_t n, int64_t k, int nf_force = 0) {
   pl.nf = (n % (2 * V3_BN) == 0 && n / (2 * V3_BN) >= target / 2) ? 2 : 1;
   if (kn.nf == 1 || (kn.nf == 2 && n % (2 * V3_BN) == 0)) pl.nf = kn.nf;
   if (nf_force == 1 || (nf_force == 2 && n % (2 * V3_BN) == 0)) pl.nf = nf_force;
+  if (partials) pl.nf = 1;
   pl.nblocks = (int)(n / (V3_BN * pl.nf));
   pl.chunks = (int)(k / V3_CK);
   pl.total_units = pl.nblocks * pl.chunks;
   pl.gt = pl.gbase = pl.grem = pl.glead = 0;
   // Few tiles: every tile is shared by gt workgroups; the last one (the owner) runs `lead` chunks longer
   // than the contributors, so their slabs and counters have landed by the time it merges.
-  const int lead = kn.lead;
+  const int lead = partials ? 0 : kn.lead;  // partial mode has no owner: equal shares
   int gt = pl.nblocks > 0 ? target / pl.nblocks : 0;
   if (gt > V3_MAX_SLOTS) gt = V3_MAX_SLOTS;
   const int gt_cap = kn.gt_cap >= 0 ? kn.gt_cap : pl.chunks / kn.gt_cap_div;
   if (gt > gt_cap) gt = gt_cap;
-  if (lead > 0 && gt >= 2 && pl.chunks - lead >= gt) {
+  if (partials && gt < 1) gt = 1;
+  if ((lead > 0 || partials) && gt >= (partials ? 1 : 2) && pl.chunks - lead >= gt) {
     pl.gt = gt;
     pl.glead = lead;
     pl.gbase = (pl.chunks - lead) / gt;
@@ -735,6 +749,14 @@ extern "C" int ll_w4a16_prepacked_supported(int64_t m, int64_t n, int64_t k, int
   return v3_shape_ok(m, n, k) && ((gdiv & (gdiv - 1)) == 0) ? 1 : 0;
 }
 
+// Split-K partial mode (epilogue 2 of ll_w4a16_matmul_prepacked): number of fp32 partials [S][M][N] the launch
+// writes; 0 when the shape has too many tiles for the tile-group split (use the ordinary epilogue then).
+extern "C" int ll_w4a16_partials_count(int64_t m, int64_t n, int64_t k, int group_size) {
+  if (!ll_w4a16_prepacked_supported(m, n, k, group_size)) return 0;
+  const V3Plan pl = v3_plan(n, k, 1, true);
+  return pl.gt >= 1 && pl.grid == pl.nblocks * pl.gt ? pl.gt : 0;
+}
+
 extern "C" int ll_w4a16_v3_workspace(int64_t m, int64_t n, int64_t k, int64_t* floats, int64_t* ints) {
   if (floats) *floats = 0;
   if (ints) *ints = 0;
@@ -759,8 +781,10 @@ extern "C" int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* w
   if (!out || !x || !wpacked || !spacked || !workspace || !counters) return LL_ERR_ARG;
   if (!ll_aligned16(x) || !ll_aligned16(wpacked) || !ll_aligned16(spacked)) return LL_ERR_ARG;
   if ((m - 1) * x_stride_m * 2 + k * 2 >= (1ll << 31)) return LL_ERR_SHAPE;
-  const V3Plan pl = v3_plan(n, k, (epilogue >> 8) & 3);
-  epilogue &= 1;
+  const bool partials = (epilogue & 3) == 2;
+  if (partials && (bias || !ll_w4a16_partials_count(m, n, k, group_size))) return LL_ERR_SHAPE;
+  const V3Plan pl = v3_plan(n, k, (epilogue >> 8) & 3, partials);
+  epilogue &= 3;
   V3Params p{};
   p.out = (uint16_t*)out; p.x = (const uint16_t*)x; p.wp = wpacked; p.sp = spacked; p.bias = (const uint16_t*)bias;
   p.workspace = workspace; p.counters = counters;

@@ -167,6 +167,89 @@ extern "C" int ll_skip_rmsnorm(void* y, const void* x, void* residual, const voi
                   : launch_skip_rmsnorm<LL_BF16, false>(yy, xx, rr, ww, rows, (int)n, eps, st);
 }
 
+// skip_rmsnorm whose input projection was left as S fp32 split-K partials [S][rows][n] (gemm_w4_v3.hip, epilogue 2):
+// x = fp16(sum_s P[s]) -- exactly the value the projection's own epilogue would have rounded and stored --
+// then the arithmetic of skip_rmsnorm_cached.  One row per block; every load issued up front.
+template <int DT, int VPT, int SMAX>
+__global__ __launch_bounds__(256) void skip_rmsnorm_partials_kernel(uint16_t* __restrict__ y, const float* __restrict__ part,
+                                                                    int s_count, uint16_t* __restrict__ r,
+                                                                    const uint16_t* __restrict__ w, int64_t rows, int n,
+                                                                    float eps) {
+  __shared__ float lds[4];
+  const int tr = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const float nf = (float)n;
+  const int64_t plane = rows * (int64_t)n;
+  U16x8 rv[VPT], wv[VPT];
+  f32x4 pv[VPT][SMAX][2];
+  bool ok[VPT];
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    const int col = (v * 256 + tr) * 8;
+    ok[v] = col < n;
+    const int64_t off = ok[v] ? row * n + col : 0;
+    rv[v] = *reinterpret_cast<const U16x8*>(r + off);
+    wv[v] = *reinterpret_cast<const U16x8*>(w + (ok[v] ? col : 0));
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+      const float* src = part + (s < s_count ? s : 0) * plane + off;  // slots >= s_count re-read slot 0 and are dropped below
+      pv[v][s][0] = *reinterpret_cast<const f32x4*>(src);
+      pv[v][s][1] = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+  }
+  float sv[VPT][8];
+  float ssq = 0.f;
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a = 0.f;
+#pragma unroll
+      for (int s = 0; s < SMAX; ++s) a += s < s_count ? pv[v][s][i >> 2][i & 3] : 0.f;
+      float x = to_f32<DT>(from_f32<DT>(a)) + to_f32<DT>(rv[v].v[i]);
+      rv[v].v[i] = from_f32<DT>(x);
+      sv[v][i] = ok[v] ? x : 0.f;
+    }
+    if (ok[v]) *reinterpret_cast<U16x8*>(r + row * n + (v * 256 + tr) * 8) = rv[v];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ssq += sv[v][i] * sv[v][i] / nf;
+  }
+  const float var = row_sum<256>(ssq, lds);
+  const float rrms = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    if (ok[v]) {
+      U16x8 yv;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) yv.v[i] = mul_storage<DT>(from_f32<DT>(sv[v][i] * rrms), wv[v].v[i]);
+      *reinterpret_cast<U16x8*>(y + row * n + (v * 256 + tr) * 8) = yv;
+    }
+  }
+}
+
+extern "C" int ll_skip_rmsnorm_partials(void* y, const float* partials, int s_count, void* residual, const void* weight,
+                                        int64_t rows, int64_t n, float eps, int dtype, void* stream) {
+  if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (rows < 0 || n <= 0 || n % 8 != 0 || n > 8192 || s_count < 1 || s_count > 12) return LL_ERR_SHAPE;
+  if (!y || !partials || !residual || !weight || !ll_aligned16(y) || !ll_aligned16(partials) || !ll_aligned16(residual) ||
+      !ll_aligned16(weight))
+    return LL_ERR_ARG;
+  if (rows == 0) return LL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int nv = (int)(n / 8);
+#define LL_PART_CASE(DT, VPT, SMAX)                                                                             \
+  skip_rmsnorm_partials_kernel<DT, VPT, SMAX><<<dim3((unsigned)rows), 256, 0, st>>>(                            \
+      (uint16_t*)y, partials, s_count, (uint16_t*)residual, (const uint16_t*)weight, rows, (int)n, eps)
+#define LL_PART_DT(DT)                                                       \
+  if (nv <= 256) { if (s_count <= 6) LL_PART_CASE(DT, 1, 6); else LL_PART_CASE(DT, 1, 12); } \
+  else if (nv <= 512) { if (s_count <= 6) LL_PART_CASE(DT, 2, 6); else LL_PART_CASE(DT, 2, 12); } \
+  else { if (s_count <= 6) LL_PART_CASE(DT, 4, 6); else LL_PART_CASE(DT, 4, 12); }
+  if (dtype == LL_F16) { LL_PART_DT(LL_F16) } else { LL_PART_DT(LL_BF16) }
+#undef LL_PART_DT
+#undef LL_PART_CASE
+  return LL_LAUNCH_CHECK();
+}
+
 // --------------------------------------------------------------------------- //
 // swiglu_forward -- reference lite_llama/kernels/swiglu.py:24-65
 // silu_and_mul   -- reference lite_llama/kernels/fused_moe.py:298-315

@@ -47,6 +47,45 @@ def skip_rmsnorm(X, residual, weight, eps=1e-5):
     return Y.view(orig_shape), X.view(orig_shape)
 
 
+class PartialSums:
+    """A projection output left as ``S`` fp32 split-K partial sums ``[S, rows, n]`` (decode-step extension, TP = 1
+    only): the W4A16 decode GEMM then has no cross-workgroup merge; the sums are added by the consumer of the
+    projection, :func:`skip_rmsnorm_partials`.  ``materialise()`` gives the tensor the projection would have
+    returned."""
+
+    __slots__ = ("parts", "shape", "dtype")
+
+    def __init__(self, parts: torch.Tensor, shape, dtype):
+        self.parts, self.shape, self.dtype = parts, tuple(shape), dtype
+
+    def materialise(self) -> torch.Tensor:
+        return self.parts.sum(0).to(self.dtype).view(self.shape)
+
+
+@torch.no_grad()
+def skip_rmsnorm_partials(X: PartialSums, residual, weight, eps=1e-5):
+    """:func:`skip_rmsnorm` over a :class:`PartialSums` input: ``x = fp16(sum of the partials)`` -- the value the
+    projection itself would have stored -- then the same add-and-normalise.  ``residual`` is required."""
+    if residual is None:
+        raise ValueError("skip_rmsnorm_partials needs a residual (the projection follows a normalised block)")
+    L.require_cuda(X.parts, residual, weight)
+    s, m, n = X.parts.shape
+    _check_row(n)
+    residual = residual.contiguous().view(-1, n)
+    if residual.shape[0] != m or residual.dtype != X.dtype:
+        raise ValueError("residual must be [rows, n] in the projection's dtype")
+    if weight.dtype != X.dtype:
+        weight = weight.to(X.dtype)
+    Y = torch.empty((m, n), dtype=X.dtype, device=residual.device)
+    L.check(
+        L.lib().ll_skip_rmsnorm_partials(Y.data_ptr(), X.parts.data_ptr(), s, residual.data_ptr(),
+                                         weight.contiguous().data_ptr(), m, n, float(eps), L.dtype_code(X.dtype),
+                                         L.stream_ptr()),
+        "skip_rmsnorm_partials",
+    )
+    return Y.view(X.shape), residual.view(X.shape)
+
+
 def swiglu_forward(a, b):
     """``silu(a.float()) * b`` in ``a``'s dtype and shape."""
     L.require_cuda(a, b)

@@ -180,6 +180,34 @@ def w4a16_matmul_prepacked(x, packed_weight, packed_scales, *, group_size: int =
     return out.reshape(*leading, n_out)
 
 
+def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 128):
+    """Decode-step extension: the projection as ``S`` fp32 split-K partial sums (:class:`PartialSums`) for
+    :func:`skip_rmsnorm_partials` to add up -- the GEMM has no cross-workgroup merge then.  ``None`` when the shape
+    is not served (the caller runs :func:`w4a16_matmul_prepacked`)."""
+    from .norm_act import PartialSums
+    L.require_cuda(x, packed_weight, packed_scales)
+    n, k = packed_weight.shape[0] * 128, packed_weight.shape[1] * 128
+    if x.dtype != torch.float16 or x.shape[-1] != k or n % 8:
+        return None
+    a = _flatten(x, k)
+    m = a.shape[0]
+    if m < 1 or m > 64:
+        return None
+    s = L.lib().ll_w4a16_partials_count(m, n, k, int(group_size))
+    if s < 1:
+        return None
+    parts = torch.empty((s, m, n), dtype=torch.float32, device=x.device)
+    ws, cnt = L.gemm_workspace(x.device, m, n, k)
+    L.check(
+        L.lib().ll_w4a16_matmul_prepacked(
+            parts.data_ptr(), a.data_ptr(), packed_weight.data_ptr(), packed_scales.data_ptr(), 0, m, n, k,
+            int(group_size), a.stride(0), ws.data_ptr(), cnt.data_ptr(), 2, L.stream_ptr(),
+        ),
+        "w4a16_matmul_partials",
+    )
+    return PartialSums(parts, (*x.shape[:-1], n), x.dtype)
+
+
 def w8a16_matmul(
     x: torch.Tensor,
     qweight: torch.Tensor,

@@ -63,7 +63,13 @@ class RowParallelLinear(LinearBase):
         super().__init__(local_in, output_size, quant=quant)
         self.full_input_size = input_size
 
-    def forward(self, x: torch.Tensor) -> torch.Tensor:
+    def forward(self, x: torch.Tensor, partials_ok: bool = False):
+        """``partials_ok`` (extension): the caller feeds the result to ``skip_rmsnorm_partials`` and accepts a
+        :class:`PartialSums` -- only taken without tensor parallelism (the all-reduce needs the finished sums)."""
+        if partials_ok and get_tp_world_size() == 1 and hasattr(self.quant_method, "apply_partials"):
+            out = self.quant_method.apply_partials(self, x)
+            if out is not None:
+                return out
         return all_reduce_tp(self.apply_linear(x))
 
 

@@ -24,7 +24,7 @@ import torch.nn.functional as F
 
 from .distributed.parallel_state import all_reduce_tp, divide, get_tp_rank, get_tp_world_size
 from .kernels.attention import decode_attention
-from .kernels.norm_act import rope_and_cache
+from .kernels.norm_act import PartialSums, rope_and_cache, skip_rmsnorm_partials
 from .kernels import (
     flash_attention2_no_pad,
     flash_decoding,
@@ -212,7 +212,7 @@ class Attention(nn.Module):
         self.attn = PagedAttention(self.num_kv_heads, self.head_dim)
         object.__setattr__(self, "_qkv", MergedColumnLinear([self.q_proj, self.kv_proj]))
 
-    def forward(self, x, atten_info, layer_index, position_embeddings):
+    def forward(self, x, atten_info, layer_index, position_embeddings, partials_ok=False):
         batch, seq_len, _ = x.shape
         x2 = x.view(-1, self.hidden_size)
         if self._qkv.refresh():
@@ -237,7 +237,7 @@ class Attention(nn.Module):
                                    atten_info.kv_buffer[layer_index], self.attn.scale, atten_info.b_req_tokens_table,
                                    atten_info.b_req_idx, atten_info.b_seq_len, atten_info.max_actual_seq_len)
             if out is not None:
-                return self.o_proj(out.view(batch, seq_len, self.q_size))
+                return self.o_proj(out.view(batch, seq_len, self.q_size), partials_ok)
         if fused and tables is not None:
             # rope (position-indexed tables) + KV scatter in one launch, in place
             rope_and_cache(xq, xkv, tables[0], tables[1], batch, seq_len, atten_info.cur_select_index,
@@ -258,6 +258,13 @@ class Attention(nn.Module):
         return self.o_proj(out.view(batch, seq_len, self.q_size))
 
 
+def add_norm(hidden_states, residual, weight, eps):
+    """``skip_rmsnorm`` that also accepts a projection left as split-K partials (kernels/norm_act.py::PartialSums)."""
+    if isinstance(hidden_states, PartialSums):
+        return skip_rmsnorm_partials(hidden_states, residual, weight, eps)
+    return skip_rmsnorm(hidden_states, residual, weight, eps)
+
+
 class FusedMLP(nn.Module):
     """down(silu(gate(x)) * up(x)) -- base.py:248-264."""
 
@@ -269,10 +276,10 @@ class FusedMLP(nn.Module):
         self.down_proj = RowParallelLinear(i, h, quant=quant, what="MLP intermediate")
         object.__setattr__(self, "_gate_up", MergedColumnLinear([self.gate_proj, self.up_proj], interleave=True))
 
-    def forward(self, x):
+    def forward(self, x, partials_ok=False):
         if self._gate_up.refresh():
-            return self.down_proj(self._gate_up.swiglu(x))  # one launch (int4 decode) or merged GEMM + swiglu
-        return self.down_proj(swiglu_forward(self.gate_proj(x), self.up_proj(x)))
+            return self.down_proj(self._gate_up.swiglu(x), partials_ok)  # one launch (int4 decode) or merged GEMM + swiglu
+        return self.down_proj(swiglu_forward(self.gate_proj(x), self.up_proj(x)), partials_ok)
 
 
 class SparseMoeBlock(nn.Module):
@@ -336,10 +343,15 @@ class DecoderLayer(nn.Module):
         self.mlp = SparseMoeBlock(geo, quant) if geo.num_experts else FusedMLP(geo, quant)
 
     def forward(self, hidden_states, atten_info, layer_index, position_embeddings, residual=None):
-        hidden_states, residual = skip_rmsnorm(hidden_states, residual, self.input_layernorm_weight, self.eps)
-        hidden_states = self.self_attn(hidden_states, atten_info, layer_index, position_embeddings)
-        hidden_states, residual = skip_rmsnorm(hidden_states, residual, self.post_attention_layernorm_weight, self.eps)
-        hidden_states = self.mlp(hidden_states)
+        """``hidden_states`` in and out may be a :class:`PartialSums` (decode, int4, TP = 1): the row-parallel
+        projections leave fp32 split-K partials and the add-and-normalise that follows adds them up."""
+        hidden_states, residual = add_norm(hidden_states, residual, self.input_layernorm_weight, self.eps)
+        hidden_states = self.self_attn(hidden_states, atten_info, layer_index, position_embeddings, partials_ok=True)
+        hidden_states, residual = add_norm(hidden_states, residual, self.post_attention_layernorm_weight, self.eps)
+        if isinstance(self.mlp, FusedMLP):
+            hidden_states = self.mlp(hidden_states, partials_ok=True)
+        else:
+            hidden_states = self.mlp(hidden_states)
         return hidden_states, residual
 
 
@@ -373,7 +385,7 @@ class CausalLM(nn.Module):
         residual = None
         for i, layer in enumerate(self.layers):
             hidden_states, residual = layer(hidden_states, atten_info, i, position_embeddings, residual)
-        hidden_states, _ = skip_rmsnorm(hidden_states, residual, self.norm_weight, self.eps)
+        hidden_states, _ = add_norm(hidden_states, residual, self.norm_weight, self.eps)
         if logits_rows is not None:
             hidden_states = hidden_states.view(-1, hidden_states.shape[-1])[logits_rows]
         return F.linear(hidden_states, self.lm_head_weight)

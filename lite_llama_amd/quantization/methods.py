@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..kernels import fused_moe, smoothquant_matmul, w4a16_matmul, w8a16_matmul
-from ..kernels.quantization import (pack_w4a16_scales, pack_w4a16_weights, w4a16_gate_up_swiglu,
+from ..kernels.quantization import (pack_w4a16_scales, pack_w4a16_weights, w4a16_gate_up_swiglu, w4a16_matmul_partials,
                                     w4a16_matmul_prepacked, w4a16_prepacked_supported)
 from .config import FP8, INT4, INT8, SMOOTHQUANT, QuantConfig
 from .params import (
@@ -79,6 +79,16 @@ class W4A16LinearMethod(LinearQuantMethod):
         return w4a16_matmul(x, layer.weight, layer.weight_scale, layer.weight_zeros,
                             group_size=layer.quant.group_k, bias=layer.bias,
                             packed_scales=self._packed(layer))
+
+    def apply_partials(self, layer, x):
+        """Decode-shaped projection left as fp32 split-K partials for ``skip_rmsnorm_partials`` (extension);
+        ``None`` -> the caller runs :meth:`apply`."""
+        if layer.bias is not None or os.environ.get("LL_W4_NO_PARTIALS"):
+            return None
+        pre = self._prepacked(layer, x)
+        if pre is None:
+            return None
+        return w4a16_matmul_partials(x, pre, self._packed(layer), group_size=layer.quant.group_k)
 
     def apply_gate_up_swiglu(self, layer, x):
         """``layer`` holds gate/up row-interleaved (linear.py::MergedColumnLinear): one launch for

@@ -164,3 +164,33 @@ def test_prepacked_random_shapes_match_reference_format_engine():
         scale = y2.float().abs().max().item() + 1e-6
         assert torch.equal(y3, y3b), (m, n, k, gs, tb)
         assert (y3.float() - y2.float()).abs().max().item() <= 2e-3 * scale + 2e-3, (m, n, k, gs, tb)
+
+
+@pytest.mark.parametrize("M,N,K_", [(64, 3584, 3584), (64, 3584, 18944), (17, 1024, 3584), (64, 4608, 3584), (1, 128, 512)])
+def test_partial_sums_and_reducing_norm(M, N, K_):
+    """Split-K partial mode: sum of the partials == the ordinary epilogue's output (fp32 order aside), and
+    skip_rmsnorm_partials == skip_rmsnorm of that output (same arithmetic from the rounded x on)."""
+    import lite_llama_amd.kernels as K
+    from lite_llama_amd.kernels.norm_act import skip_rmsnorm_partials
+    g = torch.Generator().manual_seed(N + K_)
+    x = (torch.randn(M, K_, generator=g) * 0.5).half().to(DEV)
+    qw = torch.randint(-(2**31), 2**31 - 1, (N, K_ // 8), dtype=torch.int64, generator=g).to(torch.int32).to(DEV)
+    sc = (torch.rand(N, K_ // 128, generator=g) * 0.01 + 0.005).to(DEV)
+    zr = torch.randint(0, 16, (N, K_ // 128), generator=g).float().to(DEV)
+    pw, ps = Q().pack_w4a16_weights(qw), Q().pack_w4a16_scales(sc, zr)
+    full = Q().w4a16_matmul_prepacked(x, pw, ps)
+    parts = Q().w4a16_matmul_partials(x, pw, ps)
+    assert parts is not None and parts.parts.shape[1:] == (M, N)
+    scale = full.float().abs().max().item()
+    assert (parts.materialise().float() - full.float()).abs().max().item() <= 2e-3 * scale + 2e-3
+    res = (torch.randn(M, N, generator=g) * 0.5).half().to(DEV)
+    wn = (1 + 0.1 * torch.randn(N, generator=g)).half().to(DEV)
+    y_ref, r_ref = K.skip_rmsnorm(parts.materialise(), res.clone(), wn, 1e-6)
+    r_in = res.clone()
+    y, r = skip_rmsnorm_partials(parts, r_in, wn, 1e-6)
+    assert r.data_ptr() == r_in.data_ptr()
+    # x is rounded from the same fp32 sums up to the summation order: an occasional 1-ulp flip of x is allowed
+    close(r, r_ref, 2e-3)
+    close(y, y_ref, 4e-3)
+    exact = (r == r_ref).float().mean().item()
+    assert exact > 0.98, exact
