@@ -16,7 +16,12 @@
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 
-#define FD_PART 128  // tokens per partition (reference PARTITION_SIZE, flashdecoding.py:343)
+// Tokens per partition: the reference's PARTITION_SIZE (flashdecoding.py:343).  -DFD_PART=64 builds the
+// 64-token variant (twice the waves in flight, half the gather chain per wave): measured SLOWER on the
+// headline shape (3.82 vs 3.58 ms/step, same box) -- twice the partials, a second merge round trip.
+#ifndef FD_PART
+#define FD_PART 128
+#endif
 #ifndef FD_MERGE_PB4
 #define FD_MERGE_PB4 5
 #endif
@@ -133,7 +138,9 @@ __global__ __launch_bounds__(64) void fd_stage1(
       sf[s] = *reinterpret_cast<const Q4*>(rp.sin_t + crow + s * 32 + c * 8);
     }
     // the new token lives in the last non-empty partition; head group 0 owns the write
-    if (hg == 0 && part == (int)((seq_len - 1) / FD_PART)) {
+    // (clamped to the launched partitions: a stale / too small max length then still stores the row)
+    const int wpart = (int)((seq_len - 1) / FD_PART) < nparts - 1 ? (int)((seq_len - 1) / FD_PART) : nparts - 1;
+    if (hg == 0 && part == wpart) {
       const int64_t dstrow = fd_load_idx(rp.sel, b, rp.sel_w);
       const uint16_t* kn = rp.kv_new + b * rp.kv_rs + (int64_t)kvh * D;
       const uint16_t* vn = rp.kv_new + b * rp.kv_rs + (int64_t)(hkv + kvh) * D;
@@ -170,11 +177,12 @@ __global__ __launch_bounds__(64) void fd_stage1(
   // Pool rows of the whole partition, fetched ONCE: lane l holds the rows of tokens start+l and
   // start+64+l (clamped to the last valid token, so every later gather reads a valid row); the
   // tiles pick theirs with a lane shuffle instead of a dependent table load per tile.
-  static_assert(FD_PART == 128, "the tile schedule below is written for 4 tiles of 32 tokens");
+  static_assert(FD_PART == 128 || FD_PART == 64, "the tile schedule below is written for 2 or 4 tiles of 32 tokens");
   const int64_t lastt = end - 1;
   const int64_t tk0 = start + lane < lastt ? start + lane : lastt;
   const int64_t tk1 = start + 64 + lane < lastt ? start + 64 + lane : lastt;
-  const int r0 = trow[tk0], r1 = trow[tk1];
+  const int r0 = trow[tk0];
+  const int r1 = FD_PART == 128 ? trow[tk1] : r0;
 
   // ---- gather of tile TI (32 tokens): lane (t, c) fetches rows TI*32+t and TI*32+16+t, d-range
   //      {s*32 + c*8 .. +8}, straight into MFMA fragment layout (per instruction the 4 lanes of a row
@@ -294,11 +302,13 @@ __global__ __launch_bounds__(64) void fd_stage1(
     }
     }
   FD_COMPUTE(A, 0)
-  FD_LOAD(A, 2)
+  if constexpr (FD_PART == 128) FD_LOAD(A, 2)
   if (start + 32 < end) FD_COMPUTE(B, 1)
-  FD_LOAD(B, 3)
-  if (start + 64 < end) FD_COMPUTE(A, 2)
-  if (start + 96 < end) FD_COMPUTE(B, 3)
+  if constexpr (FD_PART == 128) {
+    FD_LOAD(B, 3)
+    if (start + 64 < end) FD_COMPUTE(A, 2)
+    if (start + 96 < end) FD_COMPUTE(B, 3)
+  }
 #undef FD_LOAD
 #undef FD_COMPUTE
 
