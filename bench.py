@@ -14,10 +14,13 @@ tokens; greedy, no EOS stop, lockstep batch -- the reference's measurement proto
 (benchmarks/common.py:101-137).  Inputs are resident in HBM when the timed region starts.
 
 Rank 0 prints ONE JSON line (contract in the task statement) with two extra objects:
-  roofline     -- dominant kernel (wgemm_kernel = W4A16 dequant-GEMM): algorithmic weight bytes per
+  roofline     -- dominant kernel (wgemm3_kernel = W4A16 dequant-GEMM): algorithmic weight bytes per
                   launch / average launch duration measured live with HIP events, vs 8 TB/s HBM peak
-  cpu_baseline -- the CPU oracle (oracle/model.py, a "port") timed on the host cores on a bounded
-                  sample of the same workload (N = 1 only)
+  cpu_baseline -- the reference's CPU-runnable case (benchmarks/bench_hf_baseline.py protocol: Qwen2.5-0.5B
+                  geometry, batch 1, 2 x 8-token warm-up, TTFT, TPOT, 256 generated tokens) on the host cores,
+                  plus "oracle_port": the CPU oracle on a slice of the headline workload (N = 1 only)
+  graph        -- true when the timed steps were hipGraph replays; a refused capture is reported here (and on
+                  stderr) together with "graph_error", never silently
 """
 
 from __future__ import annotations
@@ -48,7 +51,7 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--scattered", action="store_true", help="context rows in random pool order (gather cost)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-layers", type=int, default=2, help="decoder layers in the CPU oracle sample")
+    ap.add_argument("--cpu-layers", type=int, default=1, help="decoder layers in the CPU oracle sample")
     return ap.parse_args()
 
 
@@ -74,21 +77,23 @@ def algorithmic_bytes(geo, quant, batch, ctx, tp):
 
 def gemm_roofline(model, batch, quant, iters=6):
     """Average launch duration of the dominant kernel (the weight-streaming dequant-GEMM) over every
-    projection of the model with its real weights, by HIP events on the launch stream."""
-    from lite_llama_amd.linear import LinearBase, MergedColumnLinear
+    projection of the model with its real weights -- the same calls the decode step makes (fused [q|k|v],
+    fused [gate|up] + swiglu, row-parallel projections in split-K partial mode) -- by HIP events on the
+    launch stream around hipGraph replays of the launch list (eager back-to-back launches as fallback)."""
+    from lite_llama_amd.linear import LinearBase, MergedColumnLinear, RowParallelLinear
 
-    # the GEMM launches one decode step really makes: fused [q|k|v] and [gate|up] where merged
     merged = [m for mod in model.modules() for m in vars(mod).values() if isinstance(m, MergedColumnLinear)]
     fused_members = set()
     launches_list = []  # (callable, input_size, weights in the launch)
     for mc in merged:
         if mc.layers[0].quant is not None and mc.refresh():
             fused_members.update(id(l) for l in mc.layers)
-            launches_list.append((lambda x, mc=mc: mc(x), mc.layers[0].input_size,
-                                  sum(l.input_size * l.output_size for l in mc.layers)))
+            fn = (lambda x, mc=mc: mc.swiglu(x)) if mc.interleave else (lambda x, mc=mc: mc(x))
+            launches_list.append((fn, mc.layers[0].input_size, sum(l.input_size * l.output_size for l in mc.layers)))
     for m in model.modules():
         if isinstance(m, LinearBase) and m.quant is not None and id(m) not in fused_members:
-            launches_list.append((m.apply_linear, m.input_size, m.input_size * m.output_size))
+            fn = (lambda x, m=m: m(x, partials_ok=True)) if isinstance(m, RowParallelLinear) else m.apply_linear
+            launches_list.append((fn, m.input_size, m.input_size * m.output_size))
     if not launches_list:
         return None
     dev = next(model.parameters()).device
@@ -99,11 +104,26 @@ def gemm_roofline(model, batch, quant, iters=6):
     for fn, k, _ in launches_list:  # warm
         fn(xs[k])
     torch.cuda.synchronize()
+    replay, how = None, "eager launches"
+    try:
+        g = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(g):
+            for fn, k, _ in launches_list:
+                fn(xs[k])
+        g.replay()
+        torch.cuda.synchronize()
+        replay, how = g.replay, "hipGraph replay of the launch list"
+    except Exception:  # capture refused: time the eager launches (gaps included)
+        torch.cuda.synchronize()
+    stream = torch.cuda.current_stream()
     e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
     e0.record(stream)
     for _ in range(iters):
-        for fn, k, _ in launches_list:
-            fn(xs[k])
+        if replay is not None:
+            replay()
+        else:
+            for fn, k, _ in launches_list:
+                fn(xs[k])
     e1.record(stream)
     torch.cuda.synchronize()
     nl = len(launches_list)
@@ -119,12 +139,58 @@ def gemm_roofline(model, batch, quant, iters=6):
         except Exception:
             traffic = None
     return {
-        "bound": "hbm", "kernel": "wgemm2_kernel (w4a16 dequant-GEMM, decode engine)" if quant == "int4" else "wgemm_kernel",
+        "bound": "hbm",
+        "kernel": "wgemm3_kernel (w4a16 dequant-GEMM over pre-packed weights, decode engine)" if quant == "int4" else "wgemm_kernel",
         "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
         "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic,
         "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
-        "launches_timed": launches,
+        "launches_timed": launches, "timed_as": how,
     }
+
+
+def cpu_baseline_protocol(gen_len=256, prompt_len=32, threads=None):
+    """The reference's CPU-runnable case (BASELINE.json configs[0]): benchmarks/bench_hf_baseline.py through
+    benchmarks/common.py::HFBackend.measure (common.py:174-221) restated for the host cores -- Qwen2.5-0.5B geometry
+    (random weights: no checkpoints offline) in the Hugging Face transformers implementation (sdpa attention, fp32 on
+    CPU), batch 1, greedy with min_new_tokens == max_new_tokens, two 8-token warm-up generations, TTFT from a
+    one-token generation, TPOT = (total - TTFT) / (steps - 1), tokens/s = generated tokens / total.  The prompt is
+    ``prompt_len`` random token ids (the reference's text prompts need its tokenizer files)."""
+    import platform
+    from transformers import AutoModelForCausalLM, Qwen2Config
+
+    if threads:
+        torch.set_num_threads(threads)
+    cfg = Qwen2Config(vocab_size=151936, hidden_size=896, intermediate_size=4864, num_hidden_layers=24,
+                      num_attention_heads=14, num_key_value_heads=2, max_position_embeddings=32768, rope_theta=1e6,
+                      rms_norm_eps=1e-6, tie_word_embeddings=True, attn_implementation="sdpa")
+    torch.manual_seed(0)
+    model = AutoModelForCausalLM.from_config(cfg).float().eval()
+    ids = torch.randint(0, cfg.vocab_size, (1, prompt_len))
+    att = torch.ones_like(ids)
+    kw = dict(do_sample=False, pad_token_id=0)
+    with torch.no_grad():
+        for _ in range(2):
+            model.generate(ids, attention_mask=att, min_new_tokens=8, max_new_tokens=8, **kw)
+        t0 = time.perf_counter()
+        model.generate(ids, attention_mask=att, min_new_tokens=1, max_new_tokens=1, **kw)
+        ttft = time.perf_counter() - t0
+        t0 = time.perf_counter()
+        out = model.generate(ids, attention_mask=att, min_new_tokens=gen_len, max_new_tokens=gen_len, **kw)
+        total = time.perf_counter() - t0
+    steps = out.shape[1] - prompt_len
+    cpu = platform.processor() or platform.machine()
+    try:
+        for line in open("/proc/cpuinfo"):
+            if line.startswith("model name"):
+                cpu = line.split(":", 1)[1].strip()
+                break
+    except OSError:
+        pass
+    return {"value": round(steps / total, 2), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+            "sample": f"bench_hf_baseline.py protocol (common.py:174-221) on the host: Qwen2.5-0.5B geometry, random weights, "
+                      f"HF transformers sdpa fp32, batch 1, greedy, prompt {prompt_len} ids, 2 x 8-token warm-up, {steps} generated tokens",
+            "ttft_ms": round(ttft * 1e3, 1), "tpot_ms": round((total - ttft) / max(steps - 1, 1) * 1e3, 2),
+            "sample_seconds": round(total + ttft, 1), "cpu_model": cpu, "host_cores": os.cpu_count()}
 
 
 def cpu_baseline(geo, batch, ctx, layers, quant):
@@ -240,13 +306,27 @@ def main():
             marks["t0"] = time.perf_counter()
 
     use_graph = not args.no_graph
-    graph_note = "hipGraph"
+    graph_note = "hipGraph" if use_graph else "eager (--no-graph)"
+    graph_error = None
     try:
         out = engine.decode(first, total, use_graph=use_graph, on_step=on_step)
-    except Exception as exc:  # graph capture refused (e.g. collective not capturable): measured eagerly
+    except Exception as exc:
         if not use_graph:
             raise
-        graph_note = f"eager (graph capture failed: {type(exc).__name__})"
+        graph_error = f"{type(exc).__name__}: {exc}"
+        out = None
+    if use_graph and world > 1:
+        # every rank must measure the same thing: one refusal turns the whole job eager (and the line says so)
+        flag = torch.tensor([0 if graph_error else 1], device=dev, dtype=torch.int32)
+        torch.distributed.all_reduce(flag, op=torch.distributed.ReduceOp.MIN)
+        if int(flag.item()) == 0 and graph_error is None:
+            graph_error = "graph capture failed on another rank"
+    if graph_error is not None:
+        # NOT silent: the JSON line carries "graph": false and the reason; stderr too
+        print(f"[bench] hipGraph capture FAILED ({graph_error}); measuring eager launches", file=sys.stderr, flush=True)
+        use_graph = False
+        graph_note = "eager (graph capture failed)"
+        marks.clear()
         engine = DecodeEngine(model, max_batch=args.batch, max_seq_len=args.ctx + total + 8, device=dev)
         first = engine.synthetic_context(args.batch, args.ctx, seed=1 + ps.get_dp_rank(), scattered=args.scattered)
         out = engine.decode(first, total, use_graph=False, on_step=on_step)
@@ -274,7 +354,7 @@ def main():
         "dtype": {"int4": "f16 (int4 weights, fp32 accumulate)", "int8": "f16 (int8 weights, fp32 accumulate)",
                   "fp8": "f16 (fp8-e4m3 weights, fp32 accumulate)", "smoothquant": "int8 (int32 accumulate, f16 epilogue)",
                   "none": "f16 (fp32 accumulate)"}[args.quant],
-        "data": "synthetic",
+        "data": "synthetic", "graph": bool(use_graph), "graph_error": graph_error,
         "config": {"workload": f"{args.model} {args.quant} decode, batch {args.batch}/replica, ctx {args.ctx}->"
                                f"{args.ctx + total}, {graph_note}" + (", scattered KV rows" if args.scattered else ""),
                    "global_batch": global_batch,
@@ -287,10 +367,14 @@ def main():
         rf = gemm_roofline(model, args.batch, args.quant) if quant is not None else None
         result["roofline"] = rf
         if world == 1 and not args.no_cpu_baseline:
-            try:
-                result["cpu_baseline"] = cpu_baseline(geo, args.batch, args.ctx, args.cpu_layers, args.quant)
+            try:  # SURVEY 8(d) / BASELINE configs[0]: the reference's CPU-runnable case, its protocol
+                result["cpu_baseline"] = cpu_baseline_protocol()
             except Exception as exc:  # never lose the GPU line to a host-side hiccup
                 result["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
+            try:  # second, labelled entry: the CPU oracle (checker port) on a slice of the headline workload
+                result["cpu_baseline"]["oracle_port"] = cpu_baseline(geo, args.batch, args.ctx, args.cpu_layers, args.quant)
+            except Exception as exc:
+                result["cpu_baseline"]["oracle_port"] = {"error": f"{type(exc).__name__}: {exc}"}
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.barrier()

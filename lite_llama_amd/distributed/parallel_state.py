@@ -20,6 +20,7 @@ _TP_GROUP = None
 _DP_RANK = 0
 _DP_WORLD_SIZE = 1
 _OWNS_PG = False
+_FORCE_COLLECTIVE = False  # test knob (LL_TP_FORCE_COLLECTIVE): a world of ONE still issues its all-reduces on the backend
 
 
 def grid_coordinates(global_rank: int, tp_size: int, dp_size: int) -> tuple[int, int]:
@@ -44,11 +45,14 @@ def _backend() -> str:
 def init_parallel(global_rank: int = 0, tp_size: int = 1, dp_size: int = 1, master_port: int = 29500) -> None:
     """Place this process in the ``dp_size x tp_size`` grid; creates one TP group per replica.
     Blocks in the rendezvous until all ranks joined when ``tp_size > 1``."""
-    global _TP_RANK, _TP_WORLD_SIZE, _TP_GROUP, _DP_RANK, _DP_WORLD_SIZE, _OWNS_PG
+    global _TP_RANK, _TP_WORLD_SIZE, _TP_GROUP, _DP_RANK, _DP_WORLD_SIZE, _OWNS_PG, _FORCE_COLLECTIVE
     _DP_RANK, _TP_RANK = grid_coordinates(global_rank, tp_size, dp_size)
     _DP_WORLD_SIZE = dp_size
     _TP_WORLD_SIZE = tp_size
-    if tp_size <= 1:
+    # LL_TP_FORCE_COLLECTIVE=1 (tests): a single rank joins a real process group and every row-parallel projection
+    # really calls the backend's all-reduce -- proves RCCL collectives inside a captured step on a one-GPU box
+    _FORCE_COLLECTIVE = bool(os.environ.get("LL_TP_FORCE_COLLECTIVE")) and tp_size * dp_size == 1
+    if tp_size <= 1 and not _FORCE_COLLECTIVE:
         return
     world = tp_size * dp_size
     os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
@@ -76,6 +80,12 @@ def destroy_parallel() -> None:
     if _TP_GROUP is not None and _OWNS_PG and dist.is_initialized():
         dist.destroy_process_group()
     _TP_RANK, _TP_WORLD_SIZE, _TP_GROUP, _DP_RANK, _DP_WORLD_SIZE, _OWNS_PG = 0, 1, None, 0, 1, False
+    global _FORCE_COLLECTIVE
+    _FORCE_COLLECTIVE = False
+
+
+def collective_forced() -> bool:
+    return _FORCE_COLLECTIVE
 
 
 destroy_tensor_parallel = destroy_parallel
@@ -109,7 +119,7 @@ def divide(a: int, b: int, what: str = "") -> int:
 
 def all_reduce_tp(tensor: torch.Tensor) -> torch.Tensor:
     """In-place SUM over the TP group; identity when ``world_size == 1``."""
-    if _TP_WORLD_SIZE <= 1:
+    if _TP_WORLD_SIZE <= 1 and not _FORCE_COLLECTIVE:
         return tensor
     dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=_TP_GROUP)
     return tensor

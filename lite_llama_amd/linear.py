@@ -7,7 +7,7 @@ from __future__ import annotations
 import torch
 import torch.nn as nn
 
-from .distributed.parallel_state import all_reduce_tp, divide, get_tp_world_size
+from .distributed.parallel_state import all_reduce_tp, collective_forced, divide, get_tp_world_size
 from .quantization import QuantConfig, get_linear_method
 
 
@@ -66,7 +66,8 @@ class RowParallelLinear(LinearBase):
     def forward(self, x: torch.Tensor, partials_ok: bool = False):
         """``partials_ok`` (extension): the caller feeds the result to ``skip_rmsnorm_partials`` and accepts a
         :class:`PartialSums` -- only taken without tensor parallelism (the all-reduce needs the finished sums)."""
-        if partials_ok and get_tp_world_size() == 1 and hasattr(self.quant_method, "apply_partials"):
+        if (partials_ok and get_tp_world_size() == 1 and not collective_forced()
+                and hasattr(self.quant_method, "apply_partials")):
             out = self.quant_method.apply_partials(self, x)
             if out is not None:
                 return out
