@@ -106,8 +106,10 @@ class DecodeEngine:
 
     # ------------------------------------------------------------------ prefill ----- #
     @torch.no_grad()
-    def prefill(self, prompt_ids: torch.Tensor, prompt_lens: torch.Tensor | None = None) -> torch.Tensor:
-        """``prompt_ids [B, Lp]`` (right-padded) -> greedy next token per row ``[B]``."""
+    def prefill(self, prompt_ids: torch.Tensor, prompt_lens: torch.Tensor | None = None, sampling=None) -> torch.Tensor:
+        """``prompt_ids [B, Lp]`` (right-padded) -> next token per row ``[B]``: greedy, or -- with ``sampling`` -- drawn by
+        the same sampler as every later token (llm_engine.py:168-176: the prefill step samples like a decode step; no
+        token has been generated yet, so the repetition penalty has nothing to act on)."""
         b, lp = prompt_ids.shape
         dev = self.device
         self.pool.reset()
@@ -130,7 +132,10 @@ class DecodeEngine:
         last = self.model(prompt_ids, position_ids, info, logits_rows=rows)
         self._positions = prompt_lens.long().clone().view(b, 1)
         self._batch = b
-        return greedy_argmax(last)
+        if sampling is None or sampling.temperature == 0.0:
+            return greedy_argmax(last)
+        uniform = torch.rand(b, device=dev)
+        return Sampler().sample(last, sampling, None, uniform=uniform).view(-1)
 
     @torch.no_grad()
     def synthetic_context(self, batch: int, ctx_len: int, seed: int = 0, scattered: bool = False) -> torch.Tensor:
@@ -171,9 +176,12 @@ class DecodeEngine:
         if max_new_tokens > 1:
             self.pool.alloc(b * (max_new_tokens - 1))
         self._input_ids = first_tokens.view(b, 1).clone()
-        self._out = torch.zeros(b, max_new_tokens, dtype=torch.long, device=dev)
-        self._step = torch.zeros(1, dtype=torch.long, device=dev)
-        self._row_base = torch.arange(b, device=dev) * max_new_tokens
+        # column 0 holds the token sampled by the prefill step: it is part of the generated span the repetition
+        # penalty looks at from the second token on (llm_engine.py:168-176: GeneratedSpan over tokens[:, :cur_pos])
+        self._out = torch.zeros(b, max_new_tokens + 1, dtype=torch.long, device=dev)
+        self._out[:, 0] = first_tokens.view(b)
+        self._step = torch.ones(1, dtype=torch.long, device=dev)
+        self._row_base = torch.arange(b, device=dev) * (max_new_tokens + 1)
 
     def _step_body(self):
         """forward -> greedy sample -> record -> advance metadata (all on device)."""
@@ -265,7 +273,7 @@ class DecodeEngine:
                 info.max_actual_seq_len = int(info.max_actual_seq_len)  # eager: exact value
                 self._step_body()
                 info.max_actual_seq_len += 1
-        return self._out
+        return self._out[:, 1:]
 
     def _snapshot(self):
         info = self.info

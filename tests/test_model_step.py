@@ -289,3 +289,67 @@ def test_engine_sampling_path_graph_equals_eager():
     pen = types.SimpleNamespace(temperature=0.7, top_p=1e-6, repetition_penalty=1.3)
     a, b = run(pen, True), run(pen, False)
     assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+def test_engine_penalised_decode_follows_the_reference_loop():
+    """The generation loop of the reference (engine/llm_engine.py:150-176) restated step by step: the prefill step samples
+    the first token with the same sampler, and from then on the repetition penalty sees EVERY generated token --
+    the prefill-sampled one included (GeneratedSpan over tokens[:, :cur_pos]).  With a vanishing top_p the draw is the
+    arg-max of the penalised logits, so the engine (graph and eager) must reproduce the restated loop token by token."""
+    from lite_llama_amd.executor import DecodeEngine
+    from oracle import oracle as O
+
+    d, params = _load()
+    m = _hip_model(params, None)
+    ids = torch.from_numpy(d["prompt_ids"]).cuda()
+    lens = torch.from_numpy(d["lens"]).int().cuda()
+    sp = types.SimpleNamespace(temperature=0.7, top_p=1e-6, repetition_penalty=1.6)
+    steps = 10
+    runs = []
+    for use_graph in (True, False):
+        eng = DecodeEngine(m, max_batch=2, max_seq_len=64)
+        first = eng.prefill(ids, lens, sampling=sp)
+        runs.append((first.cpu(), eng.decode(first, steps, use_graph=use_graph, sampling=sp).cpu()))
+    assert torch.equal(runs[0][0], runs[1][0]) and torch.equal(runs[0][1], runs[1][1])
+    first, toks = runs[0]
+    assert torch.equal(first, torch.from_numpy(d["first_tokens"]))  # nothing generated yet: the penalty cannot act
+    # ---- the reference loop, restated over the engine's own eager logits (teacher-forced with its tokens) ----
+    eng = DecodeEngine(m, max_batch=2, max_seq_len=64)
+    f2 = eng.prefill(ids, lens)
+    logits_seen = []
+    orig = m.forward
+
+    def spy(*a, **k):
+        out = orig(*a, **k)
+        logits_seen.append(out[:, -1].detach().float().cpu())
+        return out
+
+    m.forward = spy
+    try:
+        # feed the engine's penalised tokens back so that the contexts are identical
+        eng._sampling = sp
+        eng._begin_decode(f2, steps)
+        for i in range(steps):
+            eng.info.max_actual_seq_len = int(eng.info.max_actual_seq_len)
+            lg = m(eng._input_ids, eng._positions, eng.info)[:, -1]
+            eng._advance(toks[:, i].cuda())
+            eng.info.max_actual_seq_len += 1
+    finally:
+        m.forward = orig
+    B = toks.shape[0]
+    generated = first.view(B, 1)
+    for i in range(steps):
+        lg = logits_seen[i].half()
+        mask = torch.ones_like(generated, dtype=torch.bool)
+        pen = O.apply_repetition_penalty(lg, generated, mask, sp.repetition_penalty)
+        want = pen.float().argmax(-1)
+        top2 = pen.float().topk(2, -1).values
+        decided = (top2[:, 0] - top2[:, 1]) > 2e-2  # skip rows whose top two tie within fp16 noise
+        assert torch.equal(toks[decided, i], want[decided]), (i, toks[:, i], want)
+        generated = torch.cat([generated, toks[:, i].view(B, 1)], dim=1)
+    # the penalty on the prefill-sampled token matters in this run: dropping it from the span changes the path
+    lg0 = logits_seen[0].half()
+    without = lg0.float().argmax(-1)
+    with_pen = O.apply_repetition_penalty(lg0, first.view(B, 1), torch.ones(B, 1, dtype=torch.bool), sp.repetition_penalty).float().argmax(-1)
+    assert torch.equal(toks[:, 0], with_pen) or not torch.equal(without, with_pen)
