@@ -12,6 +12,8 @@
 //     (no data movement); V rows are staged once through LDS to be read k(token)-major.
 //   * stage 2: log-sum-exp merge of the per-partition partials (fp32 scratch).
 // Numerics follow the reference: fp32 scores/accumulators, plain exp, plain scale.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -75,8 +77,12 @@ struct FdRope {
 // decode graph, the merge itself ~1 us).  Partials are written through (sc1), a relaxed agent-scope
 // counter orders them, the merging wave reads them with coherent (sc1) loads and zeroes the counter.
 // GS: upper bound (4, 8 or 16) of the query heads per KV head handled by this wave (merge layout).
-template <int DT, int D, bool FUSE, bool ROPE, int GS>
-__global__ __launch_bounds__(64) void fd_stage1(
+// GROUPED (decode contexts of up to FD_GROUP_MAX partitions): ONE workgroup per (row, KV head group), one wave per
+// partition; the partials meet in LDS and wave 0 merges them -- no partial stores, no counter, no coherent
+// re-load: the merge tail shrinks from two global round trips (~5 us at batch 64 x ctx 512) to a barrier.
+#define FD_GROUP_MAX 8
+template <int DT, int D, bool FUSE, bool ROPE, int GS, bool GROUPED>
+__global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     const int32_t* __restrict__ table, const void* __restrict__ b_req_idx,
     const void* __restrict__ b_seq_len, float* __restrict__ mid_o, float* __restrict__ mid_lse,
@@ -86,11 +92,13 @@ __global__ __launch_bounds__(64) void fd_stage1(
   constexpr int NS = D / 32;      // MFMA k-steps over the head dim
   constexpr int NT = D / 16;      // output d-tiles
   constexpr int VSTR = D + 8;     // padded LDS row stride (elements)
-  __shared__ __attribute__((aligned(16))) uint16_t lds_v[32 * VSTR];
-
-  const int lane = threadIdx.x;
+  static_assert(!GROUPED || (FUSE && 32 * VSTR * 2 >= (16 * D + 16) * 4), "a wave's V tile doubles as its partial record");
+  extern __shared__ __attribute__((aligned(16))) uint16_t lds_all[];
+  const int lane = threadIdx.x & 63;
+  const int wave = GROUPED ? __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)) : 0;
+  uint16_t* lds_v = lds_all + wave * (32 * VSTR);  // this wave's V staging tile
   const int t = lane & 15, c = lane >> 4;
-  const int part = blockIdx.x;
+  const int part = GROUPED ? wave : (int)blockIdx.x;
   const int kvh = blockIdx.y % hkv;
   const int hg = blockIdx.y / hkv;
   const int b = blockIdx.z;
@@ -110,6 +118,7 @@ __global__ __launch_bounds__(64) void fd_stage1(
         for (int dd = c; dd < D; dd += 4) out[b * o_sb + (int64_t)head * o_sh + dd] = from_f32<DT>(nan);
       }
     }
+    if constexpr (GROUPED) __syncthreads();  // the workgroup's one barrier (the waves with tokens meet here before the merge)
     return;
   }
   const int64_t end = seq_len < start + FD_PART ? seq_len : start + FD_PART;
@@ -203,6 +212,13 @@ __global__ __launch_bounds__(64) void fd_stage1(
     _Pragma("unroll") for (int s = 0; s < NS; ++s) vb##S[s] = *reinterpret_cast<const Q4*>(vB_ + s * 32); \
   }
 
+  // The V tile belongs to ONE wave: its LDS operations execute in order, so within a multi-wave (GROUPED) workgroup a
+  // drained counter orders write -> read; the single-wave form keeps the workgroup barrier.
+#define FD_WAVE_SYNC()                                                    \
+  do {                                                                    \
+    if constexpr (GROUPED) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); \
+    else __syncthreads();                                                 \
+  } while (0)
   // ---- one 32-token tile: S^T, online softmax, O^T += V^T P^T ----
 #define FD_COMPUTE(S, TI)                                                                      \
   {                                                                                            \
@@ -242,12 +258,12 @@ __global__ __launch_bounds__(64) void fd_stage1(
     pf.z = pack2<DT>(p[4], p[5]);                                                              \
     pf.w = pack2<DT>(p[6], p[7]);                                                              \
     /* stage V rows through LDS (zero rows past the end: garbage could be NaN) */              \
-    __syncthreads(); /* previous tile's reads done */                                          \
+    FD_WAVE_SYNC(); /* previous tile's reads done */                                           \
     _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                           \
       *reinterpret_cast<Q4*>(&lds_v[t * VSTR + s * 32 + c * 8]) = okA ? va##S[s] : Q4{0, 0, 0, 0};        \
       *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + s * 32 + c * 8]) = okB ? vb##S[s] : Q4{0, 0, 0, 0}; \
     }                                                                                          \
-    __syncthreads();                                                                           \
+    FD_WAVE_SYNC();                                                                            \
     /* O^T[d][head] += V^T[d][tok] . P^T[tok][head] */                                         \
     _Pragma("unroll") for (int dt = 0; dt < NT; ++dt) {                                        \
       uint32_t w[4];                                                                           \
@@ -311,7 +327,74 @@ __global__ __launch_bounds__(64) void fd_stage1(
   }
 #undef FD_LOAD
 #undef FD_COMPUTE
+#undef FD_WAVE_SYNC
 
+  if constexpr (GROUPED) {
+    int np = (int)((seq_len + FD_PART - 1) / FD_PART);
+    if (np > nparts) np = nparts;
+    constexpr int REC = 32 * VSTR / 2;  // floats per wave record: [16 heads][D] normalised partial + [16] log-sum-exp
+    if (np > 1 && head_ok) {
+      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last tile's V reads are done: the tile becomes the record
+      float* rec = reinterpret_cast<float*>(lds_v);
+      const float inv = 1.0f / d_i;
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) {
+        f32x4 o = ot[dt];
+        o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
+        *reinterpret_cast<f32x4*>(rec + t * D + dt * 16 + 4 * c) = o;
+      }
+      if (c == 0) rec[16 * D + t] = m_i + logf(d_i);
+    }
+    __syncthreads();
+    if (wave != 0) return;
+    if (np == 1) {
+      // single partition: stage 2 computes (0*0 + 1*(o/d)) / (0*0 + 1) -- the same value
+      if (!head_ok) return;
+      uint16_t* orow = out + b * o_sb + (int64_t)head * o_sh + 4 * c;
+      const float inv = 1.0f / d_i;
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) {
+        uint16_t o4[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) o4[e] = from_f32<DT>(ot[dt][e] * inv);
+        *reinterpret_cast<uint2*>(orow + dt * 16) =
+            uint2{(uint32_t)o4[0] | ((uint32_t)o4[1] << 16), (uint32_t)o4[2] | ((uint32_t)o4[3] << 16)};
+      }
+      return;
+    }
+    // merge the np records in partition order: the recurrence of fd_stage2, element by element (same values as
+    // the global-memory merge below and as the two-launch form)
+    constexpr int D4 = D / 4;
+    constexpr int NSL = (GS * D4 + 63) / 64;
+    const int nvalid = groups - hg * 16 < 16 ? groups - hg * 16 : 16;
+    uint16_t* out_g = out + b * o_sb + (int64_t)(kvh * groups + hg * 16) * o_sh;
+    const float* recs = reinterpret_cast<const float*>(lds_all);
+#pragma unroll
+    for (int j = 0; j < NSL; ++j) {
+      const int sidx = lane + 64 * j;
+      const int hl_s = sidx / D4, d4 = sidx % D4;
+      if (hl_s >= nvalid) continue;
+      float mm = -INFINITY, dd = 0.f;
+      f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+      for (int pp = 0; pp < np; ++pp) {
+        const float* rec = recs + pp * REC;
+        const f32x4 v = *reinterpret_cast<const f32x4*>(rec + hl_s * D + d4 * 4);
+        const float l = rec[16 * D + hl_s];
+        const float m_new = fmaxf(mm, l);
+        const float alpha = expf(mm - m_new), w = expf(l - m_new);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) acc[e] = acc[e] * alpha + w * v[e];
+        dd = dd * alpha + w;
+        mm = m_new;
+      }
+      uint16_t o4[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o4[e] = from_f32<DT>(acc[e] / dd);
+      *reinterpret_cast<uint2*>(out_g + (int64_t)hl_s * o_sh + d4 * 4) =
+          uint2{(uint32_t)o4[0] | ((uint32_t)o4[1] << 16), (uint32_t)o4[2] | ((uint32_t)o4[3] << 16)};
+    }
+    return;
+  }
   if constexpr (!FUSE) {
     if (head_ok) {
       const float inv = 1.0f / d_i;
@@ -500,20 +583,36 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
   const bool fuse = counters != nullptr && (o_sb % 4 == 0) && (o_sh % 4 == 0) && ((uintptr_t)out % 8 == 0);
   if (rope && (!fuse || hgroups != 1 || d < 64)) return LL_ERR_SHAPE;
   const FdRope rp = rope ? *rope : FdRope{};
-#define LL_FD1(DD, FU, RO, GG)                                                                       \
-  fd_stage1<DT, DD, FU, RO, GG><<<grid, 64, 0, st>>>((const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, \
-                                                     table, req, seq, mid_o, mid_lse, hq, hkv, nparts, scale, q_sb, \
-                                                     q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w, (uint16_t*)out, \
-                                                     o_sb, o_sh, counters, rp)
+  // one workgroup per (row, KV head group) with a wave per partition while the context fits FD_GROUP_MAX partitions
+  const bool grouped = fuse && nparts >= 2 && nparts <= FD_GROUP_MAX && !getenv("LL_FD_UNGROUPED");
+#define LL_FD1X(DD, FU, RO, GG, GR)                                                                  \
+  {                                                                                                  \
+    constexpr int tile_bytes_ = 32 * (DD + 8) * 2;                                                   \
+    if (GR) {                                                                                        \
+      static bool attr_ = false;                                                                     \
+      if (!attr_) {                                                                                  \
+        (void)hipFuncSetAttribute((const void*)fd_stage1<DT, DD, FU, RO, GG, GR>,                    \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, FD_GROUP_MAX * tile_bytes_); \
+        attr_ = true;                                                                                \
+      }                                                                                              \
+    }                                                                                                \
+    fd_stage1<DT, DD, FU, RO, GG, GR><<<(GR) ? dim3(1, grid.y, grid.z) : grid, (GR) ? 64 * nparts : 64, \
+                                        ((GR) ? nparts : 1) * tile_bytes_, st>>>(                   \
+        (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, table, req, seq, mid_o, mid_lse, hq, hkv, nparts, \
+        scale, q_sb, q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w, (uint16_t*)out, o_sb, o_sh, counters, rp); \
+  }
+#define LL_FD1(DD, FU, RO, GG)                        \
+  if (grouped) { if constexpr (FU) LL_FD1X(DD, FU, RO, GG, true) } \
+  else LL_FD1X(DD, FU, RO, GG, false)
 #define LL_FD1G(DD, RO)                      \
-  if (groups <= 4) LL_FD1(DD, true, RO, 4);  \
-  else if (groups <= 8) LL_FD1(DD, true, RO, 8); \
+  if (groups <= 4) LL_FD1(DD, true, RO, 4)   \
+  else if (groups <= 8) LL_FD1(DD, true, RO, 8) \
   else LL_FD1(DD, true, RO, 16)
 #define LL_FD1D(DD)                   \
   if (rope) {                         \
-    if constexpr (DD >= 64) { LL_FD1G(DD, true); } \
-  } else if (fuse) { LL_FD1G(DD, false); }         \
-  else LL_FD1(DD, false, false, 16)
+    if constexpr (DD >= 64) { LL_FD1G(DD, true) } \
+  } else if (fuse) { LL_FD1G(DD, false) }         \
+  else LL_FD1X(DD, false, false, 16, false)
   switch (d) {
     case 32: LL_FD1D(32); break;
     case 64: LL_FD1D(64); break;
@@ -524,6 +623,7 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
 #undef LL_FD1D
 #undef LL_FD1G
 #undef LL_FD1
+#undef LL_FD1X
   if (!fuse)
     fd_stage2<DT><<<dim3((unsigned)hq, (unsigned)batch), d, 0, st>>>((uint16_t*)out, mid_o, mid_lse, seq, hq, d,
                                                                      nparts, o_sb, o_sh, seq_w);
