@@ -178,6 +178,10 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     }
   }
 
+  // scores are kept in the log2 domain (one v_exp_f32 per probability; plain expf costs ~15 VALU each): the
+  // running maximum m_i is in log2 units and is converted back where the log-sum-exp record is written
+  const float scale2 = scale * 1.44269504088896340736f;
+  const uint16_t* vtr = lds_v + (4 * c + (t >> 2)) * VSTR + (t & 3) * 4;
   float m_i = -INFINITY, d_i = 0.f;
   f32x4 ot[NT];
 #pragma unroll
@@ -233,18 +237,18 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
       const bool va_ok = pos0 + 4 * c + r < end;                                               \
       const bool vb_ok = pos0 + 16 + 4 * c + r < end;                                          \
-      sc[r] = va_ok ? sa[r] * scale : -INFINITY;                                               \
-      sc[4 + r] = vb_ok ? sb[r] * scale : -INFINITY;                                           \
+      sc[r] = va_ok ? sa[r] * scale2 : -INFINITY;                                              \
+      sc[4 + r] = vb_ok ? sb[r] * scale2 : -INFINITY;                                          \
       mx = fmaxf(mx, fmaxf(sc[r], sc[4 + r]));                                                 \
     }                                                                                          \
     mx = fmaxf(mx, __shfl_xor(mx, 16, 64));                                                    \
     mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                    \
     const float m_new = fmaxf(m_i, mx); /* finite: token pos0 is always valid */               \
-    const float alpha = expf(m_i - m_new);                                                     \
+    const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);                                   \
     float p[8];                                                                                \
     float ps = 0.f;                                                                            \
     _Pragma("unroll") for (int j = 0; j < 8; ++j) {                                            \
-      p[j] = expf(sc[j] - m_new);                                                              \
+      p[j] = __builtin_amdgcn_exp2f(sc[j] - m_new);                                            \
       ps += p[j];                                                                              \
     }                                                                                          \
     ps += __shfl_xor(ps, 16, 64);                                                              \
@@ -259,23 +263,33 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     pf.w = pack2<DT>(p[6], p[7]);                                                              \
     /* stage V rows through LDS (zero rows past the end: garbage could be NaN) */              \
     FD_WAVE_SYNC(); /* previous tile's reads done */                                           \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                           \
-      *reinterpret_cast<Q4*>(&lds_v[t * VSTR + s * 32 + c * 8]) = okA ? va##S[s] : Q4{0, 0, 0, 0};        \
-      *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + s * 32 + c * 8]) = okB ? vb##S[s] : Q4{0, 0, 0, 0}; \
+    if (pos0 + 32 <= end) { /* whole tile inside the context (wave-uniform): no masking */     \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                         \
+        *reinterpret_cast<Q4*>(&lds_v[t * VSTR + s * 32 + c * 8]) = va##S[s];                  \
+        *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + s * 32 + c * 8]) = vb##S[s];           \
+      }                                                                                        \
+    } else {                                                                                   \
+      _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                         \
+        *reinterpret_cast<Q4*>(&lds_v[t * VSTR + s * 32 + c * 8]) = okA ? va##S[s] : Q4{0, 0, 0, 0};        \
+        *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + s * 32 + c * 8]) = okB ? vb##S[s] : Q4{0, 0, 0, 0}; \
+      }                                                                                        \
     }                                                                                          \
     FD_WAVE_SYNC();                                                                            \
     /* O^T[d][head] += V^T[d][tok] . P^T[tok][head] */                                         \
     _Pragma("unroll") for (int dt = 0; dt < NT; ++dt) {                                        \
-      uint32_t w[4];                                                                           \
-      _Pragma("unroll") for (int jj = 0; jj < 4; ++jj) {                                       \
-        const int j0 = 2 * jj, j1 = 2 * jj + 1;                                                \
-        const int q0 = 16 * (j0 >> 2) + 4 * c + (j0 & 3);                                      \
-        const int q1 = 16 * (j1 >> 2) + 4 * c + (j1 & 3);                                      \
-        const uint32_t lo = lds_v[q0 * VSTR + dt * 16 + t];                                    \
-        const uint32_t hi = lds_v[q1 * VSTR + dt * 16 + t];                                    \
-        w[jj] = lo | (hi << 16);                                                               \
-      }                                                                                        \
-      const Q4 vf = {w[0], w[1], w[2], w[3]};                                                  \
+      /* V^T fragment: lane (d = t, group c) needs V[tok][dt*16 + t] for tok = 4c..4c+3 and 16+4c..+3.  The   \
+         transposing LDS read (benchmarks/probes/tr_probe.hip) treats the 16 lanes' 8-byte pieces as a 4 x 16  \
+         matrix -- lanes 4r..4r+3 supply row r, four columns each -- and hands lane t column t: lane t points \
+         at row 4c + (t >> 2), columns 4 (t & 3)..+3 of the d-tile */                                          \
+      const s16x4 tlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                \
+          (__attribute__((address_space(3))) s16x4*)(vtr + dt * 16));                          \
+      const s16x4 thi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(                                \
+          (__attribute__((address_space(3))) s16x4*)(vtr + 16 * VSTR + dt * 16));             \
+      Q4 vf;                                                                                   \
+      vf.x = (uint32_t)(uint16_t)tlo.x | ((uint32_t)(uint16_t)tlo.y << 16);                    \
+      vf.y = (uint32_t)(uint16_t)tlo.z | ((uint32_t)(uint16_t)tlo.w << 16);                    \
+      vf.z = (uint32_t)(uint16_t)thi.x | ((uint32_t)(uint16_t)thi.y << 16);                    \
+      vf.w = (uint32_t)(uint16_t)thi.z | ((uint32_t)(uint16_t)thi.w << 16);                    \
       f32x4 acc = ot[dt];                                                                      \
       acc[0] *= alpha; acc[1] *= alpha; acc[2] *= alpha; acc[3] *= alpha;                      \
       ot[dt] = mfma16<DT>(vf, pf, acc);                                                        \
@@ -343,7 +357,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
         o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
         *reinterpret_cast<f32x4*>(rec + t * D + dt * 16 + 4 * c) = o;
       }
-      if (c == 0) rec[16 * D + t] = m_i + logf(d_i);
+      if (c == 0) rec[16 * D + t] = m_i * 0.69314718055994530942f + logf(d_i);
     }
     __syncthreads();
     if (wave != 0) return;
@@ -405,7 +419,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
         o[0] *= inv; o[1] *= inv; o[2] *= inv; o[3] *= inv;
         *reinterpret_cast<f32x4*>(mo + dt * 16 + 4 * c) = o;
       }
-      if (c == 0) mid_lse[((int64_t)b * hq + head) * nparts + part] = m_i + logf(d_i);
+      if (c == 0) mid_lse[((int64_t)b * hq + head) * nparts + part] = m_i * 0.69314718055994530942f + logf(d_i);
     }
   } else {
     int np = (int)((seq_len + FD_PART - 1) / FD_PART);
@@ -424,7 +438,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
         // one 128-byte line per (head, partition): a line that the merging wave's own XCD has
         // written into (its own lse) could otherwise serve a stale copy of a neighbour's value
         if (c == 0)
-          __hip_atomic_store(mid_lse + (hrow + part) * FD_LSE_PAD, m_i + logf(d_i), __ATOMIC_RELAXED,
+          __hip_atomic_store(mid_lse + (hrow + part) * FD_LSE_PAD, m_i * 0.69314718055994530942f + logf(d_i), __ATOMIC_RELAXED,
                              __HIP_MEMORY_SCOPE_AGENT);
       }
       asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // the partials are out before the counter moves
