@@ -279,13 +279,16 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
     if (u < 12) { V3_TL(5 + 3 * u) }
     v3_barrier();
     if (u < 12) { V3_TL(6 + 3 * u) }
-    if (v3_walk_ends(cc)) {  // the consumers' k-half exchange, one round per 128-row block
-#pragma unroll
-      for (int f = 0; f < NF; ++f) v3_barrier();
+    if (v3_walk_ends(cc)) {  // the consumers' k-half exchange: 1 barrier, or 3 for 256-row tiles with two batch halves
+      const int nb = NF == 1 ? 1 : (p.m > 32 ? 3 : 1);
+      for (int f = 0; f < nb; ++f) v3_barrier();
     }
     v3_walk_next(cc, q);
   }
 }
+
+struct V3One { static constexpr int value = 1; };
+struct V3Two { static constexpr int value = 2; };
 
 template <int MT, int NF>
 struct V3Ops {  // everything a consumer wave needs for one unit
@@ -363,119 +366,153 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   };
   zero_acc();
 
-  // contribution counter of a parked partial, posted once its write-through stores have landed
-  // (the consumers have no other memory operation in flight: vmcnt(0) waits for exactly those stores)
+  // contribution counters of a parked partial (pend_n consecutive ones: one per batch half this wave finished),
+  // posted once its write-through stores have landed (the consumers have no other memory operation in flight:
+  // vmcnt(0) waits for exactly those stores)
   int32_t* pend_ctr = nullptr;
-  int pend_val = 0;
+  int pend_val = 0, pend_n = 0;
   int pending = 0;
   auto post_pending = [&]() {
     asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    if (lane < NF) __hip_atomic_fetch_add(pend_ctr + lane * 8, pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (lane < pend_n) __hip_atomic_fetch_add(pend_ctr + lane, pend_val, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
     pending = 0;
   };
 
-  // Finish one 32-row batch half `mt` of row group ng for tile t, whose chunks [c_lo, c_hi] this workgroup
-  // has just summed into v (k-halves already added).
-  auto flush = [&](f32x16& v, int mt, int t, int f, int c_lo, int c_hi) {
+  // Finish NM (1 or 2) 32-row batch halves mt0, mt0 + 1 of row group ng, 128-row block f of tile t, whose chunks
+  // [c_lo, c_hi] this workgroup has just summed into v0 (and v1) -- k-halves already added.
+  auto flush = [&](f32x16& v0, f32x16& v1, auto nm_tag, int mt0, int t, int f, int c_lo, int c_hi) {
+    constexpr int NM = decltype(nm_tag)::value;
     const int w0 = p.gt ? t * p.gt : (int)((uint32_t)(t * chunks) / (uint32_t)p.upw);  // first contributor of the tile
     const int slot = (int)blockIdx.x - w0;
     const int blk = t * NF + f;  // 128-row block
+    auto vsel = [&](int i) -> f32x16& { return i == 0 ? v0 : v1; };
     if (p.epi == 2) {
       // split-K partial mode: every workgroup of the tile group leaves its fp32 partial [slot][m][n] for the
       // consumer kernel (ll_skip_rmsnorm_partials) to add up -- no counters, no polling, no owner
-      const int64_t mrow = nl + mt * 32;
-      if (mrow < p.m) {
-        float* dst = reinterpret_cast<float*>(p.out) + ((int64_t)slot * p.m + mrow) * p.n + (int64_t)blk * V3_BN + ng * 32 + 4 * h;
 #pragma unroll
-        for (int g = 0; g < 4; ++g)
-          *reinterpret_cast<f32x4*>(dst + 8 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+      for (int i = 0; i < NM; ++i) {
+        const f32x16& v = vsel(i);
+        const int64_t mrow = nl + (mt0 + i) * 32;
+        if (mrow < p.m) {
+          float* dst = reinterpret_cast<float*>(p.out) + ((int64_t)slot * p.m + mrow) * p.n + (int64_t)blk * V3_BN + ng * 32 + 4 * h;
+#pragma unroll
+          for (int g = 0; g < 4; ++g)
+            *reinterpret_cast<f32x4*>(dst + 8 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+        }
       }
       return;
     }
-    int32_t* ctr = &p.counters[(blk * 4 + ng) * 2 + mt];
+    int32_t* ctr = &p.counters[(blk * 4 + ng) * 2 + mt0];
+    auto slab = [&](int sq, int mt) { return p.workspace + ((((int64_t)blk * p.slots + sq) * 4 + ng) * 2 + mt) * V3_FRAG; };
     if (c_hi != chunks - 1) {
-      // contributor: park the partial in this workgroup's slab (counter follows, see post_pending)
-      float* ws = p.workspace + ((((int64_t)blk * p.slots + slot) * 4 + ng) * 2 + mt) * V3_FRAG;
+      // contributor: park the partials in this workgroup's slab (counters follow, see post_pending)
 #pragma unroll
-      for (int g = 0; g < 4; ++g) {
-        const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-        float* dst = ws + (g * 64 + lane) * 4;
-        asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(o) : "memory");
+      for (int i = 0; i < NM; ++i) {
+        const f32x16& v = vsel(i);
+        float* ws = slab(slot, mt0 + i);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+          float* dst = ws + (g * 64 + lane) * 4;
+          asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(o) : "memory");
+        }
       }
-      if (f == 0) pend_ctr = ctr;  // block f's counter is NF * 8 further... see post_pending
+      pend_ctr = ctr;
       pend_val = c_hi - c_lo + 1;
+      pend_n = NM;
       pending = 1;
       return;
     }
     if (c_lo != 0) {
       // owner: chunks [0, c_lo) were summed by the `slot` lower-numbered contributors
       for (int spin = 0; spin < V3_SPIN_LIMIT; ++spin) {
-        const int seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        int seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        if constexpr (NM == 2) {
+          const int s1 = __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+          seen = seen < s1 ? seen : s1;
+        }
         if (__builtin_amdgcn_readfirstlane(seen) >= c_lo) break;
         __builtin_amdgcn_s_sleep(4);
       }
-      if (lane == 0) __hip_atomic_store(ctr, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (lane < NM) __hip_atomic_store(ctr + lane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       V3_TL(52)
       // slabs were written through (sc1) before their counter: coherent (sc1) loads, no acquire fence.
-      // Four slabs in flight per round trip; the tail of the last round is masked to +0.
-      for (int sl = 0; sl < slot; sl += 4) {
-        i32x4 va[4][4];
+      // Sixteen loads in flight per round trip (4 slabs x 1 batch half or 2 x 2); the tail of the last round is
+      // masked to +0.
+      constexpr int SLB = 4 / NM;
+      for (int sl = 0; sl < slot; sl += SLB) {
+        i32x4 va[SLB][NM][4];
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+        for (int j = 0; j < SLB; ++j) {
           const int sq = sl + j < slot ? sl + j : sl;
-          const float* src = p.workspace + ((((int64_t)blk * p.slots + sq) * 4 + ng) * 2 + mt) * V3_FRAG + lane * 4;
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(va[j][g]) : "v"(src + g * 256) : "memory");
+          for (int i = 0; i < NM; ++i) {
+            const float* src = slab(sq, mt0 + i) + lane * 4;
+#pragma unroll
+            for (int g = 0; g < 4; ++g)
+              asm volatile("global_load_dwordx4 %0, %1, off sc1" : "=v"(va[j][i][g]) : "v"(src + g * 256) : "memory");
+          }
         }
         asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
 #pragma unroll
-        for (int j = 0; j < 4; ++j)
+        for (int j = 0; j < SLB; ++j)
 #pragma unroll
-          for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(va[j][g]));  // uses stay below the wait
+          for (int i = 0; i < NM; ++i)
 #pragma unroll
-        for (int j = 0; j < 4; ++j) {
+            for (int g = 0; g < 4; ++g) asm volatile("" : "+v"(va[j][i][g]));  // uses stay below the wait
+#pragma unroll
+        for (int j = 0; j < SLB; ++j) {
           const int keep = sl + j < slot ? -1 : 0;
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
+          for (int i = 0; i < NM; ++i) {
+            f32x16& v = vsel(i);
 #pragma unroll
-            for (int e = 0; e < 4; ++e) v[4 * g + e] += __int_as_float(va[j][g][e] & keep);
+            for (int g = 0; g < 4; ++g)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) v[4 * g + e] += __int_as_float(va[j][i][g][e] & keep);
+          }
         }
       }
     }
     V3_TL(53)
-    const int64_t mrow = nl + mt * 32;
-    if (mrow >= p.m) return;
     const bool has_bias = p.bias != nullptr;
 #pragma unroll
-    for (int g = 0; g < 4; ++g) {
-      const int64_t nn = (int64_t)blk * V3_BN + ng * 32 + 8 * g + 4 * h;
-      uint16_t o[4];
+    for (int i = 0; i < NM; ++i) {
+      const f32x16& v = vsel(i);
+      const int64_t mrow = nl + (mt0 + i) * 32;
+      if (mrow >= p.m) continue;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        float f = v[4 * g + e];
-        if (has_bias) f += f16_bits_to_f32(p.bias[nn + e]);
-        o[e] = f32_to_f16_bits(f);
-      }
-      if (p.epi) {
-        // weight rows 2j / 2j+1 are gate_j / up_j: both land in this lane.  Same arithmetic as the
-        // stand-alone kernels: the two GEMM outputs rounded to fp16, then silu(g) * u in fp32.
-        const float g0 = f16_bits_to_f32(o[0]), u0 = f16_bits_to_f32(o[1]);
-        const float g1 = f16_bits_to_f32(o[2]), u1 = f16_bits_to_f32(o[3]);
-        const uint32_t s0 = f32_to_f16_bits(g0 * ll_sigmoidf(g0) * u0);
-        const uint32_t s1 = f32_to_f16_bits(g1 * ll_sigmoidf(g1) * u1);
-        *reinterpret_cast<uint32_t*>(p.out + mrow * (p.n >> 1) + (nn >> 1)) = s0 | (s1 << 16);
-      } else {
-        uint2 pk;
-        pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-        pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-        *reinterpret_cast<uint2*>(p.out + mrow * p.n + nn) = pk;
+      for (int g = 0; g < 4; ++g) {
+        const int64_t nn = (int64_t)blk * V3_BN + ng * 32 + 8 * g + 4 * h;
+        uint16_t o[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          float fv = v[4 * g + e];
+          if (has_bias) fv += f16_bits_to_f32(p.bias[nn + e]);
+          o[e] = f32_to_f16_bits(fv);
+        }
+        if (p.epi) {
+          // weight rows 2j / 2j+1 are gate_j / up_j: both land in this lane.  Same arithmetic as the
+          // stand-alone kernels: the two GEMM outputs rounded to fp16, then silu(g) * u in fp32.
+          const float g0 = f16_bits_to_f32(o[0]), u0 = f16_bits_to_f32(o[1]);
+          const float g1 = f16_bits_to_f32(o[2]), u1 = f16_bits_to_f32(o[3]);
+          const uint32_t s0 = f32_to_f16_bits(g0 * ll_sigmoidf(g0) * u0);
+          const uint32_t s1 = f32_to_f16_bits(g1 * ll_sigmoidf(g1) * u1);
+          *reinterpret_cast<uint32_t*>(p.out + mrow * (p.n >> 1) + (nn >> 1)) = s0 | (s1 << 16);
+        } else {
+          uint2 pk;
+          pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+          pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
+          *reinterpret_cast<uint2*>(p.out + mrow * p.n + nn) = pk;
+        }
       }
     }
   };
 
-  // End of a tile segment: the two k-halves of a row group exchange one batch half each through LDS, so
-  // that wave kh ends up with the complete sums of batch half kh (MT = 2), or kh = 0 with everything (MT = 1).
+  // End of a tile segment: the two k-halves of a row group exchange partial sums through LDS (4 KB per wave).
+  //   128-row tiles: wave kh ends up with the complete sums of batch half kh (MT = 2) or kh = 0 with everything (MT = 1);
+  //   256-row tiles: wave kh ends up with BOTH batch halves of 128-row block kh, so the two blocks' flushes (slab
+  //   stores, or counter wait + slab loads + epilogue) run side by side in the two waves instead of one after the other.
   auto segment_end = [&](int t, int c_lo, int c_hi) {
     float* red = reinterpret_cast<float*>(lds + LD::OFF_R) + ng * (2 * V3_FRAG);
     V3_TL(50)
@@ -493,32 +530,54 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         for (int e = 0; e < 4; ++e) a[4 * g + e] += o[e];
       }
     };
-    auto round = [&](f32x16& a0, f32x16& a1, int f) {  // one 128-row block: a0 / a1 = batch halves 0 / 1
+    auto xbarrier = [&]() { asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory"); };
+    if constexpr (NF == 1) {
       if constexpr (MT == 2) {
         f32x16 give, v;  // one copy of the exchange / flush code for both waves of the row group
 #pragma unroll
         for (int r = 0; r < 16; ++r) {
-          give[r] = kh == 0 ? a1[r] : a0[r];
-          v[r] = kh == 0 ? a0[r] : a1[r];
+          give[r] = kh == 0 ? acc1[r] : acc0[r];
+          v[r] = kh == 0 ? acc0[r] : acc1[r];
         }
         put(give, 1 - kh);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        xbarrier();
         V3_TL(51)
         get_add(v, kh);
-        flush(v, kh, t, f, c_lo, c_hi);
+        flush(v, v, V3One{}, kh, t, 0, c_lo, c_hi);
       } else {
-        if (kh == 1) put(a0, 0);
-        asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
+        if (kh == 1) put(acc0, 0);
+        xbarrier();
         if (kh == 0) {
-          get_add(a0, 0);
-          flush(a0, 0, t, f, c_lo, c_hi);
+          get_add(acc0, 0);
+          flush(acc0, acc0, V3One{}, 0, t, 0, c_lo, c_hi);
         }
       }
-    };
-    round(acc0, acc1, 0);
-    if constexpr (NF == 2) {
-      asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // block 0's exchange reads are done before the buffer is rewritten
-      round(acc2, acc3, 1);
+    } else {
+      // wave kh keeps block kh: round A moves the batch-half-0 partials, round B the batch-half-1 ones
+      f32x16 give, v0, v1;
+#pragma unroll
+      for (int r = 0; r < 16; ++r) {
+        give[r] = kh == 0 ? acc2[r] : acc0[r];
+        v0[r] = kh == 0 ? acc0[r] : acc2[r];
+      }
+      put(give, kh);
+      xbarrier();
+      V3_TL(51)
+      get_add(v0, 1 - kh);
+      if constexpr (MT == 2) {
+        xbarrier();  // the partner has read round A before round B overwrites the buffer
+#pragma unroll
+        for (int r = 0; r < 16; ++r) {
+          give[r] = kh == 0 ? acc3[r] : acc1[r];
+          v1[r] = kh == 0 ? acc1[r] : acc3[r];
+        }
+        put(give, kh);
+        xbarrier();
+        get_add(v1, 1 - kh);
+        flush(v0, v1, V3Two{}, 0, t, kh, c_lo, c_hi);
+      } else {
+        flush(v0, v0, V3One{}, 0, t, kh, c_lo, c_hi);
+      }
     }
     zero_acc();
   };
