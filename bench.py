@@ -158,8 +158,6 @@ def cpu_baseline_protocol(gen_len=256, prompt_len=32, threads=None):
     import platform
     from transformers import AutoModelForCausalLM, Qwen2Config
 
-    if threads:
-        torch.set_num_threads(threads)
     cfg = Qwen2Config(vocab_size=151936, hidden_size=896, intermediate_size=4864, num_hidden_layers=24,
                       num_attention_heads=14, num_key_value_heads=2, max_position_embeddings=32768, rope_theta=1e6,
                       rms_norm_eps=1e-6, tie_word_embeddings=True, attn_implementation="sdpa")
@@ -168,7 +166,25 @@ def cpu_baseline_protocol(gen_len=256, prompt_len=32, threads=None):
     ids = torch.randint(0, cfg.vocab_size, (1, prompt_len))
     att = torch.ones_like(ids)
     kw = dict(do_sample=False, pad_token_id=0)
+    all_threads = torch.get_num_threads()
     with torch.no_grad():
+        # thread count: a 0.5B model at batch 1 does not scale to every core of a big host (128 threads run it ~15x
+        # SLOWER than 16 on the 256-core EPYC of the GPU box); the protocol's "all threads" is therefore replaced by the
+        # best of a short probe over {all, 32, 16, 8} threads, and the count used is reported in "cores"
+        best = None
+        for nt in ([threads] if threads else sorted({all_threads, 32, 16, 8}, reverse=True)):
+            if nt > all_threads:
+                continue
+            torch.set_num_threads(nt)
+            model.generate(ids, attention_mask=att, min_new_tokens=2, max_new_tokens=2, **kw)
+            t0 = time.perf_counter()
+            model.generate(ids, attention_mask=att, min_new_tokens=4, max_new_tokens=4, **kw)
+            dt = time.perf_counter() - t0
+            if best is None or dt < best[0]:
+                best = (dt, nt)
+        torch.set_num_threads(best[1])
+        # bounded sample: the protocol's 256 tokens unless that would take much longer than ~30 s on this host
+        gen_len = max(16, min(gen_len, int(30.0 / max(best[0] / 4, 1e-3))))
         for _ in range(2):
             model.generate(ids, attention_mask=att, min_new_tokens=8, max_new_tokens=8, **kw)
         t0 = time.perf_counter()
@@ -186,7 +202,9 @@ def cpu_baseline_protocol(gen_len=256, prompt_len=32, threads=None):
                 break
     except OSError:
         pass
-    return {"value": round(steps / total, 2), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
+    used = torch.get_num_threads()
+    torch.set_num_threads(all_threads)
+    return {"value": round(steps / total, 2), "unit": "tokens/s", "cores": used, "kind": "port",
             "sample": f"bench_hf_baseline.py protocol (common.py:174-221) on the host: Qwen2.5-0.5B geometry, random weights, "
                       f"HF transformers sdpa fp32, batch 1, greedy, prompt {prompt_len} ids, 2 x 8-token warm-up, {steps} generated tokens",
             "ttft_ms": round(ttft * 1e3, 1), "tpot_ms": round((total - ttft) / max(steps - 1, 1) * 1e3, 2),
