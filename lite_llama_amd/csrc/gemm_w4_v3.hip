@@ -264,7 +264,10 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
   };
   const int wv = KIND == 0 ? 8 + L : 10 + L;  // (timeline builds)
   (void)wv;
-  const int pre = cnt < D ? cnt : D;
+  // Prologue: only the units the consumers need to START are requested before the first barrier (requesting the
+  // whole ring first costs its issue time -- the memory pipeline accepts ~37 KB/us -- before the first MFMA); the
+  // ring then fills two units per step until it runs D ahead.
+  const int pre = cnt < AHEAD ? cnt : AHEAD;
   for (int i = 0; i < pre; ++i) issue();
   V3_TL(2)
   v3_wait_units<OPS>(issued - (cnt < AHEAD ? cnt : AHEAD));  // units < AHEAD have landed
@@ -272,7 +275,9 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
   V3_TL(3)
   V3Walk cc = v3_walk_begin(q);
   for (int u = 0; u < cnt; ++u) {
-    if (issued < cnt) issue();
+    const int want = cnt < u + 1 + D ? cnt : u + 1 + D;
+    if (issued < want) issue();
+    if (issued < want) issue();
     if (u < 12) { V3_TL(4 + 3 * u) }
     const int need = cnt < u + 1 + AHEAD ? cnt : u + 1 + AHEAD;
     v3_wait_units<OPS>(issued - need);
