@@ -69,7 +69,14 @@ struct FdRope {
   int sel_w;
   uint16_t* pool_k;           // same storage as kc / vc, writable
   uint16_t* pool_v;
+  // q / k_new / v_new left by the fused q|k|v projection as fp32 split-K partials [qs][batch][row_w] (GROUPED only):
+  // the workgroup adds them up (+ bias, one fp16 rounding: the value the projection would have stored) into LDS
+  const float* qp;            // nullptr: q / kv_new are finished fp16 tensors
+  int qs;                     // number of partials (<= FD_QS_MAX)
+  int64_t qp_plane, qp_row;   // elements per partial, per batch row
+  const uint16_t* qbias;      // [row_w] or nullptr
 };
+#define FD_QS_MAX 8
 
 // grid = (nparts, hkv * head_groups, batch), block = 64 (one wave)
 // FUSE: the wave that finishes the LAST non-empty partition of its (row, KV head group) also does the
@@ -107,9 +114,66 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
   const bool head_ok = hl < groups;
   const int head = kvh * groups + hl;
 
+  // ---- q | k_new | v_new of this (row, KV head) from split-K partials: requested first (they depend on nothing
+  //      but the block index), summed and published to LDS once the dependent index loads have been issued ----
+  uint16_t* q_lds = lds_all + (GROUPED ? (int)(blockDim.x >> 6) : 1) * (32 * VSTR);
+  constexpr bool QPART_OK = GROUPED && ROPE;
+  const bool qpart = QPART_OK && rp.qp != nullptr;
+  f32x4 qacc[QPART_OK ? FD_QS_MAX : 1][QPART_OK ? 2 : 1];
+  int qe[2] = {0, 0};
+  int64_t qcol[2] = {0, 0};
+  bool qok[2] = {false, false};
+  if constexpr (QPART_OK) {
+    if (qpart) {
+      const int nq = groups * D;                // this KV head's query values, then its new K row, then its new V row
+      const int nslot = (nq + 2 * D) / 4;
+#pragma unroll
+      for (int it = 0; it < 2; ++it) {          // up to 2 float4 slots per lane (>= 2 waves: 128 lanes x 2 >= 288 slots at GQA 7)
+        const int slot = (int)threadIdx.x + it * (int)blockDim.x;
+        qok[it] = slot < nslot;
+        const int e = qok[it] ? slot * 4 : 0;
+        qe[it] = e;
+        qcol[it] = e < nq ? (int64_t)kvh * nq + e
+                          : (e < nq + D ? (int64_t)hq * D + (int64_t)kvh * D + (e - nq)
+                                        : (int64_t)hq * D + (int64_t)hkv * D + (int64_t)kvh * D + (e - nq - D));
+#pragma unroll
+        for (int sl = 0; sl < FD_QS_MAX; ++sl) {
+          const int ss = sl < rp.qs ? sl : 0;   // clamped; dropped below
+          qacc[sl][it] = *reinterpret_cast<const f32x4*>(rp.qp + ss * rp.qp_plane + b * rp.qp_row + qcol[it]);
+        }
+      }
+    }
+  }
+  auto publish_q = [&]() {
+    if constexpr (QPART_OK) {
+      if (qpart) {
+#pragma unroll
+        for (int it = 0; it < 2; ++it) {
+          f32x4 a = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int sl = 0; sl < FD_QS_MAX; ++sl)
+#pragma unroll
+            for (int e = 0; e < 4; ++e) a[e] += sl < rp.qs ? qacc[sl][it][e] : 0.f;
+          uint16_t o4[4];
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            float f = a[e];
+            if (rp.qbias) f += to_f32<DT>(rp.qbias[qcol[it] + e]);
+            o4[e] = from_f32<DT>(f);
+          }
+          if (qok[it])
+            *reinterpret_cast<uint2*>(q_lds + qe[it]) =
+                uint2{(uint32_t)o4[0] | ((uint32_t)o4[1] << 16), (uint32_t)o4[2] | ((uint32_t)o4[3] << 16)};
+        }
+        __syncthreads();  // every wave of the workgroup passes here exactly once (empty partitions included)
+      }
+    }
+  };
+
   const int64_t seq_len = fd_load_idx(b_seq_len, b, seq_w);
   const int64_t start = (int64_t)part * FD_PART;
   if (start >= seq_len) {  // empty partition stores nothing (flashdecoding.py:141-161)
+    publish_q();
     if constexpr (FUSE) {
       // a zero-length row has no merging wave: its first partition writes the 0/0 the reference's
       // stage 2 computes for it (:264-287)
@@ -124,16 +188,30 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
   const int64_t end = seq_len < start + FD_PART ? seq_len : start + FD_PART;
   const int64_t req = fd_load_idx(b_req_idx, b, req_w);
   const int32_t* trow = table + req * t_sb;
+  // Pool rows of the whole partition, requested now (the K/V gathers depend on them; everything up to the first
+  // gather overlaps this round trip)
+  const int64_t lastt = end - 1;
+  const int64_t tk0 = start + lane < lastt ? start + lane : lastt;
+  const int64_t tk1 = start + 64 + lane < lastt ? start + 64 + lane : lastt;
+  const int r0 = trow[tk0];
+  const int r1 = FD_PART == 128 ? trow[tk1] : r0;
+  publish_q();
 
   // Q^T fragments (MFMA B operand): lane (head t, group c) holds q[head][s*32 + c*8 .. +8] -- the
   // natural k order of MFMA step s, so the 4 lanes of a row read 64 contiguous bytes per instruction
   Q4 qf[NS];
+  if (qpart) {
 #pragma unroll
-  for (int s = 0; s < NS; ++s) {
-    if (head_ok)
-      qf[s] = *reinterpret_cast<const Q4*>(q + b * q_sb + (int64_t)head * q_sh + s * 32 + c * 8);
-    else
-      qf[s] = Q4{0, 0, 0, 0};
+    for (int s = 0; s < NS; ++s)
+      qf[s] = head_ok ? *reinterpret_cast<const Q4*>(q_lds + hl * D + s * 32 + c * 8) : Q4{0, 0, 0, 0};
+  } else {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) {
+      if (head_ok)
+        qf[s] = *reinterpret_cast<const Q4*>(q + b * q_sb + (int64_t)head * q_sh + s * 32 + c * 8);
+      else
+        qf[s] = Q4{0, 0, 0, 0};
+    }
   }
 
   constexpr int HS = ROPE ? NS / 2 : 1;
@@ -151,8 +229,8 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     const int wpart = (int)((seq_len - 1) / FD_PART) < nparts - 1 ? (int)((seq_len - 1) / FD_PART) : nparts - 1;
     if (hg == 0 && part == wpart) {
       const int64_t dstrow = fd_load_idx(rp.sel, b, rp.sel_w);
-      const uint16_t* kn = rp.kv_new + b * rp.kv_rs + (int64_t)kvh * D;
-      const uint16_t* vn = rp.kv_new + b * rp.kv_rs + (int64_t)(hkv + kvh) * D;
+      const uint16_t* kn = qpart ? q_lds + groups * D : rp.kv_new + b * rp.kv_rs + (int64_t)kvh * D;
+      const uint16_t* vn = qpart ? q_lds + groups * D + D : rp.kv_new + b * rp.kv_rs + (int64_t)(hkv + kvh) * D;
       if (lane < D / 16) {
         const int j = lane * 8;
         const U16x8 k1 = *reinterpret_cast<const U16x8*>(kn + j), k2 = *reinterpret_cast<const U16x8*>(kn + D / 2 + j);
@@ -187,15 +265,10 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
 #pragma unroll
   for (int i = 0; i < NT; ++i) ot[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
-  // Pool rows of the whole partition, fetched ONCE: lane l holds the rows of tokens start+l and
-  // start+64+l (clamped to the last valid token, so every later gather reads a valid row); the
-  // tiles pick theirs with a lane shuffle instead of a dependent table load per tile.
+  // (r0 / r1 above: lane l holds the pool rows of tokens start+l and start+64+l, clamped to the last valid token, so
+  // every later gather reads a valid row; the tiles pick theirs with a lane shuffle instead of a dependent table
+  // load per tile.)
   static_assert(FD_PART == 128 || FD_PART == 64, "the tile schedule below is written for 2 or 4 tiles of 32 tokens");
-  const int64_t lastt = end - 1;
-  const int64_t tk0 = start + lane < lastt ? start + lane : lastt;
-  const int64_t tk1 = start + 64 + lane < lastt ? start + 64 + lane : lastt;
-  const int r0 = trow[tk0];
-  const int r1 = FD_PART == 128 ? trow[tk1] : r0;
 
   // ---- gather of tile TI (32 tokens): lane (t, c) fetches rows TI*32+t and TI*32+16+t, d-range
   //      {s*32 + c*8 .. +8}, straight into MFMA fragment layout (per instruction the 4 lanes of a row
@@ -597,8 +670,12 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
   const bool fuse = counters != nullptr && (o_sb % 4 == 0) && (o_sh % 4 == 0) && ((uintptr_t)out % 8 == 0);
   if (rope && (!fuse || hgroups != 1 || d < 64)) return LL_ERR_SHAPE;
   const FdRope rp = rope ? *rope : FdRope{};
+  const bool grouped_ok = fuse && nparts >= 2 && nparts <= FD_GROUP_MAX;
+  // split-K partial inputs need the grouped form and two float4 slots per lane: (groups + 2) * d / 4 <= 2 * 64 * nparts
+  if (rope && rp.qp && (!grouped_ok || rp.qs < 1 || rp.qs > FD_QS_MAX || (groups + 2) * d / 4 > 128 * nparts || getenv("LL_FD_UNGROUPED")))
+    return LL_ERR_SHAPE;
   // one workgroup per (row, KV head group) with a wave per partition while the context fits FD_GROUP_MAX partitions
-  const bool grouped = fuse && nparts >= 2 && nparts <= FD_GROUP_MAX && !getenv("LL_FD_UNGROUPED");
+  const bool grouped = grouped_ok && !getenv("LL_FD_UNGROUPED");
 #define LL_FD1X(DD, FU, RO, GG, GR)                                                                  \
   {                                                                                                  \
     constexpr int tile_bytes_ = 32 * (DD + 8) * 2;                                                   \
@@ -606,12 +683,12 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
       static bool attr_ = false;                                                                     \
       if (!attr_) {                                                                                  \
         (void)hipFuncSetAttribute((const void*)fd_stage1<DT, DD, FU, RO, GG, GR>,                    \
-                                  hipFuncAttributeMaxDynamicSharedMemorySize, FD_GROUP_MAX * tile_bytes_); \
+                                  hipFuncAttributeMaxDynamicSharedMemorySize, FD_GROUP_MAX * tile_bytes_ + 18 * DD * 2); \
         attr_ = true;                                                                                \
       }                                                                                              \
     }                                                                                                \
     fd_stage1<DT, DD, FU, RO, GG, GR><<<(GR) ? dim3(1, grid.y, grid.z) : grid, (GR) ? 64 * nparts : 64, \
-                                        ((GR) ? nparts : 1) * tile_bytes_, st>>>(                   \
+                                        ((GR) ? nparts : 1) * tile_bytes_ + ((GR) ? 18 * DD * 2 : 0), st>>>( \
         (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, table, req, seq, mid_o, mid_lse, hq, hkv, nparts, \
         scale, q_sb, q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w, (uint16_t*)out, o_sb, o_sh, counters, rp); \
   }
@@ -703,8 +780,36 @@ extern "C" int ll_decode_attention(void* out, const void* q, const void* kv_new,
   if ((kv_row_stride | cs_row_stride) % 8 != 0 || !ll_aligned16(kv_new) || !ll_aligned16(cos_t) || !ll_aligned16(sin_t))
     return LL_ERR_ARG;
   const FdRope rp{(const uint16_t*)kv_new, kv_row_stride, (const uint16_t*)cos_t, (const uint16_t*)sin_t, cs_row_stride,
-                  positions, select_index, sel_width, (uint16_t*)k_cache, (uint16_t*)v_cache};
+                  positions, select_index, sel_width, (uint16_t*)k_cache, (uint16_t*)v_cache, nullptr, 0, 0, 0, nullptr};
   return fd_entry(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch, hq, hkv, d, max_len,
                   qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_b,
                   o_stride_h, table_stride_b, dtype, req_width, seq_width, counters, &rp, stream);
+}
+
+// ll_decode_attention whose q / k_new / v_new come as the fp32 split-K partials of the fused q|k|v projection
+// (ll_w4a16_matmul_prepacked epilogue 2): qkv_partials [s_count][batch][row_width] with row_width = (hq + 2 hkv) * d
+// (q heads, K heads, V heads), qkv_bias [row_width] (projection bias, dtype of the pool) or NULL.  x = fp16(sum of the
+// partials + bias) -- the value the projection would have stored -- then exactly ll_decode_attention.  Served for
+// contexts of 2..8 partitions (129..1024 tokens); LL_ERR_SHAPE otherwise: finish the sums and call ll_decode_attention.
+extern "C" int ll_decode_attention_partials(void* out, const float* qkv_partials, int s_count, const void* qkv_bias,
+                                            const void* cos_t, const void* sin_t, int64_t cs_row_stride,
+                                            const int64_t* positions, const void* select_index, int sel_width,
+                                            void* k_cache, void* v_cache, const int32_t* table, const void* b_req_idx,
+                                            const void* b_seq_len, int batch, int hq, int hkv, int d, int64_t max_len,
+                                            float qk_scale, int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t,
+                                            int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
+                                            int64_t table_stride_b, int dtype, int req_width, int seq_width, void* stream) {
+  if (!qkv_partials || !cos_t || !sin_t || !positions || !select_index) return LL_ERR_ARG;
+  if (sel_width != LL_I32 && sel_width != LL_I64) return LL_ERR_DTYPE;
+  if (cs_row_stride % 8 != 0 || !ll_aligned16(qkv_partials) || !ll_aligned16(cos_t) || !ll_aligned16(sin_t) || d % 4 != 0)
+    return LL_ERR_ARG;
+  const int64_t row_w = (int64_t)(hq + 2 * hkv) * d;
+  static int32_t dummy_counters = 0;  // the grouped form never touches the counters; fd_entry only wants a non-null pointer
+  const FdRope rp{nullptr, 0, (const uint16_t*)cos_t, (const uint16_t*)sin_t, cs_row_stride, positions, select_index,
+                  sel_width, (uint16_t*)k_cache, (uint16_t*)v_cache, qkv_partials, s_count, (int64_t)batch * row_w, row_w,
+                  (const uint16_t*)qkv_bias};
+  // q pointer / strides are unused in this mode; pass the pool (aligned, non-null) to satisfy the argument checks
+  return fd_entry(out, k_cache, k_cache, v_cache, table, b_req_idx, b_seq_len, nullptr, nullptr, batch, hq, hkv, d, max_len,
+                  qk_scale, 8, 8, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_b, o_stride_h, table_stride_b,
+                  dtype, req_width, seq_width, &dummy_counters, &rp, stream);
 }

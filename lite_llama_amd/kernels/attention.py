@@ -137,6 +137,57 @@ def decode_attention(q, kv, cos_table, sin_table, positions, select_index, kv_bu
     return out
 
 
+def decode_attention_partials_supported(max_actual_seq_len, num_heads: int, num_kv_heads: int, head_dim: int) -> bool:
+    """Whether :func:`decode_attention_partials` serves this step (known before the projection is launched)."""
+    nparts = L.lib().ll_flash_decoding_num_partitions(int(max_actual_seq_len))
+    return (2 <= nparts <= 8 and head_dim >= 64 and head_dim % 32 == 0 and num_heads % num_kv_heads == 0
+            and num_heads // num_kv_heads <= 16 and (num_heads // num_kv_heads + 2) * head_dim // 4 <= 128 * nparts)
+
+
+@torch.no_grad()
+def decode_attention_partials(parts, bias, num_heads: int, num_kv_heads: int, head_dim: int, cos_table, sin_table,
+                              positions, select_index, kv_buffer, qk_scale, b_req_tokens_table, b_req_idx, b_seq_len,
+                              max_actual_seq_len):
+    """:func:`decode_attention` whose ``q | k | v`` come as the fp32 split-K partials of the fused projection
+    (``PartialSums`` ``[S, B, (Hq + 2 Hkv) D]``, ``bias`` the projection bias or ``None``): every workgroup adds the
+    partials of its (row, KV head) -- plus bias, one rounding to the pool dtype: the value the projection itself would
+    have stored -- and continues as ``decode_attention``.  Returns ``None`` when the shape is not served (contexts of
+    129..1024 tokens, head_dim >= 64, <= 16 query heads per KV head): finish the sums and call ``decode_attention``."""
+    p = parts.parts
+    L.require_cuda(p, bias, cos_table, sin_table, positions, select_index, kv_buffer, b_req_tokens_table, b_req_idx, b_seq_len)
+    s_count, batchs, row_w = p.shape
+    dt = kv_buffer.dtype
+    positions = positions.reshape(-1)
+    if (row_w != (num_heads + 2 * num_kv_heads) * head_dim or head_dim < 64 or head_dim % 32 or num_heads % num_kv_heads
+            or num_heads // num_kv_heads > 16 or s_count > 8 or not p.is_contiguous() or parts.dtype != dt
+            or dt not in (torch.float16, torch.bfloat16) or cos_table.dtype != dt or sin_table.dtype != dt
+            or cos_table.dim() != 2 or cos_table.stride(1) != 1 or sin_table.stride(1) != 1
+            or cos_table.stride(0) != sin_table.stride(0) or cos_table.stride(0) % 8 != 0
+            or positions.dtype != torch.int64 or not positions.is_contiguous() or positions.shape[0] != batchs
+            or kv_buffer.stride(2) != 1 or b_req_tokens_table.dtype != torch.int32 or b_req_tokens_table.stride(1) != 1
+            or (bias is not None and (bias.dtype != dt or not bias.is_contiguous() or bias.numel() != row_w))):
+        return None
+    max_len = int(max_actual_seq_len)
+    nparts = L.lib().ll_flash_decoding_num_partitions(max_len)
+    if nparts < 2 or nparts > 8 or (num_heads // num_kv_heads + 2) * head_dim // 4 > 128 * nparts:
+        return None
+    k_cache, v_cache = kv_buffer[:, :num_kv_heads], kv_buffer[:, num_kv_heads:]
+    out = torch.empty((batchs, num_heads, head_dim), dtype=dt, device=p.device)
+    L.check(
+        L.lib().ll_decode_attention_partials(
+            out.data_ptr(), p.data_ptr(), s_count, L.ptr(bias), cos_table.data_ptr(), sin_table.data_ptr(),
+            cos_table.stride(0), positions.data_ptr(), select_index.data_ptr(), L.index_width(select_index),
+            k_cache.data_ptr(), v_cache.data_ptr(), b_req_tokens_table.data_ptr(), b_req_idx.data_ptr(),
+            b_seq_len.data_ptr(), batchs, num_heads, num_kv_heads, head_dim, max_len, float(qk_scale),
+            k_cache.stride(0), k_cache.stride(1), v_cache.stride(0), v_cache.stride(1), out.stride(0), out.stride(1),
+            b_req_tokens_table.stride(0), L.dtype_code(dt), L.index_width(b_req_idx), L.index_width(b_seq_len),
+            L.stream_ptr(),
+        ),
+        "decode_attention_partials",
+    )
+    return out
+
+
 @torch.no_grad()
 def flash_attention2_no_pad(q, k, v, sm_scale, b_start_loc, b_seq_len, max_seq_len):
     """Varlen causal prefill attention (``sm_scale`` must already include log2(e); the

@@ -168,6 +168,16 @@ class MergedColumnLinear:
             return out[..., 0::2], out[..., 1::2]
         return torch.split(out, [l.output_size for l in self.layers], dim=-1)
 
+    def partials(self, x: torch.Tensor):
+        """The merged projection left as fp32 split-K partials (:class:`PartialSums`, bias NOT added -- returned next
+        to it) for a consumer that adds them up (``decode_attention_partials``); ``None`` when not served."""
+        h = self._holder
+        if h is None or h.interleaved or not hasattr(h.quant_method, "apply_partials") or get_tp_world_size() != 1 \
+                or collective_forced():
+            return None
+        parts = h.quant_method.apply_partials(h, x, allow_bias=True)
+        return None if parts is None else (parts, h.bias)
+
     def swiglu(self, x: torch.Tensor) -> torch.Tensor:
         """``silu(gate(x)) * up(x)`` for a (gate, up) pair: one launch when interleaved and the shape is
         in the decode engine, else the merged GEMM followed by ``swiglu_forward``."""

@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .distributed.parallel_state import all_reduce_tp, divide, get_tp_rank, get_tp_world_size
-from .kernels.attention import decode_attention
+from .kernels.attention import decode_attention, decode_attention_partials, decode_attention_partials_supported
 from .kernels.norm_act import PartialSums, rope_and_cache, skip_rmsnorm_partials
 from .kernels import (
     flash_attention2_no_pad,
@@ -215,7 +215,28 @@ class Attention(nn.Module):
     def forward(self, x, atten_info, layer_index, position_embeddings, partials_ok=False):
         batch, seq_len, _ = x.shape
         x2 = x.view(-1, self.hidden_size)
-        if self._qkv.refresh():
+        if (seq_len == 1 and not self.use_qk_norm and not _TWO_CALL_ATTENTION and isinstance(position_embeddings, RopeTables)
+                and self._qkv.refresh() and not os.environ.get("LL_NO_QKV_PARTIALS")
+                and decode_attention_partials_supported(atten_info.max_actual_seq_len, self.num_heads, self.num_kv_heads,
+                                                        self.head_dim)):
+            # decode, int4, TP = 1: the fused q|k|v projection leaves fp32 split-K partials and the one-launch attention
+            # adds them up (+ bias) while its first K/V gathers are in flight -- the GEMM has no merge at all
+            pq = self._qkv.partials(x2)
+            if pq is not None:
+                tables = position_embeddings
+                out = decode_attention_partials(pq[0], pq[1], self.num_heads, self.num_kv_heads, self.head_dim, tables[0],
+                                                tables[1], tables[2], atten_info.cur_select_index,
+                                                atten_info.kv_buffer[layer_index], self.attn.scale,
+                                                atten_info.b_req_tokens_table, atten_info.b_req_idx, atten_info.b_seq_len,
+                                                atten_info.max_actual_seq_len)
+                if out is not None:
+                    return self.o_proj(out.view(batch, seq_len, self.q_size), partials_ok)
+                # not served (context outside 129..1024 tokens, ...): finish the sums and take the ordinary route
+                qkv = pq[0].materialise() if pq[1] is None else (pq[0].parts.sum(0) + pq[1].float()).to(pq[0].dtype)
+                xq, xkv = torch.split(qkv.view(-1, self.q_size + 2 * self.kv_size), [self.q_size, 2 * self.kv_size], dim=-1)
+            else:
+                xq, xkv = self._qkv(x2)
+        elif self._qkv.refresh():
             xq, xkv = self._qkv(x2)  # one launch; strided column views of [n, q + 2 kv]
         else:
             xq = self.q_proj(x2)

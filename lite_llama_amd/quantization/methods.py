@@ -80,10 +80,11 @@ class W4A16LinearMethod(LinearQuantMethod):
                             group_size=layer.quant.group_k, bias=layer.bias,
                             packed_scales=self._packed(layer))
 
-    def apply_partials(self, layer, x):
-        """Decode-shaped projection left as fp32 split-K partials for ``skip_rmsnorm_partials`` (extension);
-        ``None`` -> the caller runs :meth:`apply`."""
-        if layer.bias is not None or os.environ.get("LL_W4_NO_PARTIALS"):
+    def apply_partials(self, layer, x, allow_bias: bool = False):
+        """Decode-shaped projection left as fp32 split-K partials for ``skip_rmsnorm_partials`` /
+        ``decode_attention_partials`` (extension); ``None`` -> the caller runs :meth:`apply`.  The partials never
+        include the bias: a consumer that adds it itself passes ``allow_bias``."""
+        if (layer.bias is not None and not allow_bias) or os.environ.get("LL_W4_NO_PARTIALS"):
             return None
         pre = self._prepacked(layer, x)
         if pre is None:

@@ -194,3 +194,51 @@ def test_partial_sums_and_reducing_norm(M, N, K_):
     close(y, y_ref, 4e-3)
     exact = (r == r_ref).float().mean().item()
     assert exact > 0.98, exact
+
+
+@pytest.mark.parametrize("dtype_bias", [True, False])
+@pytest.mark.parametrize("ctx", [200, 300, 549, 1000])
+def test_decode_attention_over_qkv_partials(ctx, dtype_bias):
+    """The one-launch decode attention fed with the fp32 split-K partials of the fused q|k|v projection == the same
+    attention fed with the finished projection (Qwen2.5-7B head geometry): pool rows of the new token and outputs agree
+    up to the rounding of x (the sums are the same fp32 values up to the summation order)."""
+    import lite_llama_amd.kernels as K
+    from lite_llama_amd.kernels.attention import decode_attention, decode_attention_partials
+    HQ, HKV, D, B, HID = 28, 4, 128, 16, 3584
+    N = (HQ + 2 * HKV) * D
+    g = torch.Generator().manual_seed(ctx)
+    x = (torch.randn(B, HID, generator=g) * 0.5).half().to(DEV)
+    qw = torch.randint(-(2**31), 2**31 - 1, (N, HID // 8), dtype=torch.int64, generator=g).to(torch.int32).to(DEV)
+    sc = (torch.rand(N, HID // 128, generator=g) * 0.004 + 0.002).to(DEV)
+    zr = torch.randint(0, 16, (N, HID // 128), generator=g).float().to(DEV)
+    bias = (torch.randn(N, generator=g) * 0.1).half().to(DEV) if dtype_bias else None
+    pw, ps = Q().pack_w4a16_weights(qw), Q().pack_w4a16_scales(sc, zr)
+    parts = Q().w4a16_matmul_partials(x, pw, ps)
+    assert parts is not None
+    full = Q().w4a16_matmul_prepacked(x, pw, ps, bias=bias)
+    rows = B * (ctx + 1)
+    pool_a = (torch.randn(rows, 2 * HKV, D, generator=g) * 0.5).half().to(DEV)
+    pool_b = pool_a.clone()
+    table = torch.randperm(rows, generator=g).int().view(B, ctx + 1).to(DEV)
+    sel = table[:, ctx].contiguous()
+    seq = torch.full((B,), ctx + 1, dtype=torch.int32, device=DEV)
+    req = torch.arange(B, dtype=torch.int32, device=DEV)
+    pos = torch.full((B,), ctx, dtype=torch.int64, device=DEV)
+    cos = torch.randn(ctx + 8, D, generator=g).half().to(DEV)
+    sin = torch.randn(ctx + 8, D, generator=g).half().to(DEV)
+    scale = 1.0 / D**0.5
+    q = full[:, : HQ * D].view(B, HQ, D)
+    kv = full[:, HQ * D:].view(B, 2 * HKV, D)
+    want = decode_attention(q, kv, cos, sin, pos, sel, pool_a, scale, table, req, seq, ctx + 1)
+    got = decode_attention_partials(parts, bias, HQ, HKV, D, cos, sin, pos, sel, pool_b, scale, table, req, seq, ctx + 1)
+    if ctx == 200:  # two partitions = 128 lanes x 2 slots < the 288 slots of (7 + 2) x 128 values: declined, caller falls back
+        assert got is None
+        return
+    assert want is not None and got is not None
+    new_a, new_b = pool_a[sel.long()], pool_b[sel.long()]
+    close(new_b, new_a, 4e-3)
+    assert (new_a == new_b).float().mean().item() > 0.97
+    untouched = torch.ones(rows, dtype=torch.bool, device=DEV)
+    untouched[sel.long()] = False
+    assert torch.equal(pool_a[untouched], pool_b[untouched])
+    close(got, want, 4e-3)
