@@ -88,7 +88,10 @@ def gemm_roofline(model, batch, quant, iters=6):
     for mc in merged:
         if mc.layers[0].quant is not None and mc.refresh():
             fused_members.update(id(l) for l in mc.layers)
-            fn = (lambda x, mc=mc: mc.swiglu(x)) if mc.interleave else (lambda x, mc=mc: mc(x))
+            if mc.interleave:
+                fn = lambda x, mc=mc: mc.swiglu(x)
+            else:  # the decode step leaves the fused q|k|v projection as split-K partials for the attention kernel
+                fn = lambda x, mc=mc: (mc.partials(x) or mc(x))
             launches_list.append((fn, mc.layers[0].input_size, sum(l.input_size * l.output_size for l in mc.layers)))
     for m in model.modules():
         if isinstance(m, LinearBase) and m.quant is not None and id(m) not in fused_members:

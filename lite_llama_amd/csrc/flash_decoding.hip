@@ -672,10 +672,11 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
   const FdRope rp = rope ? *rope : FdRope{};
   const bool grouped_ok = fuse && nparts >= 2 && nparts <= FD_GROUP_MAX;
   // split-K partial inputs need the grouped form and two float4 slots per lane: (groups + 2) * d / 4 <= 2 * 64 * nparts
-  if (rope && rp.qp && (!grouped_ok || rp.qs < 1 || rp.qs > FD_QS_MAX || (groups + 2) * d / 4 > 128 * nparts || getenv("LL_FD_UNGROUPED")))
+  if (rope && rp.qp && (!grouped_ok || rp.qs < 1 || rp.qs > FD_QS_MAX || (groups + 2) * d / 4 > 128 * nparts || getenv("LL_FD_UNGROUPED") != nullptr))
     return LL_ERR_SHAPE;
   // one workgroup per (row, KV head group) with a wave per partition while the context fits FD_GROUP_MAX partitions
-  const bool grouped = grouped_ok && !getenv("LL_FD_UNGROUPED");
+  static const bool ungrouped_env = getenv("LL_FD_UNGROUPED") != nullptr;  // A/B knob, read once
+  const bool grouped = grouped_ok && !ungrouped_env;
 #define LL_FD1X(DD, FU, RO, GG, GR)                                                                  \
   {                                                                                                  \
     constexpr int tile_bytes_ = 32 * (DD + 8) * 2;                                                   \

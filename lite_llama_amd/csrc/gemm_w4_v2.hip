@@ -662,16 +662,29 @@ struct V2Plan {
   int gt, gbase, grem, glead;
 };
 
-static int v2_num_cus() {
-  static int cus = 0;
-  if (!cus) {
-    int dev = 0;
+static int v2_num_cus() {  // per device
+  static int cus[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return 256;
+  if (!cus[dev]) {
     hipDeviceProp_t prop;
-    if (hipGetDevice(&dev) == hipSuccess && hipGetDeviceProperties(&prop, dev) == hipSuccess)
-      cus = prop.multiProcessorCount;
-    if (cus <= 0) cus = 256;
+    cus[dev] = hipGetDeviceProperties(&prop, dev) == hipSuccess && prop.multiProcessorCount > 0 ? prop.multiProcessorCount : 256;
   }
-  return cus;
+  return cus[dev];
+}
+
+struct V2Knobs {  // the environment is read once per process
+  int wgs = 0, lead = 4, gt_cap = -1;
+  bool v1 = false;
+  V2Knobs() {
+    if (const char* e = getenv("LL_GEMM2_WGS")) wgs = atoi(e);
+    if (const char* e = getenv("LL_GEMM2_LEAD")) lead = atoi(e);
+    if (const char* e = getenv("LL_GEMM2_GT")) gt_cap = atoi(e);
+  }
+};
+static const V2Knobs& v2_knobs() {
+  static const V2Knobs k;
+  return k;
 }
 
 static V2Plan v2_plan(int64_t n, int64_t k) {
@@ -679,26 +692,21 @@ static V2Plan v2_plan(int64_t n, int64_t k) {
   pl.nblocks = (int)(n / V2_BN);
   pl.chunks = (int)(k / V2_CK);
   pl.total_units = pl.nblocks * pl.chunks;
-  int target = v2_num_cus();  // one persistent 12-wave workgroup per CU
-  if (const char* e = getenv("LL_GEMM2_WGS")) {
-    const int v = atoi(e);
-    if (v > 0) target = v;
-  }
+  const V2Knobs& kn = v2_knobs();
+  const int target = kn.wgs > 0 ? kn.wgs : v2_num_cus();  // one persistent 12-wave workgroup per CU
   pl.gt = pl.gbase = pl.grem = pl.glead = 0;
   // Few tiles (N <= 16 K at K = 3584): every tile is shared by gt workgroups and, with equal
   // shares, all of them finish together -- the owner then pays the whole merge chain (store ack,
   // flag, poll, slab loads: ~8 us) after its last unit.  Tile-group split: the owner gets `lead`
   // more chunks than the contributors, so their slabs and flags have landed by the time it is
   // done; the chain collapses to one round of slab loads.
-  int lead = 4;  // measured: 4 units (~3.5 us) cover the contributors' store ack + flag
-  if (const char* e = getenv("LL_GEMM2_LEAD")) lead = atoi(e);
+  const int lead = kn.lead;  // measured: 4 units (~3.5 us) cover the contributors' store ack + flag
   int gt = pl.nblocks > 0 ? target / pl.nblocks : 0;
   if (gt > V2_MAX_SLOTS) gt = V2_MAX_SLOTS;
   // the owner adds the slabs two per fabric round trip (more contributors, more rounds) and runs
   // lead units longer than everybody else: measured optimum ~ one workgroup per 5 chunks
   // (28 chunks -> 5, 148 chunks -> as many as there are CUs for)
-  int gt_cap = pl.chunks / 5;
-  if (const char* e = getenv("LL_GEMM2_GT")) gt_cap = atoi(e);
+  const int gt_cap = kn.gt_cap >= 0 ? kn.gt_cap : pl.chunks / 5;
   if (gt > gt_cap) gt = gt_cap;
   if (lead > 0 && gt >= 2 && pl.chunks - lead >= gt) {
     pl.gt = gt;
@@ -798,7 +806,10 @@ extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweig
   hipStream_t st = (hipStream_t)stream;
 #define V2_LAUNCH_PK(PK, ABL)                                                                                   \
   {                                                                                                             \
-    static bool attr_set = false;                                                                               \
+    static bool attr_set_[16] = {false};                                                                        \
+    int dev_ = 0;                                                                                               \
+    (void)hipGetDevice(&dev_);                                                                                  \
+    bool& attr_set = attr_set_[dev_ >= 0 && dev_ < 16 ? dev_ : 0];                                              \
     if (!attr_set) {                                                                                            \
       (void)hipFuncSetAttribute((const void*)wgemm2_kernel<1, PK, ABL>,                                         \
                                 hipFuncAttributeMaxDynamicSharedMemorySize, V2_LDS_BYTES);                      \
