@@ -6,6 +6,8 @@ import lite_llama_amd.kernels.quantization as Q
 
 dev = "cuda"
 shapes = [("qkv", 4608, 3584, 0), ("o", 3584, 3584, 0), ("gate|up", 37888, 3584, 1), ("down", 3584, 18944, 0)]
+if os.environ.get("SHAPES"):
+    shapes = [(f"s{i}", *map(int, t.split("x")), 0) for i, t in enumerate(os.environ["SHAPES"].split(","))]
 for name, n, k, epi in shapes:
     copies = 3
     ws = [(torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64, device=dev).to(torch.int32),

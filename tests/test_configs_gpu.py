@@ -138,7 +138,7 @@ def _tp_moe_worker(rank, world, port, q):
         assert blk.moe_intermediate_size == I5 // world
         with torch.no_grad():
             out = blk(_moe_input().to(DEV))
-        q.put((rank, True, out.cpu()))
+        q.put((rank, True, out.cpu().numpy()))  # by value: a shared-memory tensor handle dies with the worker
     except Exception as exc:  # pragma: no cover
         import traceback
 
@@ -162,6 +162,7 @@ def test_config5_moe_block_tp2_matches_tp1():
         p.join(timeout=60)
     for rank, ok, payload in results:
         assert ok is True, (rank, payload)
+    results = [(r, ok, torch.from_numpy(a)) for r, ok, a in results]
     assert torch.equal(results[0][2], results[1][2])  # both ranks hold the reduced sum
     blk, _ = _moe_block()
     with torch.no_grad():
@@ -297,7 +298,7 @@ def _rccl_worker(port, q):
             issued = calls["n"] - before
             # eager: 2 layers x 2 row-parallel projections x 6 steps; graph: warm-up + capture only
             assert issued == (24 if not use_graph else 8), (use_graph, issued)
-        q.put((True, torch.equal(outs[0], outs[1]), outs[0]))
+        q.put((True, torch.equal(outs[0], outs[1]), outs[0].numpy()))
     except Exception as exc:  # pragma: no cover
         import traceback
 

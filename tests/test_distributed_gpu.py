@@ -65,7 +65,7 @@ def _worker(rank, world, port, q):
         ps.init_tensor_parallel(rank, world, master_port=port)
         assert ps.get_tp_world_size() == world
         first, toks, logits = _run()
-        q.put((rank, True, first, (toks, logits)))
+        q.put((rank, True, first.numpy(), (toks.numpy(), logits.numpy())))  # by value: a shared-memory tensor handle dies with the worker
     except Exception as exc:  # pragma: no cover
         import traceback
 
@@ -87,8 +87,9 @@ def test_tp2_sharded_int4_decode_matches_tp1():
         p.join(timeout=60)
     for rank, ok, a, b in results:
         assert ok is True, (rank, a)
-    first0, (toks0, logits0) = results[0][2], results[0][3]
-    first1, (toks1, logits1) = results[1][2], results[1][3]
+    t = torch.from_numpy
+    first0, (toks0, logits0) = t(results[0][2]), tuple(map(t, results[0][3]))
+    first1, (toks1, logits1) = t(results[1][2]), tuple(map(t, results[1][3]))
     assert torch.equal(first0, first1) and torch.equal(toks0, toks1)  # every rank computes the same argmax
     assert torch.equal(logits0, logits1)
     ref_first, ref_toks, ref_logits = _run()                           # tp = 1 in this process
