@@ -107,7 +107,7 @@ class MergedColumnLinear:
 
     def _snapshot(self):
         return tuple((n, t.data_ptr(), t._version) for l in self.layers for n, t in l._parameters.items()
-                     if t is not None) + tuple(id(l.quant_method) for l in self.layers)
+                     if t is not None) + tuple((id(l.quant_method), id(getattr(l, "act_perm", None))) for l in self.layers)
 
     @torch.no_grad()
     def refresh(self) -> bool:
@@ -122,6 +122,10 @@ class MergedColumnLinear:
         self._holder = None
         ok = all(type(l.quant_method) is type(first.quant_method) and l.quant == first.quant
                  and l.input_size == first.input_size for l in self.layers)
+        # activation-ordered GPTQ members (weights.py): one launch needs ONE input order
+        perms = [getattr(l, "act_perm", None) for l in self.layers]
+        if any(p is not None for p in perms):
+            ok = ok and all(p is not None and torch.equal(p, perms[0]) for p in perms)
         il = (self.interleave and ok and len(self.layers) == 2 and hasattr(first.quant_method, "apply_gate_up_swiglu")
               and self.layers[0].output_size == self.layers[1].output_size)
         holder = _MergedHolder()
@@ -129,6 +133,7 @@ class MergedColumnLinear:
         holder.input_size = first.input_size
         holder.output_size = sum(l.output_size for l in self.layers)
         holder.quant, holder.quant_method = first.quant, first.quant_method
+        holder.act_perm = getattr(first, "act_perm", None)
         merged = {}
         for name in first._parameters:
             ts = [l._parameters.get(name) for l in self.layers]
@@ -195,3 +200,4 @@ class MergedColumnLinear:
 class _MergedHolder:
     """Attribute bag with the fields a quant method's ``apply`` reads from a layer."""
     bias = None
+    act_perm = None

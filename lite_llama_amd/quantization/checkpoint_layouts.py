@@ -6,7 +6,9 @@ the three tensors of one linear are converted on the device, bit-exactly, into w
 [N, K/g] -- methods/w4a16.py:18-27), after which the layer runs the ordinary int4 path.
 
 Formats (third-party, not part of the reference; restated from their published packers):
-AutoAWQ 0.2.x GEMM and AutoGPTQ 0.7.x without activation reordering -- see include/lite_llama_amd.h.
+AutoAWQ 0.2.x GEMM and AutoGPTQ 0.7.x -- see include/lite_llama_amd.h.  Activation-ordered GPTQ tensors
+(``desc_act``: ``g_idx[k]`` = group of input channel k, any order) are brought into group order at load time
+(:func:`gptq_sort_groups`); the layer then reads its activations through the same permutation.
 """
 
 from __future__ import annotations
@@ -47,17 +49,43 @@ def awq_to_w4a16(qweight, qzeros, scales, group_size: int = 128):
 
 
 @torch.no_grad()
+def gptq_sort_groups(qweight, g_idx, group_size: int = 128):
+    """AutoGPTQ ``qweight [K/8, N]`` whose input channels belong to groups ``g_idx [K]`` ->
+    ``(qweight', perm)`` with the channels in group order: ``perm = stable argsort(g_idx)``, row j of the unpacked
+    ``qweight'`` is row ``perm[j]`` of the original, so ``g_idx[perm[j]] == j // group_size`` and
+    ``sum_j x[perm[j]] W'[j] == sum_k x[k] W[k]``.  Returns ``(qweight, None)`` when the channels already are in
+    group order.  Load-time only (plain tensor ops on the tensor's device)."""
+    k = qweight.shape[0] * 8
+    g_idx = g_idx.view(-1).to(torch.int64)
+    if g_idx.numel() != k:
+        raise ValueError(f"gptq_sort_groups: g_idx has {g_idx.numel()} entries for {k} input channels")
+    want = torch.arange(k, device=g_idx.device) // group_size
+    if torch.equal(g_idx, want):
+        return qweight, None
+    perm = torch.argsort(g_idx, stable=True)
+    if not torch.equal(g_idx[perm], want):
+        raise ValueError("gptq_sort_groups: g_idx does not hold exactly group_size channels per group")
+    shifts = torch.arange(0, 32, 4, device=qweight.device, dtype=torch.int32).view(1, 8, 1)
+    nib = ((qweight.unsqueeze(1) >> shifts) & 0xF).reshape(k, -1)            # [K, N]: row 8i + j = nibble j of word row i
+    nib = nib.index_select(0, perm.to(qweight.device)).view(k // 8, 8, -1).to(torch.int64)
+    packed = (nib << shifts.to(torch.int64)).sum(dim=1)                       # disjoint nibbles: the sum is the OR
+    packed = torch.where(packed >= 2 ** 31, packed - 2 ** 32, packed).to(torch.int32)
+    return packed.contiguous(), perm.to(qweight.device)
+
+
+@torch.no_grad()
 def gptq_to_w4a16(qweight, qzeros, scales, g_idx=None, group_size: int = 128, checkpoint_format: str = "gptq"):
     """AutoGPTQ tensors (qweight [K/8, N], qzeros [K/g, N/8], scales fp16 [K/g, N]) -> the same triple.
-    ``checkpoint_format`` "gptq" (v1: stored zero = z - 1) or "gptq_v2" (stored zero = z).  Activation
-    reordering (a ``g_idx`` other than ``k // group_size``) is not supported and raises."""
+    ``checkpoint_format`` "gptq" (v1: stored zero = z - 1) or "gptq_v2" (stored zero = z).  The device kernel reads
+    channel k's group as ``k // group_size``: an activation-ordered ``g_idx`` raises here -- bring the tensor into
+    group order first (:func:`gptq_sort_groups`; ``load_int4_checkpoint_linear`` and the checkpoint loader do)."""
     k, n = qweight.shape[0] * 8, qweight.shape[1]
     if checkpoint_format not in ("gptq", "gptq_v2"):
         raise ValueError(f"gptq_to_w4a16: unknown checkpoint_format {checkpoint_format!r}")
     if g_idx is not None:
         want = torch.arange(k, device=g_idx.device) // group_size
         if g_idx.numel() != k or not torch.equal(g_idx.to(want.dtype).view(-1), want):
-            raise NotImplementedError("gptq_to_w4a16: activation-reordered checkpoints (desc_act) are not supported")
+            raise NotImplementedError("gptq_to_w4a16: activation-ordered tensor (desc_act): call gptq_sort_groups first")
     out = _check(qweight, qzeros, scales, k, n, group_size, "gptq_to_w4a16")
     qweight, qzeros, scales = qweight.contiguous(), qzeros.contiguous(), scales.contiguous()
     L.check(L.lib().ll_w4_from_gptq(out[0].data_ptr(), out[1].data_ptr(), out[2].data_ptr(), qweight.data_ptr(),
@@ -77,7 +105,11 @@ def load_int4_checkpoint_linear(layer, qweight, qzeros, scales, *, fmt: str, gro
     if fmt == "awq":
         w, s, z = awq_to_w4a16(qweight, qzeros, scales, group_size)
     elif fmt in ("gptq", "gptq_v2"):
-        w, s, z = gptq_to_w4a16(qweight, qzeros, scales, g_idx, group_size, fmt)
+        perm = None
+        if g_idx is not None:
+            qweight, perm = gptq_sort_groups(qweight, g_idx, group_size)
+        w, s, z = gptq_to_w4a16(qweight, qzeros, scales, None, group_size, fmt)
+        layer.act_perm = perm
     else:
         raise ValueError(f"unknown int4 checkpoint format {fmt!r} (awq, gptq, gptq_v2)")
     if tuple(w.shape) != (layer.output_size, layer.input_size // 8):

@@ -1,7 +1,7 @@
 """Quantised-weight layout descriptor -- host-side mirror of the reference's ``QuantConfig``
 (lite_llama/models/quantization/config.py:70-251): every scheme is a low-bit weight plus one
-scale per ``group_n x group_k`` block.  Only the parts the hot path needs are kept (no HF
-``config.json`` parsing -- checkpoints are out of scope)."""
+scale per ``group_n x group_k`` block.  ``quantization_config`` of a checkpoint's config.json is read by
+``lite_llama_amd/weights.py::quantization_from_hf_config`` (config.py:99-157)."""
 
 from __future__ import annotations
 

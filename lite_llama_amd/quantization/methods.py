@@ -63,6 +63,13 @@ class UnquantizedLinearMethod(LinearQuantMethod):
         return F.linear(x, layer.weight, layer.bias)
 
 
+def _ordered_input(layer, x):
+    """Activation-ordered GPTQ linears (``layer.act_perm``, set by the checkpoint loader) keep their weight columns in
+    group order; the activations are read through the same permutation (a gather of ``[tokens, K]``)."""
+    perm = getattr(layer, "act_perm", None)
+    return x if perm is None else x.index_select(-1, perm)
+
+
 class W4A16LinearMethod(LinearQuantMethod):
     """methods/w4a16.py:18-43."""
 
@@ -73,6 +80,7 @@ class W4A16LinearMethod(LinearQuantMethod):
         layer.weight_zeros = RawParameter(torch.empty(*q.scale_shape(output_size, input_size), dtype=torch.float32))
 
     def apply(self, layer, x):
+        x = _ordered_input(layer, x)
         pre = self._prepacked(layer, x)
         if pre is not None:
             return w4a16_matmul_prepacked(x, pre, self._packed(layer), group_size=layer.quant.group_k, bias=layer.bias)
@@ -86,6 +94,7 @@ class W4A16LinearMethod(LinearQuantMethod):
         include the bias: a consumer that adds it itself passes ``allow_bias``."""
         if (layer.bias is not None and not allow_bias) or os.environ.get("LL_W4_NO_PARTIALS"):
             return None
+        x = _ordered_input(layer, x)
         pre = self._prepacked(layer, x)
         if pre is None:
             return None
@@ -96,6 +105,7 @@ class W4A16LinearMethod(LinearQuantMethod):
         both projections and the activation; ``None`` -> the caller falls back to the two-step form."""
         if layer.bias is not None:
             return None
+        x = _ordered_input(layer, x)
         pre = self._prepacked(layer, x)
         if pre is not None:
             return w4a16_matmul_prepacked(x, pre, self._packed(layer), group_size=layer.quant.group_k,

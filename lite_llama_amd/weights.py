@@ -1,0 +1,500 @@
+"""Checkpoint ingestion for the hot path's model: HuggingFace key -> parameter placement,
+tensor-parallel sharding on the way in, streaming shard reader, coverage accounting -- the host-side mirror of
+lite_llama/models/weights.py:42-330 and lite_llama/executor/weight_utils.py:35-175 (same function names,
+argument meaning and error behaviour, so the reference's tests/models/test_weight_mapping.py reads 1:1 on this
+module) -- plus what the reference cannot do (weights.py:166-173,266-268 map such keys to unknown parameters):
+AutoAWQ / AutoGPTQ int4 linears (``qweight / qzeros / scales [/ g_idx]``) are cut for this rank in their
+CHECKPOINT layout, converted on the device into the native W4A16 parameters (csrc/w4_layouts.hip) and installed,
+activation-ordered GPTQ (``desc_act``) included.
+
+Placement model: a checkpoint tensor lands in a :class:`Region` of one parameter -- all of it, one of ``parts``
+equal row blocks (the fused K/V pair), one expert's slice of a stacked ``[E, ...]`` parameter, or a row block of
+that slice (gate / up inside an expert).
+"""
+
+from __future__ import annotations
+
+import re
+from collections.abc import Callable, Iterable, Iterator, Mapping
+from dataclasses import dataclass
+from pathlib import Path
+
+import torch
+import torch.nn as nn
+
+from .distributed.parallel_state import get_tp_rank, get_tp_world_size
+
+FP8_BLOCK = 128                     # block-fp8 checkpoints: one fp32 scale per 128 x 128 weights (weight_utils.py:58-71)
+SCALE_SUFFIX = "weight_scale_inv"
+INT4_LEAVES = ("qweight", "qzeros", "scales", "g_idx")
+
+
+# ------------------------------------------------------------------------------------- #
+# where a checkpoint tensor lands
+# ------------------------------------------------------------------------------------- #
+@dataclass(frozen=True)
+class Region:
+    """Callable ``parameter tensor -> the view one checkpoint tensor fills``."""
+
+    expert: int | None = None   # index into a stacked [E, ...] parameter
+    part: int | None = None     # row block `part` of `parts` equal blocks (of the expert's slice if `expert` is set)
+    parts: int = 2
+
+    def __call__(self, param: torch.Tensor) -> torch.Tensor:
+        view = param if self.expert is None else param[self.expert]
+        if self.part is not None:
+            rows = view.shape[0] // self.parts
+            view = view.narrow(0, self.part * rows, rows)
+        return view
+
+
+whole = Region()
+
+
+def half(index: int) -> Region:
+    """Half ``index`` of a parameter fused along dim 0 (k_proj / v_proj inside kv_proj)."""
+    return Region(part=index)
+
+
+def expert(index: int) -> Region:
+    return Region(expert=index)
+
+
+def expert_half(index: int, half_index: int) -> Region:
+    """gate (0) / up (1) rows inside expert ``index``'s slice of the stacked gate_up parameter."""
+    return Region(expert=index, part=half_index)
+
+
+Destination = Callable[[torch.Tensor], torch.Tensor]
+Target = tuple[str, Destination] | None
+Translator = Callable[[str], Target]
+Sharder = Callable[[str, torch.Tensor], torch.Tensor]
+
+# ------------------------------------------------------------------------------------- #
+# key translation (text decoder stack; the model's own prefix already stripped)
+# ------------------------------------------------------------------------------------- #
+_EXACT = {"norm.weight": "norm_weight", "lm_head.weight": "lm_head_weight"}
+# layers.N.mlp.experts.E.{gate,up,down}_proj.{weight,weight_scale_inv} -> the three stacked tensors
+_EXPERT = re.compile(r"^(.*\.mlp\.experts)\.(\d+)\.(gate|up|down)_proj\.(weight|weight_scale_inv)$")
+# HF modules that are bare parameters here: "<module>.<leaf>" -> "<module>_<leaf>"
+_BARE = re.compile(r"(?:^|\.)(self_attn\.[qk]_norm|input_layernorm|post_attention_layernorm|mlp\.gate)$")
+_KV = re.compile(r"^(.*?)self_attn\.([kv])_proj$")
+
+
+def translate_text_key(key: str) -> Target:
+    """``layers.3.self_attn.v_proj.weight`` -> ``("layers.3.self_attn.kv_proj.weight", half(1))`` and so on; keys that
+    already carry a parameter name map to themselves.  Works on any leaf (``bias``, ``qweight``, ...): only the
+    module path decides."""
+    if key in _EXACT:
+        return _EXACT[key], whole
+    m = _EXPERT.match(key)
+    if m is not None:
+        stack, index, proj, leaf = m.group(1), int(m.group(2)), m.group(3), m.group(4)
+        tail = "_scale_inv" if leaf == SCALE_SUFFIX else ""  # a ParameterDict entry has no second leaf
+        if proj == "down":
+            return f"{stack}.down_proj{tail}", expert(index)
+        return f"{stack}.gate_up_proj{tail}", expert_half(index, 0 if proj == "gate" else 1)
+    module, _, leaf = key.rpartition(".")
+    m = _KV.match(module)
+    if m is not None:
+        return f"{m.group(1)}self_attn.kv_proj.{leaf}", half("kv".index(m.group(2)))
+    if _BARE.search(module):
+        return f"{module}_{leaf}", whole
+    return key, whole
+
+
+def strip_prefix(key: str, prefix: str) -> str | None:
+    return key[len(prefix):] if key.startswith(prefix) else None
+
+
+# ------------------------------------------------------------------------------------- #
+# tensor parallelism: which dimension of the INCOMING tensor is cut
+# ------------------------------------------------------------------------------------- #
+_LEAF_TAILS = (".weight_scale_inv", "_scale_inv", ".weight", ".bias") + tuple("." + leaf for leaf in INT4_LEAVES)
+# module-path suffix -> 0: output rows (column-parallel), 1: contracted columns (row-parallel)
+_CUT = (("self_attn.q_proj", 0), ("self_attn.kv_proj", 0), ("self_attn.o_proj", 1),
+        ("mlp.experts.gate_up_proj", 0), ("mlp.experts.down_proj", 1),
+        ("mlp.gate_proj", 0), ("mlp.up_proj", 0), ("mlp.down_proj", 1))
+
+
+def _module_of(param_name: str) -> str:
+    for tail in _LEAF_TAILS:
+        if param_name.endswith(tail):
+            return param_name[: -len(tail)]
+    return param_name
+
+
+def shard_dim(param_name: str) -> int | None:
+    """Dimension of an incoming fp16 / fp8 weight (or its bias / scale grid) that tensor parallelism splits; ``None``
+    for replicated parameters and for everything under ``vision_tower.``."""
+    if param_name.startswith("vision_tower."):
+        return None
+    module = _module_of(param_name)
+    for suffix, dim in _CUT:
+        if module.endswith(suffix):
+            return dim
+    return None
+
+
+def _narrow_for_rank(name: str, tensor: torch.Tensor, dim: int) -> torch.Tensor:
+    world = get_tp_world_size()
+    size = tensor.shape[dim]
+    if size % world != 0:
+        raise ValueError(f"{name}: dimension {dim} of size {size} does not divide across {world} tensor-parallel ranks")
+    return tensor.narrow(dim, get_tp_rank() * (size // world), size // world)
+
+
+def tp_shard(param_name: str, tensor: torch.Tensor) -> torch.Tensor:
+    """This rank's slice of an incoming tensor (the tensor itself when nothing is cut): splitting on the way in keeps a
+    rank's peak memory at its own share of the checkpoint."""
+    if get_tp_world_size() == 1:
+        return tensor
+    dim = shard_dim(param_name)
+    if dim is None:
+        return tensor
+    if tensor.dim() <= dim:  # the bias of a row-parallel projection would be replicated (none exists in the path)
+        return tensor
+    return _narrow_for_rank(param_name, tensor, dim)
+
+
+def tp_shard_int4(param_name: str, tensor: torch.Tensor, group_size: int) -> torch.Tensor:
+    """The same cut on an AutoAWQ / AutoGPTQ tensor in its checkpoint layout.  All of ``qweight`` (AWQ ``[K, N/8]``,
+    GPTQ ``[K/8, N]``), ``qzeros [K/g, N/8]`` and ``scales [K/g, N]`` carry the contracted dimension first and the
+    output dimension last: a column-parallel layer keeps a block of the LAST dimension (whole 8-column words), a
+    row-parallel one a block of the FIRST (whole groups).  ``g_idx [K]`` follows the contracted dimension and is
+    rebased to the rank's first group."""
+    world = get_tp_world_size()
+    if world == 1:
+        return tensor
+    cut = shard_dim(param_name)
+    if cut is None:
+        return tensor
+    leaf = param_name.rpartition(".")[2]
+    if leaf == "g_idx":
+        if cut == 0:
+            return tensor
+        k = tensor.shape[0]
+        if (k // world) % group_size != 0:
+            raise ValueError(f"{param_name}: {k} input channels over {world} ranks do not end on a group boundary")
+        if not torch.equal(tensor.view(-1).to(torch.int64), torch.arange(k, device=tensor.device) // group_size):
+            raise NotImplementedError(
+                f"{param_name}: an activation-ordered (desc_act) row-parallel linear cannot be cut along its input "
+                "channels (a rank's channels belong to arbitrary groups)")
+        part = _narrow_for_rank(param_name, tensor, 0)
+        return part - get_tp_rank() * (k // world // group_size)
+    return _narrow_for_rank(param_name, tensor, tensor.dim() - 1 if cut == 0 else 0)
+
+
+# ------------------------------------------------------------------------------------- #
+# int4 third-party linears: collect the tensors of a module, convert, install
+# ------------------------------------------------------------------------------------- #
+@dataclass(frozen=True)
+class Int4Checkpoint:
+    """What ``quantization_config`` of the checkpoint's config.json says: ``fmt`` "awq" | "gptq" | "gptq_v2"."""
+
+    fmt: str
+    group_size: int = 128
+
+    @classmethod
+    def from_hf_config(cls, config: Mapping) -> "Int4Checkpoint | None":
+        q = config.get("quantization_config") or {}
+        method = str(q.get("quant_method", "")).lower()
+        if method not in ("awq", "gptq"):
+            return None
+        if int(q.get("bits", q.get("w_bit", 4))) != 4:
+            raise ValueError(f"{method} checkpoint with {q.get('bits', q.get('w_bit'))}-bit weights: only 4-bit is supported")
+        group = int(q.get("group_size", q.get("q_group_size", 128)))
+        if method == "awq":
+            if str(q.get("version", "gemm")).lower() != "gemm":
+                raise ValueError(f"AutoAWQ layout {q.get('version')!r}: only the GEMM layout is supported")
+            return cls("awq", group)
+        return cls("gptq_v2" if str(q.get("checkpoint_format", "gptq")).lower() == "gptq_v2" else "gptq", group)
+
+
+class _Int4Assembler:
+    """Holds the tensors of int4 linears until a (module, region) has its triple, then converts and installs it."""
+
+    def __init__(self, model: nn.Module, spec: Int4Checkpoint):
+        self.model, self.spec = model, spec
+        self.pending: dict[tuple[str, Region], dict[str, torch.Tensor]] = {}
+        self.switched: set[str] = set()
+        self.filled: dict[str, int] = {}
+        self.order: dict[str, torch.Tensor | None] = {}
+
+    def add(self, module_name: str, leaf: str, region: Region, tensor: torch.Tensor) -> None:
+        slot = self.pending.setdefault((module_name, region), {})
+        if leaf in slot:
+            raise ValueError(f"{module_name}.{leaf} arrived twice")
+        slot[leaf] = tensor
+        if all(k in slot for k in ("qweight", "qzeros", "scales")) and (self.spec.fmt == "awq" or "g_idx" in slot):
+            self._install(module_name, region, self.pending.pop((module_name, region)))
+
+    def finish(self) -> None:
+        for (module_name, region), slot in list(self.pending.items()):
+            if all(k in slot for k in ("qweight", "qzeros", "scales")):  # a GPTQ linear without g_idx: plain group order
+                self._install(module_name, region, self.pending.pop((module_name, region)))
+        if self.pending:
+            (module_name, _), slot = next(iter(self.pending.items()))
+            raise ValueError(f"int4 linear {module_name!r} is incomplete: only {sorted(slot)} arrived")
+
+    def _install(self, module_name: str, region: Region, slot: dict[str, torch.Tensor]) -> None:
+        from .quantization import QuantConfig, get_linear_method
+        from .quantization.checkpoint_layouts import awq_to_w4a16, gptq_sort_groups, gptq_to_w4a16
+        from .quantization.methods import RawParameter
+
+        layer = self.model.get_submodule(module_name)
+        g = self.spec.group_size
+        qweight, qzeros, scales = slot["qweight"], slot["qzeros"], slot["scales"]
+        perm = None
+        if self.spec.fmt == "awq":
+            w, s, z = awq_to_w4a16(qweight, qzeros, scales, g)
+        else:
+            g_idx = slot.get("g_idx")
+            if g_idx is not None:
+                qweight, perm = gptq_sort_groups(qweight, g_idx, g)
+            w, s, z = gptq_to_w4a16(qweight, qzeros, scales, None, g, self.spec.fmt)
+        if module_name not in self.switched:
+            n, k = layer.output_size, layer.input_size
+            dev = w.device
+            layer.weight = RawParameter(torch.empty(n, k // 8, dtype=torch.int32, device=dev))
+            layer.weight_scale = RawParameter(torch.empty(n, k // g, dtype=torch.float32, device=dev))
+            layer.weight_zeros = RawParameter(torch.empty(n, k // g, dtype=torch.float32, device=dev))
+            layer.quant = QuantConfig.int4_groupwise(g)
+            layer.quant_method = get_linear_method(layer.quant)
+            self.switched.add(module_name)
+            for leaf in ("weight", "weight_scale", "weight_zeros"):
+                self.filled[f"{module_name}.{leaf}"] = 0
+        for leaf, value in (("weight", w), ("weight_scale", s), ("weight_zeros", z)):
+            view = region(getattr(layer, leaf).data)
+            if view.shape != value.shape:
+                raise ValueError(f"int4 linear {module_name!r}: converted {leaf} has shape {tuple(value.shape)} but the "
+                                 f"layer expects {tuple(view.shape)}")
+            view.copy_(value)
+            self.filled[f"{module_name}.{leaf}"] += view.numel()
+        # every region of a fused parameter must use ONE input order (k_proj / v_proj read the same activations)
+        if module_name not in self.order:
+            self.order[module_name] = perm
+            layer.act_perm = perm
+        else:
+            seen = self.order[module_name]
+            if (perm is None) != (seen is None) or (perm is not None and not torch.equal(perm, seen)):
+                raise ValueError(f"{module_name}: the fused halves of this linear use different activation orders")
+
+
+# ------------------------------------------------------------------------------------- #
+# the copy loop
+# ------------------------------------------------------------------------------------- #
+def load_weights(model: nn.Module, weights: Iterable[tuple[str, torch.Tensor]], translate: Translator,
+                 tied: Mapping[str, str] | None = None, shard: Sharder | None = None,
+                 int4: Int4Checkpoint | None = None) -> None:
+    """Copy a checkpoint stream into ``model``'s allocated parameters and verify that every parameter was written
+    exactly once (never / partially / more than fits are three distinguishable errors, named by parameter).
+
+    ``translate`` returns ``None`` for keys to skip; ``tied`` = {target: source} filled by copy when the checkpoint
+    omits the target (``tie_word_embeddings``); ``shard`` narrows incoming tensors to this rank's slice.  ``int4``
+    (extension) turns ``qweight / qzeros / scales / g_idx`` keys into native W4A16 parameters; without it such keys
+    are unknown parameters, as in the reference."""
+    params = dict(model.named_parameters())
+    filled = dict.fromkeys(params, 0)
+    assembler = _Int4Assembler(model, int4) if int4 is not None else None
+
+    for key, tensor in weights:
+        target = translate(key)
+        if target is None:
+            continue
+        name, region = target
+        module_name, _, leaf = name.rpartition(".")
+        if assembler is not None and leaf in INT4_LEAVES:
+            if shard is not None:
+                tensor = tp_shard_int4(name, tensor, int4.group_size)
+            assembler.add(module_name, leaf, region, tensor)
+            continue
+        param = params.get(name)
+        if param is None:
+            raise ValueError(f"checkpoint key {key!r} maps to unknown parameter {name!r}")
+        if shard is not None:
+            tensor = shard(name, tensor)
+        view = region(param.data)
+        if view.shape != tensor.shape:
+            raise ValueError(f"checkpoint key {key!r} has shape {tuple(tensor.shape)} but {name!r} expects "
+                             f"{tuple(view.shape)}")
+        view.copy_(tensor)
+        filled[name] += view.numel()
+
+    if assembler is not None:
+        assembler.finish()
+        params = dict(model.named_parameters())  # the int4 linears replaced their fp16 weight
+        filled = {n: assembler.filled.get(n, filled.get(n, 0)) for n in params}
+
+    for target_name, source_name in (tied or {}).items():
+        if filled.get(target_name) == 0:
+            params[target_name].data.copy_(params[source_name].data)
+            filled[target_name] = params[target_name].numel()
+
+    _verify_coverage(params, filled)
+
+
+def _verify_coverage(params: Mapping[str, nn.Parameter], filled: Mapping[str, int]) -> None:
+    never = sorted(n for n, c in filled.items() if c == 0)
+    wrong = sorted(f"{n} ({c} of {params[n].numel()} elements)" for n, c in filled.items() if 0 < c != params[n].numel())
+    if not never and not wrong:
+        return
+    problems = []
+    if never:
+        problems.append(f"{len(never)} never written, e.g. {', '.join(never[:5])}")
+    if wrong:
+        problems.append(f"{len(wrong)} partially written, e.g. {', '.join(wrong[:5])}")
+    raise ValueError("checkpoint does not cover every parameter — " + "; ".join(problems))
+
+
+# ------------------------------------------------------------------------------------- #
+# reading checkpoint files
+# ------------------------------------------------------------------------------------- #
+def hf_weight_files(checkpoints_dir: str | Path) -> list[Path]:
+    """``*.safetensors`` of the directory in name order, else ``*.bin`` (repos that carry both keep the legacy files as
+    mirrors); ``FileNotFoundError`` when there is neither."""
+    root = Path(checkpoints_dir)
+    for pattern in ("*.safetensors", "*.bin"):
+        found = sorted(root.glob(pattern))
+        if found:
+            return found
+    raise FileNotFoundError(f"no *.safetensors or *.bin weight file in {root}; point --model-dir at a HuggingFace "
+                            "checkpoint directory (the one holding config.json)")
+
+
+def dequant_block_fp8(weight: torch.Tensor, scale_inv: torch.Tensor) -> torch.Tensor:
+    """``W[i, j] = w8[i, j] * s[i // 128, j // 128]`` in fp32 (e4m3 -> fp32 is exact), then fp16; the trailing blocks may
+    be partial."""
+    rows, cols = weight.shape
+    s = scale_inv.to(torch.float32)
+    ri = torch.arange(rows, device=weight.device) // FP8_BLOCK
+    ci = torch.arange(cols, device=weight.device) // FP8_BLOCK
+    return (weight.to(torch.float32) * s[ri][:, ci]).to(torch.float16)
+
+
+def _finish_tensor(key: str, tensor: torch.Tensor, scale, device, dequantize_fp8: bool) -> torch.Tensor:
+    if scale is None:
+        return tensor.to(device)
+    if dequantize_fp8:
+        return dequant_block_fp8(tensor.to(device), scale.to(device))
+    return tensor.view(torch.uint8).to(device)  # raw e4m3 bytes: the 8-bit kernels widen them themselves
+
+
+def hf_weights_iterator(checkpoints_dir: str | Path, device: str | torch.device = "cpu",
+                        dequantize_fp8: bool = True) -> Iterator[tuple[str, torch.Tensor]]:
+    """Stream ``(key, tensor)`` pairs, tensors already on ``device``, shard files in name order and keys in sorted
+    order inside a safetensors shard (one tensor resident at a time).  Block-fp8 weights are either widened to fp16
+    here (their ``*.weight_scale_inv`` consumed) or passed through as ``uint8`` next to their scale tables."""
+    tail = "." + SCALE_SUFFIX
+    for path in hf_weight_files(checkpoints_dir):
+        if path.suffix == ".safetensors":
+            from safetensors import safe_open
+
+            with safe_open(path, framework="pt", device="cpu") as shard:
+                keys = set(shard.keys())
+                for key in sorted(keys):
+                    if key.endswith(tail):
+                        if not dequantize_fp8:
+                            yield key, shard.get_tensor(key).to(device)
+                        continue
+                    scale_key = key.removesuffix(".weight") + tail
+                    scale = shard.get_tensor(scale_key) if scale_key in keys else None
+                    yield key, _finish_tensor(key, shard.get_tensor(key), scale, device, dequantize_fp8)
+        else:
+            state = torch.load(path, map_location="cpu", mmap=True, weights_only=True)
+            for key, tensor in state.items():
+                if key.endswith(tail):
+                    if not dequantize_fp8:
+                        yield key, tensor.to(device)
+                    continue
+                yield key, _finish_tensor(key, tensor, state.get(key.removesuffix(".weight") + tail), device, dequantize_fp8)
+
+
+def load_checkpoint(model: nn.Module, checkpoints_dir: str | Path, *, device: str | torch.device = "cuda",
+                    hf_prefix: str = "model.", int4: Int4Checkpoint | None = None, dequantize_fp8: bool | None = None,
+                    quantization=None) -> nn.Module:
+    """The loader's three steps for a :class:`lite_llama_amd.model.CausalLM` (executor/loader.py:104-147): stream the
+    checkpoint into the parameters (this rank's shards only), optionally quantise an fp16 checkpoint at load time,
+    leave the model on ``device`` in eval mode.  ``lm_head.weight`` sits outside ``hf_prefix``."""
+    if dequantize_fp8 is None:
+        dequantize_fp8 = getattr(model, "quant", None) is None
+    model.to(device)
+    tied = {"lm_head_weight": "embed_tokens.weight"} if getattr(model.geo, "tie_word_embeddings", False) else None
+
+    def translate(key: str) -> Target:
+        return translate_text_key(key.removeprefix(hf_prefix))
+
+    with torch.no_grad():
+        load_weights(model, hf_weights_iterator(checkpoints_dir, device, dequantize_fp8), translate, tied=tied,
+                     shard=tp_shard, int4=int4)
+        if quantization is not None and getattr(model, "quant", None) is None and int4 is None:
+            model.quantize_(quantization)
+    return model.eval()
+
+
+# ------------------------------------------------------------------------------------- #
+# config.json -> what to build (the subset of models/config.py + quantization/config.py:99-157 the loader needs)
+# ------------------------------------------------------------------------------------- #
+def geometry_from_hf_config(config: Mapping, name: str | None = None):
+    """``config.json`` (a dict) -> :class:`lite_llama_amd.model.ModelGeometry` for the llama / qwen2 / qwen3 /
+    qwen3_moe families of the hot path."""
+    from .model import ModelGeometry
+
+    kind = str(config.get("model_type", "")).lower()
+    if kind not in ("llama", "qwen2", "qwen3", "qwen3_moe"):
+        raise ValueError(f"unsupported model_type {kind!r}; supported: llama, qwen2, qwen3, qwen3_moe")
+    heads = int(config["num_attention_heads"])
+    hidden = int(config["hidden_size"])
+    rope = dict(config.get("rope_scaling") or config.get("rope_parameters") or {})
+    theta = float(config.get("rope_theta", rope.get("rope_theta", 10000.0)))
+    moe = kind == "qwen3_moe"
+    return ModelGeometry(
+        name=name or kind, hidden_size=hidden, num_layers=int(config["num_hidden_layers"]), num_heads=heads,
+        num_kv_heads=int(config.get("num_key_value_heads", heads)), head_dim=int(config.get("head_dim") or hidden // heads),
+        intermediate_size=int(config["intermediate_size"]), vocab_size=int(config["vocab_size"]),
+        rms_norm_eps=float(config.get("rms_norm_eps", 1e-6)), rope_theta=theta, qkv_bias=kind == "qwen2",
+        use_qk_norm=kind in ("qwen3", "qwen3_moe"), tie_word_embeddings=bool(config.get("tie_word_embeddings", False)),
+        rope_type=str(rope.get("rope_type", rope.get("type", "default"))), rope_scaling=rope,
+        num_experts=int(config.get("num_experts", 0)) if moe else 0,
+        num_experts_per_tok=int(config.get("num_experts_per_tok", 0)) if moe else 0,
+        moe_intermediate_size=int(config.get("moe_intermediate_size", 0)) if moe else 0,
+        norm_topk_prob=bool(config.get("norm_topk_prob", True)))
+
+
+def quantization_from_hf_config(config: Mapping):
+    """``quantization_config`` -> ``(QuantConfig to build the layers with | None, Int4Checkpoint | None)``:
+    block-fp8 checkpoints build 8-bit layers and load raw; AutoAWQ / AutoGPTQ checkpoints build fp16 layers that the
+    loader replaces linear by linear (the second element)."""
+    from .quantization import QuantConfig
+
+    q = config.get("quantization_config") or {}
+    method = str(q.get("quant_method", "")).lower()
+    if not method:
+        return None, None
+    if method == "fp8":
+        if str(q.get("fmt", "e4m3")).lower() != "e4m3":
+            raise ValueError(f"unsupported fp8 format {q.get('fmt')!r}; only e4m3 is implemented")
+        gn, gk = (int(v) for v in (q.get("weight_block_size") or (FP8_BLOCK, FP8_BLOCK)))
+        if gn % FP8_BLOCK or gk % FP8_BLOCK:
+            raise ValueError(f"weight_block_size {[gn, gk]} is not a multiple of {FP8_BLOCK}")
+        return QuantConfig.fp8_block(gn, gk), None
+    if method in ("awq", "gptq"):
+        return None, Int4Checkpoint.from_hf_config(config)
+    raise ValueError(f"unsupported quant_method {method!r}; supported: awq, fp8, gptq")
+
+
+def load_pretrained(checkpoints_dir: str | Path, *, device: str | torch.device = "cuda", quantization: str | None = None):
+    """Build the model a checkpoint directory describes and fill it (executor/loader.py:104-147): ``config.json`` ->
+    geometry + weight format, parameters allocated on ``device``, checkpoint streamed in (this rank's shards),
+    optional load-time quantisation (``quantization``: a ``--quantization`` scheme name) of an fp16 checkpoint."""
+    import json
+
+    from .model import CausalLM
+    from .quantization import QuantConfig
+
+    with open(Path(checkpoints_dir) / "config.json") as f:
+        config = json.load(f)
+    quant, int4 = quantization_from_hf_config(config)
+    model = CausalLM(geometry_from_hf_config(config), quant)
+    runtime = QuantConfig.for_runtime_scheme(quantization) if quantization and quant is None and int4 is None else None
+    return load_checkpoint(model, checkpoints_dir, device=device, int4=int4, quantization=runtime)

@@ -1,5 +1,5 @@
 """TEST INFRASTRUCTURE ONLY -- numpy restatement of the AutoAWQ (0.2.x, GEMM) and AutoGPTQ (0.7.x,
-no act-order) int4 checkpoint layouts: their packers (to build test checkpoints) and the conversion
+incl. the act-order meaning of ``g_idx``) int4 checkpoint layouts: their packers (to build test checkpoints) and the conversion
 into the reference's native W4A16 layout (lite_llama/kernels/quantization/w4a16.py:152-207,
 models/quantization/params/int4.py:33-49).
 
@@ -71,3 +71,11 @@ def dequant_kn(q_kn, zeros_gn, scales_gn_f16, group_size):
     z = np.repeat(zeros_gn.astype(np.float32), group_size, axis=0)
     s = np.repeat(scales_gn_f16.astype(np.float32), group_size, axis=0)
     return (q_kn.astype(np.float32) - z) * s
+
+
+def dequant_kn_act_order(q_kn, zeros_gn, scales_gn_f16, g_idx):
+    """AutoGPTQ with ``desc_act``: input channel k belongs to group ``g_idx[k]`` (any order, ``group_size`` channels
+    per group) -- W[k, n] = (q[k, n] - z[g_idx[k], n]) * s[g_idx[k], n] in fp32 -> [K, N]  (QuantLinear.forward of
+    auto_gptq/nn_modules/qlinear/qlinear_cuda_old.py: ``zeros[g_idx]``, ``scales[g_idx]``)."""
+    g = np.asarray(g_idx).astype(np.int64)
+    return (q_kn.astype(np.float32) - zeros_gn.astype(np.float32)[g]) * scales_gn_f16.astype(np.float32)[g]
