@@ -4,7 +4,7 @@ sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 import lite_llama_amd.kernels as K
 
 dev = "cuda"
-B, HQ, HKV, D = int(os.environ.get("B", 64)), 28, 4, 128
+B, HQ, HKV, D = int(os.environ.get("B", 64)), int(os.environ.get("HQ", 28)), int(os.environ.get("HKV", 4)), 128
 for ctx in [int(c) for c in os.environ.get("CTX", "64,128,256,384,512,640,1024,2048").split(",")]:
     rows = B * ctx
     pools = [torch.randn(rows, 2 * HKV, D, device=dev, dtype=torch.float16) * 0.5 for _ in range(8)]

@@ -98,3 +98,21 @@ __device__ __forceinline__ float ll_sigmoidf(float v) { return 1.0f / (1.0f + ex
 static inline bool ll_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define LL_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? LL_OK : LL_ERR_LAUNCH)
+
+// Reductions over the four 16-lane rows of a wave (lanes t, t + 16, t + 32, t + 48) with the gfx950 row-swap VALU
+// instructions instead of two ds_bpermute round trips through the LDS pipe: v_permlane16_swap exchanges the odd rows of
+// its first operand with the even rows of its second, v_permlane32_swap the upper half of the first with the lower half
+// of the second -- fed the same value twice, the two results hold a lane's own value and its partner's.
+__device__ __forceinline__ float rows_max(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+}
+__device__ __forceinline__ float rows_sum(float x) {
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  x = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(x), __float_as_uint(x), false, false);
+  return __uint_as_float(b[0]) + __uint_as_float(b[1]);
+}
+

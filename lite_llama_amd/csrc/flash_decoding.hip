@@ -314,8 +314,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
       sc[4 + r] = vb_ok ? sb[r] * scale2 : -INFINITY;                                          \
       mx = fmaxf(mx, fmaxf(sc[r], sc[4 + r]));                                                 \
     }                                                                                          \
-    mx = fmaxf(mx, __shfl_xor(mx, 16, 64));                                                    \
-    mx = fmaxf(mx, __shfl_xor(mx, 32, 64));                                                    \
+    mx = rows_max(mx);                                                                         \
     const float m_new = fmaxf(m_i, mx); /* finite: token pos0 is always valid */               \
     const float alpha = __builtin_amdgcn_exp2f(m_i - m_new);                                   \
     float p[8];                                                                                \
@@ -324,8 +323,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
       p[j] = __builtin_amdgcn_exp2f(sc[j] - m_new);                                            \
       ps += p[j];                                                                              \
     }                                                                                          \
-    ps += __shfl_xor(ps, 16, 64);                                                              \
-    ps += __shfl_xor(ps, 32, 64);                                                              \
+    ps = rows_sum(ps);                                                                         \
     d_i = d_i * alpha + ps;                                                                    \
     m_i = m_new;                                                                               \
     /* P^T fragment (MFMA B operand): k-slot j <-> token 16*(j>>2) + 4c + (j&3) */             \
@@ -369,6 +367,21 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     }                                                                                          \
   }
 
+#if defined(FD_ABLATE) && (FD_ABLATE & 1)  // debug: loads only -- the registers are consumed, nothing is computed
+#undef FD_COMPUTE
+#define FD_COMPUTE(S, TI)                                                                                        \
+  _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                               \
+    asm volatile("" ::"v"(__builtin_bit_cast(i32x4, ka##S[s])), "v"(__builtin_bit_cast(i32x4, kb##S[s])),          \
+                 "v"(__builtin_bit_cast(i32x4, va##S[s])), "v"(__builtin_bit_cast(i32x4, vb##S[s])));             \
+  }
+#endif
+#if defined(FD_ABLATE) && (FD_ABLATE & 2)  // debug: arithmetic only -- no K / V gathers
+#undef FD_LOAD
+#define FD_LOAD(S, TI)                                                                                           \
+  _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                                               \
+    ka##S[s] = kb##S[s] = va##S[s] = vb##S[s] = Q4{(uint32_t)(TI) * 0x3c003c00u + (uint32_t)r0, (uint32_t)r1 & 0x3fff3fffu, 0x3c003c00u, (uint32_t)s}; \
+  }
+#endif
   // two register sets: tile i+1 is in flight while tile i is multiplied
   Q4 kaA[NS], kbA[NS], vaA[NS], vbA[NS], kaB[NS], kbB[NS], vaB[NS], vbB[NS];
   FD_LOAD(A, 0)

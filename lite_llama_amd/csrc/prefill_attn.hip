@@ -8,6 +8,8 @@
 // softmax is lane-local per query, and the S^T accumulators are directly the P^T B-operand of
 // O^T = V^T.P^T.  K fragments come straight from global memory (L2-shared between the waves
 // of a head), V is staged per 32-key tile through LDS to be read key-major.
+#include <stdlib.h>
+
 #include "common.h"
 
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
@@ -162,11 +164,207 @@ __global__ __launch_bounds__(64) void fa_prefill(
   }
 }
 
+// Second form (D = 64 / 128): a four-wave workgroup owns 64 * QB consecutive queries of one (sequence, head) and walks
+// the keys in tiles of 64.  A tile's K and V rows are fetched ONCE per workgroup (global -> registers -> LDS, the next
+// tile's loads in flight under the current tile's MFMAs) and shared by the four waves: 64 * QB queries per byte of K/V
+// instead of 16 -- the one-wave form re-reads K/V per 16 queries and saturates the CU's memory pipeline (4.8 TB/s of
+// L2 traffic at batch 64 x 512).  Each wave keeps 16 * QB query columns: K fragments are read from LDS once per tile
+// and used for QB query blocks, V^T fragments come from transposing LDS reads (ds_read_b64_tr_b16), the online softmax
+// runs once per 64 keys (one rescale of O per tile, skipped when no running maximum moved).
+template <int DT, int D, int QB>
+__global__ __launch_bounds__(256) __attribute__((amdgpu_waves_per_eu(2))) void fa_prefill2(
+    uint16_t* __restrict__ out, const uint16_t* __restrict__ q, const uint16_t* __restrict__ k,
+    const uint16_t* __restrict__ v, const void* __restrict__ b_start_loc, const void* __restrict__ b_seq_len,
+    int hq, int hkv, float sm_scale, int64_t q_st, int64_t q_sh, int64_t k_st, int64_t k_sh, int64_t v_st,
+    int64_t v_sh, int64_t o_st, int64_t o_sh, int start_w, int seq_w) {
+  constexpr int NS = D / 32, NT = D / 16, STR = D + 8, TK = 64;
+  constexpr int TPR = D / 8, RPP = 256 / TPR, PASSES = TK / RPP;  // 16-byte pieces per row, rows per pass
+  __shared__ __attribute__((aligned(16))) uint16_t lds_k[TK * STR];
+  __shared__ __attribute__((aligned(16))) uint16_t lds_v[TK * STR];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int t = lane & 15, c = lane >> 4;
+  const int head = blockIdx.y, b = blockIdx.z;
+  const int kvh = head / (hq / hkv);
+  const int64_t seq_len = pa_load_idx(b_seq_len, b, seq_w);
+  const int64_t start = pa_load_idx(b_start_loc, b, start_w);
+  const int64_t q0 = (int64_t)(gridDim.x - 1 - blockIdx.x) * (64 * QB);  // the longest key ranges are dispatched first
+  if (q0 >= seq_len) return;
+  const int64_t qw = q0 + wave * (16 * QB);  // this wave's first query
+
+  Q4 qf[QB][NS];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int64_t qi = qw + qb * 16 + t;
+    const int64_t qrow = qi < seq_len ? qi : seq_len - 1;  // rows past the end: a valid row, never stored
+#pragma unroll
+    for (int s = 0; s < NS; ++s)
+      qf[qb][s] = *reinterpret_cast<const Q4*>(q + (start + qrow) * q_st + (int64_t)head * q_sh + s * 32 + c * 8);
+  }
+  float m_i[QB], d_i[QB];
+  f32x4 ot[QB][NT];
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    m_i[qb] = -INFINITY;
+    d_i[qb] = 0.f;
+#pragma unroll
+    for (int i = 0; i < NT; ++i) ot[qb][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+
+  const int64_t kend = q0 + 64 * QB < seq_len ? q0 + 64 * QB : seq_len;  // causal: the workgroup needs keys < kend
+  const int lrow = tid / TPR, lcol = (tid % TPR) * 8;
+  i32x4 kr[PASSES], vr[PASSES];  // (vector type, not the Q4 struct: the struct copy into LDS kept the array in scratch)
+  auto fetch = [&](int64_t p0) {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      int64_t key = p0 + ps * RPP + lrow;
+      if (key >= seq_len) key = seq_len - 1;
+      kr[ps] = *reinterpret_cast<const i32x4*>(k + (start + key) * k_st + (int64_t)kvh * k_sh + lcol);
+      vr[ps] = *reinterpret_cast<const i32x4*>(v + (start + key) * v_st + (int64_t)kvh * v_sh + lcol);
+    }
+  };
+  auto stage = [&](int64_t p0) {
+#pragma unroll
+    for (int ps = 0; ps < PASSES; ++ps) {
+      const int row = ps * RPP + lrow;
+      *reinterpret_cast<i32x4*>(&lds_k[row * STR + lcol]) = kr[ps];
+      // rows past the sequence end are multiplied by p = 0: they must not hold NaN / Inf bit patterns
+      *reinterpret_cast<i32x4*>(&lds_v[row * STR + lcol]) = p0 + row < seq_len ? vr[ps] : i32x4{0, 0, 0, 0};
+    }
+  };
+  const uint16_t* vtr = lds_v + (4 * c + (t >> 2)) * STR + (t & 3) * 4;
+
+  fetch(0);
+  for (int64_t p0 = 0; p0 < kend; p0 += TK) {
+    __syncthreads();  // the previous tile's fragment reads are done
+    stage(p0);
+    __syncthreads();
+    fetch(p0 + TK < kend ? p0 + TK : p0);  // in flight under this tile's arithmetic (unconditional: a branch around
+                                           // loads parks the prefetch registers in scratch)
+    if (p0 >= qw + 16 * QB) continue;    // every key of the tile lies after this wave's last query
+    // S^T blocks for all QB query blocks from ONE read of each K fragment: rows = keys p0 + 16 kb + 4c + r, column =
+    // query qw + 16 qb + t.  (A query block that lies entirely before the tile gets all-masked scores: p = 0, alpha = 1.)
+    f32x4 sacc[QB][4];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb)
+#pragma unroll
+      for (int kb = 0; kb < 4; ++kb) sacc[qb][kb] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+    for (int kb = 0; kb < 4; ++kb) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) {
+        const Q4 kf = *reinterpret_cast<const Q4*>(&lds_k[(kb * 16 + t) * STR + s * 32 + c * 8]);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) sacc[qb][kb] = mfma16<DT>(kf, qf[qb][s], sacc[qb][kb]);
+      }
+    }
+    Q4 pf[QB][2];
+#pragma unroll
+    for (int qb = 0; qb < QB; ++qb) {
+      const int64_t qfirst = qw + qb * 16;
+      // scores stay raw until the exponent: p = exp2(s * scale - m) is one fma + one v_exp per key (scale > 0, so the
+      // maximum is taken over the raw scores); masked keys hold the raw value whose scaled form is the reference's -1e8
+      float sc[16];
+      float mx = -INFINITY;
+      if (p0 + TK - 1 <= qfirst) {  // whole tile at or before the block's first query: no mask (wave-uniform)
+#pragma unroll
+        for (int j = 0; j < 16; ++j) sc[j] = sacc[qb][j >> 2][j & 3];
+      } else {
+        const int64_t qi = qfirst + t;
+        const float masked = -1.0e8f / sm_scale;
+#pragma unroll
+        for (int j = 0; j < 16; ++j) {
+          const int64_t key = p0 + 16 * (j >> 2) + 4 * c + (j & 3);
+          sc[j] = key <= qi ? sacc[qb][j >> 2][j & 3] : masked;  // reference: where(causal, qk * scale, -1e8)
+        }
+      }
+#pragma unroll
+      for (int j = 0; j < 16; j += 2) mx = fmaxf(mx, fmaxf(sc[j], sc[j + 1]));
+      mx *= sm_scale;
+      mx = rows_max(mx);
+      const float m_new = fmaxf(m_i[qb], mx);
+      const float alpha = __builtin_amdgcn_exp2f(m_i[qb] - m_new);
+      float psum = 0.f;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        sc[j] = __builtin_amdgcn_exp2f(__builtin_fmaf(sc[j], sm_scale, -m_new));
+        psum += sc[j];
+      }
+      psum = rows_sum(psum);
+      d_i[qb] = d_i[qb] * alpha + psum;
+      m_i[qb] = m_new;
+      if (__builtin_amdgcn_ballot_w64(alpha != 1.0f) != 0) {  // some query's maximum moved: rescale O
+#pragma unroll
+        for (int dt = 0; dt < NT; ++dt) {
+          ot[qb][dt][0] *= alpha; ot[qb][dt][1] *= alpha; ot[qb][dt][2] *= alpha; ot[qb][dt][3] *= alpha;
+        }
+      }
+#pragma unroll
+      for (int hf = 0; hf < 2; ++hf) {  // 32 keys per PV step: P^T k-slot j <-> key 32 hf + 16 (j >> 2) + 4c + (j & 3)
+        pf[qb][hf].x = pack2<DT>(sc[8 * hf + 0], sc[8 * hf + 1]);
+        pf[qb][hf].y = pack2<DT>(sc[8 * hf + 2], sc[8 * hf + 3]);
+        pf[qb][hf].z = pack2<DT>(sc[8 * hf + 4], sc[8 * hf + 5]);
+        pf[qb][hf].w = pack2<DT>(sc[8 * hf + 6], sc[8 * hf + 7]);
+      }
+    }
+    // O^T += V^T P^T: each V^T fragment (transposing LDS read) feeds all QB query blocks
+#pragma unroll
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) {
+        const s16x4 tlo = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(vtr + (32 * hf) * STR + dt * 16));
+        const s16x4 thi = __builtin_amdgcn_ds_read_tr16_b64_v4i16(
+            (__attribute__((address_space(3))) s16x4*)(vtr + (32 * hf + 16) * STR + dt * 16));
+        Q4 vf;
+        vf.x = (uint32_t)(uint16_t)tlo.x | ((uint32_t)(uint16_t)tlo.y << 16);
+        vf.y = (uint32_t)(uint16_t)tlo.z | ((uint32_t)(uint16_t)tlo.w << 16);
+        vf.z = (uint32_t)(uint16_t)thi.x | ((uint32_t)(uint16_t)thi.y << 16);
+        vf.w = (uint32_t)(uint16_t)thi.z | ((uint32_t)(uint16_t)thi.w << 16);
+#pragma unroll
+        for (int qb = 0; qb < QB; ++qb) ot[qb][dt] = mfma16<DT>(vf, pf[qb][hf], ot[qb][dt]);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int qb = 0; qb < QB; ++qb) {
+    const int64_t qi = qw + qb * 16 + t;
+    if (qi < seq_len) {
+      const float inv = 1.0f / d_i[qb];
+      uint16_t* o = out + (start + qi) * o_st + (int64_t)head * o_sh;
+#pragma unroll
+      for (int dt = 0; dt < NT; ++dt) {
+        uint2 pk;
+        pk.x = pack2<DT>(ot[qb][dt][0] * inv, ot[qb][dt][1] * inv);
+        pk.y = pack2<DT>(ot[qb][dt][2] * inv, ot[qb][dt][3] * inv);
+        *reinterpret_cast<uint2*>(o + dt * 16 + 4 * c) = pk;
+      }
+    }
+  }
+}
+
 template <int DT>
 static int launch_fa(void* out, const void* q, const void* k, const void* v, const void* start, const void* seq,
                      int batch, int hq, int hkv, int d, int64_t max_seq_len, float sm_scale, int64_t q_st,
                      int64_t q_sh, int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh, int64_t o_st,
                      int64_t o_sh, int start_w, int seq_w, hipStream_t st) {
+  if (d == 64 || d == 128) {
+    static const int qb_env = getenv("LL_FA_QB") ? atoi(getenv("LL_FA_QB")) : 0;  // debug knob, read once
+    const int qb = qb_env == 1 || qb_env == 2 ? qb_env : (max_seq_len > 64 ? 2 : 1);
+    dim3 grid2((unsigned)((max_seq_len + 64 * qb - 1) / (64 * qb)), (unsigned)hq, (unsigned)batch);
+#define LL_FA2(DD, QQ)                                                                                          \
+  fa_prefill2<DT, DD, QQ><<<grid2, 256, 0, st>>>((uint16_t*)out, (const uint16_t*)q, (const uint16_t*)k,        \
+                                                 (const uint16_t*)v, start, seq, hq, hkv, sm_scale, q_st, q_sh, \
+                                                 k_st, k_sh, v_st, v_sh, o_st, o_sh, start_w, seq_w)
+    if (d == 64) {
+      if (qb == 2) LL_FA2(64, 2); else LL_FA2(64, 1);
+    } else {
+      if (qb == 2) LL_FA2(128, 2); else LL_FA2(128, 1);
+    }
+#undef LL_FA2
+    return LL_LAUNCH_CHECK();
+  }
   dim3 grid((unsigned)((max_seq_len + 15) / 16), (unsigned)hq, (unsigned)batch);
 #define LL_FA(DD)                                                                                        \
   fa_prefill<DT, DD><<<grid, 64, 0, st>>>((uint16_t*)out, (const uint16_t*)q, (const uint16_t*)k,        \

@@ -559,6 +559,29 @@ def test_fa2_nopad_oracle(lens, hq, hkv, d):
     close(out.cpu()[0], v[0].repeat_interleave(hq // hkv, dim=0), 2e-2)
 
 
+@pytest.mark.parametrize("d,dtype", [(128, torch.float16), (64, torch.float16), (128, torch.bfloat16)])
+def test_fa2_nopad_tile_boundaries(d, dtype):
+    """The four-wave form (64-key tiles shared through LDS, 64 or 128 queries per workgroup): sequence lengths on both
+    sides of every tile / query-block boundary, GQA 7, against a plain fp32 causal softmax per (sequence, head)."""
+    lens, hq, hkv = [1, 63, 64, 65, 127, 128, 129, 257, 500], 14, 2
+    lp, bsz = max(lens), len(lens)
+    g = torch.Generator(device=DEV).manual_seed(31)
+    q = (torch.randn(bsz * lp, hq, d, device=DEV, generator=g) * 0.5).to(dtype)
+    k = (torch.randn(bsz * lp, hkv, d, device=DEV, generator=g) * 0.5).to(dtype)
+    v = torch.randn(bsz * lp, hkv, d, device=DEV, generator=g).to(dtype)
+    start = torch.arange(bsz, dtype=torch.int32, device=DEV) * lp
+    seq = torch.tensor(lens, dtype=torch.int32, device=DEV)
+    out = K().flash_attention2_no_pad(q, k, v, 1.4426950408889634 / math.sqrt(d), start, seq, lp)
+    tol = 2e-2 if dtype == torch.float16 else 4e-2
+    for i, n in enumerate(lens):
+        qs, ks, vs = (t[i * lp : i * lp + n].float() for t in (q, k, v))
+        ks, vs = ks.repeat_interleave(hq // hkv, dim=1), vs.repeat_interleave(hq // hkv, dim=1)
+        sc = torch.einsum("qhd,khd->hqk", qs, ks) / math.sqrt(d)
+        sc = sc.masked_fill(~torch.ones(n, n, dtype=torch.bool, device=DEV).tril(), float("-inf"))
+        ref = torch.einsum("hqk,khd->qhd", sc.softmax(-1), vs)
+        close(out[i * lp : i * lp + n].float(), ref, tol)
+
+
 def test_fa2_nopad_no_cross_sequence_leak():
     """Changing sequence 1's K/V must not change sequence 0's output."""
     lens, hq, hkv, d = [20, 30], 4, 2, 64
