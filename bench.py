@@ -50,6 +50,7 @@ def parse():
     ap.add_argument("--quant", default="int4", choices=["int4", "int8", "smoothquant", "fp8", "none"])
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--scattered", action="store_true", help="context rows in random pool order (gather cost)")
+    ap.add_argument("--kv-block-size", type=int, default=0, help="block-granular KV paging on the device (0: the reference's bump allocator)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=1, help="decoder layers in the CPU oracle sample")
     return ap.parse_args()
@@ -310,7 +311,8 @@ def main():
     t_build = time.perf_counter() - t_build
 
     total = args.warmup + args.steps
-    engine = DecodeEngine(model, max_batch=args.batch, max_seq_len=args.ctx + total + 8, device=dev)
+    engine = DecodeEngine(model, max_batch=args.batch, max_seq_len=args.ctx + total + 8, device=dev,
+                              kv_block_size=args.kv_block_size or None)
     first = engine.synthetic_context(args.batch, args.ctx, seed=1 + ps.get_dp_rank(), scattered=args.scattered)
 
     marks = {}
@@ -348,7 +350,8 @@ def main():
         use_graph = False
         graph_note = "eager (graph capture failed)"
         marks.clear()
-        engine = DecodeEngine(model, max_batch=args.batch, max_seq_len=args.ctx + total + 8, device=dev)
+        engine = DecodeEngine(model, max_batch=args.batch, max_seq_len=args.ctx + total + 8, device=dev,
+                              kv_block_size=args.kv_block_size or None)
         first = engine.synthetic_context(args.batch, args.ctx, seed=1 + ps.get_dp_rank(), scattered=args.scattered)
         out = engine.decode(first, total, use_graph=False, on_step=on_step)
     barrier()
@@ -377,7 +380,8 @@ def main():
                   "none": "f16 (fp32 accumulate)"}[args.quant],
         "data": "synthetic", "graph": bool(use_graph), "graph_error": graph_error,
         "config": {"workload": f"{args.model} {args.quant} decode, batch {args.batch}/replica, ctx {args.ctx}->"
-                               f"{args.ctx + total}, {graph_note}" + (", scattered KV rows" if args.scattered else ""),
+                               f"{args.ctx + total}, {graph_note}" + (", scattered KV rows" if args.scattered else "")
+                               + (f", KV paged in blocks of {args.kv_block_size}" if args.kv_block_size else ""),
                    "global_batch": global_batch,
                    "parallelism": f"dp{dp}xtp{tp}", "build_seconds": round(t_build, 1)},
         "step_roofline": {"algorithmic_bytes_per_step_per_gpu": int(step_bytes),

@@ -291,6 +291,31 @@ int ll_kv_alloc(int32_t* state, int64_t n_rows, int64_t need, int contiguous_fir
 int ll_kv_ref_update(int32_t* state, int64_t n_rows, const void* index, int64_t count, int idx_width,
                      int delta, int64_t* free_rows, void* stream);
 
+/* ---- block-granular KV paging on the device (extension) -----------------------
+ * The reference's pool is token-granular (executor/kv_cache_manager.py:197-216) with the TODO "reshape into
+ * [blocks, block_size, ...] to support PagedAttention" (:211); its kernels read the per-token table
+ * b_req_tokens_table[req][pos] (executor/model_runner.py:153-218).  These entries hand the SAME pool out in blocks of
+ * block_size consecutive rows and derive the per-token table (row = block * block_size + pos % block_size) on the
+ * device, so every kernel above runs unchanged.  State, all int32 on the device: free_stack [num_blocks - 1];
+ * state[2] = {free blocks, error flags (1 = out of blocks, 2 = a request outgrew its block-table row)};
+ * block_table [max_reqs][bt_stride]; req_blocks [max_reqs].  Block num_blocks - 1 is the junk block (rows for padded
+ * prefill positions and refused requests); a fresh pool hands out blocks 0, 1, 2, ... in request order.  No host
+ * read-back anywhere: all three entries are stream-ordered and may sit inside a captured decode step.  n <= 1024
+ * requests per call, each listed once. */
+int ll_kv_paged_reset(int32_t* free_stack, int32_t* state, int32_t* req_blocks, int64_t num_blocks, int64_t max_reqs,
+                      void* stream);
+/* Make request req_idx[i] hold ceil((lens[i] + len_bias) / block_size) blocks (all-or-nothing per call) and write the
+ * rows of the grid [n][grid_len]: from_end 0 = positions 0 .. grid_len - 1 (padded prefill grid; positions >= the
+ * length get junk rows in select_out and leave the token table alone), from_end 1 = the last grid_len positions
+ * (decode append with grid_len 1: position len - 1).  token_table[req][p] = row; select_out [n * grid_len]. */
+int ll_kv_paged_extend(int32_t* free_stack, int32_t* state, int32_t* block_table, int64_t bt_stride, int32_t* req_blocks,
+                       const int32_t* req_idx, const int32_t* lens, int len_bias, int64_t n, int block_size,
+                       int64_t grid_len, int from_end, int32_t* token_table, int64_t tt_stride, int32_t* select_out,
+                       int64_t num_blocks, void* stream);
+/* Return every block of the listed requests to the stack (request order, block order). */
+int ll_kv_paged_release(int32_t* free_stack, int32_t* state, const int32_t* block_table, int64_t bt_stride,
+                        int32_t* req_blocks, const int32_t* req_idx, int64_t n, void* stream);
+
 /* ---- load-time ingestion of third-party int4 checkpoint layouts -------------
  * The reference reaches W4A16 only by re-quantising fp16 weights: AutoAWQ / AutoGPTQ tensors map
  * to unknown parameters (models/weights.py:166-173,266-268).  These two entries convert such

@@ -61,6 +61,9 @@ SIGNATURES = {
     "ll_kv_alloc_scratch_bytes": [L],
     "ll_kv_alloc": [P, L, L, I, P, P, P, P, P],
     "ll_kv_ref_update": [P, L, P, L, I, I, P, P],
+    "ll_kv_paged_reset": [P, P, P, L, L, P],
+    "ll_kv_paged_extend": [P, P, P, L, P, P, P, I, L, I, L, I, P, L, P, L, P],
+    "ll_kv_paged_release": [P, P, P, L, P, P, L, P],
     "ll_w4_from_awq": [P, P, P, P, P, P, L, L, L, P],
     "ll_w4_from_gptq": [P, P, P, P, P, P, L, L, L, I, P],
     "ll_repetition_penalty": [P, P, P, P, P, F, L, L, L, L, L, L, L, I, I, P],

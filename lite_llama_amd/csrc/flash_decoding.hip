@@ -123,6 +123,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
   int qe[2] = {0, 0};
   int64_t qcol[2] = {0, 0};
   bool qok[2] = {false, false};
+  uint2 qbv[2] = {uint2{0, 0}, uint2{0, 0}};  // the 4 bias values of a slot, fetched with the partials (one 8-byte load)
   if constexpr (QPART_OK) {
     if (qpart) {
       const int nq = groups * D;                // this KV head's query values, then its new K row, then its new V row
@@ -141,6 +142,10 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
           const int ss = sl < rp.qs ? sl : 0;   // clamped; dropped below
           qacc[sl][it] = *reinterpret_cast<const f32x4*>(rp.qp + ss * rp.qp_plane + b * rp.qp_row + qcol[it]);
         }
+        // unconditional (a pointer select, not a branch: a load inside a branch is waited for with vmcnt(0), and the
+        // per-element form of this cost eight dependent round trips in the launch's ramp)
+        const uint16_t* bsrc = rp.qbias ? rp.qbias + qcol[it] : reinterpret_cast<const uint16_t*>(rp.qp);
+        qbv[it] = *reinterpret_cast<const uint2*>(bsrc);
       }
     }
   }
@@ -157,9 +162,9 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
           uint16_t o4[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
-            float f = a[e];
-            if (rp.qbias) f += to_f32<DT>(rp.qbias[qcol[it] + e]);
-            o4[e] = from_f32<DT>(f);
+            const uint32_t w = e < 2 ? qbv[it].x : qbv[it].y;
+            const float bias = to_f32<DT>((uint16_t)(e & 1 ? w >> 16 : w));
+            o4[e] = from_f32<DT>(rp.qbias ? a[e] + bias : a[e]);
           }
           if (qok[it])
             *reinterpret_cast<uint2*>(q_lds + qe[it]) =

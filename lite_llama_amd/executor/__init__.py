@@ -88,14 +88,26 @@ class DecodeEngine:
     updated, so at ``flash_decoding`` time ``b_seq_len`` already counts the token being fed.
     """
 
-    def __init__(self, model, max_batch: int, max_seq_len: int, device="cuda", kv_dtype=torch.float16):
+    def __init__(self, model, max_batch: int, max_seq_len: int, device="cuda", kv_dtype=torch.float16,
+                 kv_block_size: int | None = None):
+        """``kv_block_size`` (extension): hand the KV pool out in blocks of that many rows from a device-side
+        free stack (:class:`PagedKVPool`) instead of the reference's bump allocator; the kernels read the same per-token
+        table either way, so the generated tokens are identical."""
         geo = model.geo
         self.model = model
         self.device = device
         self.max_batch = max_batch
         self.max_seq_len = max_seq_len
         at0 = model.layers[0].self_attn
-        self.pool = KVPool(geo.num_layers, max_batch * max_seq_len, at0.num_kv_heads, geo.head_dim, device, kv_dtype)
+        self.paged = kv_block_size is not None
+        if self.paged:
+            from .paged_kv import PagedKVPool
+
+            per_req = (max_seq_len + kv_block_size - 1) // kv_block_size
+            self.pool = PagedKVPool(geo.num_layers, max_batch * per_req + 1, kv_block_size, at0.num_kv_heads, geo.head_dim,
+                                    device, max_batch, max_seq_len, kv_dtype)
+        else:
+            self.pool = KVPool(geo.num_layers, max_batch * max_seq_len, at0.num_kv_heads, geo.head_dim, device, kv_dtype)
         self.info = AttentionMetadata(kv_buffer=self.pool.kv_buffer)
         self.info.b_req_tokens_table = torch.zeros(max_batch, max_seq_len, dtype=torch.int32, device=device)
         self._graph = None
@@ -117,16 +129,20 @@ class DecodeEngine:
             prompt_lens = torch.full((b,), lp, dtype=torch.int32, device=dev)
         info = self.info
         info.b_req_idx = torch.arange(b, dtype=torch.int32, device=dev)
-        info.cur_select_index = self.pool.alloc(b * lp)
         info.b_seq_len = prompt_lens.to(torch.int32).clone()
         info.max_actual_seq_len = lp
         info.b_start_loc = torch.arange(b, dtype=torch.int32, device=dev) * lp
-        # table[i, j] = row of token j of sequence i on the padded grid, valid tokens only
-        # (_init_req_tokens_table, model_runner.py:153-179); a sequence's pad rows hold junk K/V
-        # that attention never reads, and its own decode steps name fresh rows
-        valid = torch.arange(lp, device=dev).unsqueeze(0) < info.b_seq_len.view(b, 1)
-        info.b_req_tokens_table[:b, :lp] = torch.where(valid, info.cur_select_index.view(b, lp),
-                                                       info.b_req_tokens_table[:b, :lp])
+        if self.paged:
+            # blocks for the valid tokens only; the grid's pad positions write their junk K/V into the junk block
+            info.cur_select_index = self.pool.admit(info.b_req_idx, info.b_seq_len, lp, info.b_req_tokens_table)
+        else:
+            info.cur_select_index = self.pool.alloc(b * lp)
+            # table[i, j] = row of token j of sequence i on the padded grid, valid tokens only
+            # (_init_req_tokens_table, model_runner.py:153-179); a sequence's pad rows hold junk K/V
+            # that attention never reads, and its own decode steps name fresh rows
+            valid = torch.arange(lp, device=dev).unsqueeze(0) < info.b_seq_len.view(b, 1)
+            info.b_req_tokens_table[:b, :lp] = torch.where(valid, info.cur_select_index.view(b, lp),
+                                                           info.b_req_tokens_table[:b, :lp])
         position_ids = torch.arange(lp, device=dev).unsqueeze(0).expand(b, lp)
         rows = torch.arange(b, device=dev) * lp + (prompt_lens.long() - 1)
         last = self.model(prompt_ids, position_ids, info, logits_rows=rows)
@@ -150,13 +166,19 @@ class DecodeEngine:
         g = torch.Generator(device=dev)
         g.manual_seed(seed)
         info.b_req_idx = torch.arange(batch, dtype=torch.int32, device=dev)
-        rows = self.pool.alloc(batch * ctx_len)
-        if scattered:
-            rows = rows[torch.randperm(batch * ctx_len, generator=g, device=dev)]
-        info.b_req_tokens_table[:batch, :ctx_len] = rows.view(batch, ctx_len)
-        for kv in self.pool.kv_buffer:
-            kv[: batch * ctx_len].copy_(
-                (torch.randn(batch * ctx_len, kv.shape[1], kv.shape[2], generator=g, device=dev) * 0.5).to(kv.dtype))
+        if self.paged:
+            lens = torch.full((batch,), ctx_len, dtype=torch.int32, device=dev)
+            rows = self.pool.admit(info.b_req_idx, lens, ctx_len, info.b_req_tokens_table).long()  # fills the table
+            for kv in self.pool.kv_buffer:
+                kv[rows] = (torch.randn(batch * ctx_len, kv.shape[1], kv.shape[2], generator=g, device=dev) * 0.5).to(kv.dtype)
+        else:
+            rows = self.pool.alloc(batch * ctx_len)
+            if scattered:
+                rows = rows[torch.randperm(batch * ctx_len, generator=g, device=dev)]
+            info.b_req_tokens_table[:batch, :ctx_len] = rows.view(batch, ctx_len)
+            for kv in self.pool.kv_buffer:
+                kv[: batch * ctx_len].copy_(
+                    (torch.randn(batch * ctx_len, kv.shape[1], kv.shape[2], generator=g, device=dev) * 0.5).to(kv.dtype))
         info.b_seq_len = torch.full((batch,), ctx_len, dtype=torch.int32, device=dev)
         info.max_actual_seq_len = ctx_len
         self._positions = torch.full((batch, 1), ctx_len, dtype=torch.long, device=dev)
@@ -167,14 +189,19 @@ class DecodeEngine:
     def _begin_decode(self, first_tokens: torch.Tensor, max_new_tokens: int):
         b, dev, info = self._batch, self.device, self.info
         # decode_alloc_kv_cache for the first decode step
-        info.cur_select_index = self.pool.alloc(b)
         info.b_seq_len = info.b_seq_len + 1
         info.max_actual_seq_len += 1
-        update_kv_index(info.b_req_tokens_table, info.b_req_idx, info.b_seq_len, info.cur_select_index)
-        # reserve the rows of all remaining steps now: the bump allocator hands out the next B
-        # rows each step, which the graph reproduces on device as ``cur_select_index += B``
-        if max_new_tokens > 1:
-            self.pool.alloc(b * (max_new_tokens - 1))
+        if self.paged:
+            # the row of position seq_len - 1 (a block is popped on the device when the position opens one); every
+            # later step repeats this launch inside the step (graph included) -- nothing is reserved ahead
+            info.cur_select_index = self.pool.append(info.b_req_idx, info.b_seq_len, info.b_req_tokens_table)
+        else:
+            info.cur_select_index = self.pool.alloc(b)
+            update_kv_index(info.b_req_tokens_table, info.b_req_idx, info.b_seq_len, info.cur_select_index)
+            # reserve the rows of all remaining steps now: the bump allocator hands out the next B
+            # rows each step, which the graph reproduces on device as ``cur_select_index += B``
+            if max_new_tokens > 1:
+                self.pool.alloc(b * (max_new_tokens - 1))
         self._input_ids = first_tokens.view(b, 1).clone()
         # column 0 holds the token sampled by the prefill step: it is part of the generated span the repetition
         # penalty looks at from the second token on (llm_engine.py:168-176: GeneratedSpan over tokens[:, :cur_pos])
@@ -211,6 +238,14 @@ class DecodeEngine:
         has the engine's own dtypes, else the reference-shaped sequence of tensor ops."""
         info, b = self.info, self._batch
         t = info.b_req_tokens_table
+        if self.paged:
+            self._out.view(-1).scatter_(0, self._row_base + self._step, nxt)
+            self._step += 1
+            self._input_ids.copy_(nxt.view(b, 1))
+            self._positions += 1
+            info.b_seq_len += 1
+            self.pool.append(info.b_req_idx, info.b_seq_len, t, out=info.cur_select_index)
+            return
         if (nxt.dtype == torch.int64 and info.cur_select_index.dtype == torch.int32 and info.b_seq_len.dtype == torch.int32
                 and info.b_req_idx.dtype == torch.int32 and t.dtype == torch.int32 and nxt.is_contiguous()
                 and info.cur_select_index.is_contiguous() and info.b_seq_len.is_contiguous()
@@ -279,7 +314,7 @@ class DecodeEngine:
         info = self.info
         return (self._input_ids.clone(), self._positions.clone(), info.cur_select_index.clone(),
                 info.b_seq_len.clone(), self._step.clone(), self._out.clone(),
-                info.b_req_tokens_table.clone())
+                info.b_req_tokens_table.clone(), self.pool.snapshot() if self.paged else None)
 
     def _restore(self, snap):
         info = self.info
@@ -290,6 +325,8 @@ class DecodeEngine:
         self._step.copy_(snap[4])
         self._out.copy_(snap[5])
         info.b_req_tokens_table.copy_(snap[6])
+        if self.paged:
+            self.pool.restore(snap[7])
 
 
 from .slots import DEFAULT_BATCH_SIZES, DEFAULT_SEQ_LEN_BUCKETS, SlotBatch, SlotRunner, StepGraphs, slot_advance  # noqa: E402,F401
