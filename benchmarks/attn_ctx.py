@@ -12,7 +12,11 @@ for ctx in [int(c) for c in os.environ.get("CTX", "64,128,256,384,512,640,1024,2
     table = torch.randperm(rows, device=dev).int().view(B, ctx)
     req = torch.arange(B, dtype=torch.int32, device=dev)
     seq = torch.full((B,), ctx, dtype=torch.int32, device=dev)
-    f = lambda p: K.flash_decoding(q, p[:, :HKV], p[:, HKV:], 1.0 / D**0.5, table, req, seq, ctx)
+    if os.environ.get("FP8"):  # e4m3 pool (extension): half the K/V bytes
+        pools = [p.to(torch.float8_e4m3fn) for p in pools]
+        f = lambda p: K.flash_decoding_fp8kv(q, p[:, :HKV], p[:, HKV:], 1.0 / D**0.5, table, req, seq, ctx)
+    else:
+        f = lambda p: K.flash_decoding(q, p[:, :HKV], p[:, HKV:], 1.0 / D**0.5, table, req, seq, ctx)
     f(pools[0]); torch.cuda.synchronize()
     g = torch.cuda.CUDAGraph()
     with torch.cuda.graph(g):
@@ -25,5 +29,5 @@ for ctx in [int(c) for c in os.environ.get("CTX", "64,128,256,384,512,640,1024,2
         g.replay()
     e1.record(); torch.cuda.synchronize()
     us = e0.elapsed_time(e1) * 1e3 / (5 * len(pools))
-    byt = rows * 2 * HKV * D * 2
+    byt = rows * 2 * HKV * D * (1 if os.environ.get("FP8") else 2)
     print(f"ctx {ctx:5d}: {us:7.2f} us  {byt / us / 1e6:5.2f} TB/s  ({byt / 1e6:.1f} MB, {B * HKV * ((ctx + 127) // 128)} waves)", flush=True)

@@ -291,6 +291,24 @@ int ll_kv_alloc(int32_t* state, int64_t n_rows, int64_t need, int contiguous_fir
 int ll_kv_ref_update(int32_t* state, int64_t n_rows, const void* index, int64_t count, int idx_width,
                      int delta, int64_t* free_rows, void* stream);
 
+/* ---- fp8 KV cache (extension -- the reference's pool is fp16, executor/kv_cache_manager.py:197-216) ----
+ * The pool holds OCP e4m3 bytes; stored value * k_scale (v_scale) = K (V) value, static per pool.
+ * ll_update_kv_buffer_fp8: a3's scatter with quantisation -- heads [0, k_heads) are K heads (divided by k_scale), the
+ * rest V heads; clamp to +-448, round to nearest even; vals fp16 / bf16 [tokens, heads, hd], buf uint8 (strides in
+ * bytes), hd % 8 == 0.  ll_flash_decoding_fp8kv: a5 over such a pool -- k_cache / v_cache byte views (strides in bytes),
+ * fp16 q / out, d in {64, 128}, counters required (one-launch forms); the fragments are widened to fp16 in registers
+ * (exact), k_scale rides on qk_scale and v_scale on the normalisation: the result is ll_flash_decoding's on the
+ * widened pool. */
+int ll_update_kv_buffer_fp8(const void* vals, const void* select_index, void* buf, int64_t tokens, int heads, int k_heads,
+                            int hd, int64_t v_stride_t, int64_t v_stride_h, int64_t b_stride_t, int64_t b_stride_h,
+                            float k_scale, float v_scale, int dtype, int idx_width, void* stream);
+int ll_flash_decoding_fp8kv(void* out, const void* q, const void* k_cache, const void* v_cache, const int32_t* table,
+                            const void* b_req_idx, const void* b_seq_len, float* mid_o, float* mid_lse, int batch, int hq,
+                            int hkv, int d, int64_t max_len, float qk_scale, float k_scale, float v_scale,
+                            int64_t q_stride_b, int64_t q_stride_h, int64_t k_stride_t, int64_t k_stride_h,
+                            int64_t v_stride_t, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
+                            int64_t table_stride_b, int req_width, int seq_width, int32_t* counters, void* stream);
+
 /* ---- block-granular KV paging on the device (extension) -----------------------
  * The reference's pool is token-granular (executor/kv_cache_manager.py:197-216) with the TODO "reshape into
  * [blocks, block_size, ...] to support PagedAttention" (:211); its kernels read the per-token table

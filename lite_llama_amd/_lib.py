@@ -61,6 +61,8 @@ SIGNATURES = {
     "ll_kv_alloc_scratch_bytes": [L],
     "ll_kv_alloc": [P, L, L, I, P, P, P, P, P],
     "ll_kv_ref_update": [P, L, P, L, I, I, P, P],
+    "ll_update_kv_buffer_fp8": [P, P, P, L, I, I, I, L, L, L, L, F, F, I, I, P],
+    "ll_flash_decoding_fp8kv": [P, P, P, P, P, P, P, P, P, I, I, I, I, L, F, F, F, L, L, L, L, L, L, L, L, L, I, I, P, P],
     "ll_kv_paged_reset": [P, P, P, L, L, P],
     "ll_kv_paged_extend": [P, P, P, L, P, P, P, I, L, I, L, I, P, L, P, L, P],
     "ll_kv_paged_release": [P, P, P, L, P, P, L, P],

@@ -75,6 +75,7 @@ struct FdRope {
   int qs;                     // number of partials (<= FD_QS_MAX)
   int64_t qp_plane, qp_row;   // elements per partial, per batch row
   const uint16_t* qbias;      // [row_w] or nullptr
+  float k_scale, v_scale;     // fp8 KV cache (KV8): stored value * scale = K / V value
 };
 #define FD_QS_MAX 8
 
@@ -88,7 +89,33 @@ struct FdRope {
 // partition; the partials meet in LDS and wave 0 merges them -- no partial stores, no counter, no coherent
 // re-load: the merge tail shrinks from two global round trips (~5 us at batch 64 x ctx 512) to a barrier.
 #define FD_GROUP_MAX 8
-template <int DT, int D, bool FUSE, bool ROPE, int GS, bool GROUPED>
+// KV8 (extension): the pool holds OCP e4m3 bytes (ll_update_kv_buffer_fp8); fragments are gathered as 8-byte pieces and
+// widened to fp16 in registers (v_cvt_scalef32_pk_f16_fp8, exact), k_scale rides on the softmax scale and v_scale on
+// the final normalisation -- half the K/V bytes, the same MFMA arithmetic.  fp16 queries only, no in-kernel rope.
+struct alignas(8) Q2 {
+  uint32_t x, y;
+};
+template <bool KV8>
+struct FdKv {
+  using Reg = Q4;
+  using Elem = uint16_t;
+  static __device__ __forceinline__ Q4 frag(const Q4& r) { return r; }
+};
+template <>
+struct FdKv<true> {
+  using Reg = Q2;
+  using Elem = uint8_t;
+  static __device__ __forceinline__ Q4 frag(const Q2& r) {
+    Q4 o;
+    o.x = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)r.x, 1.0f, false));
+    o.y = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)r.x, 1.0f, true));
+    o.z = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)r.y, 1.0f, false));
+    o.w = __builtin_bit_cast(uint32_t, __builtin_amdgcn_cvt_scalef32_pk_f16_fp8((int)r.y, 1.0f, true));
+    return o;
+  }
+};
+
+template <int DT, int D, bool FUSE, bool ROPE, int GS, bool GROUPED, bool KV8 = false>
 __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     const int32_t* __restrict__ table, const void* __restrict__ b_req_idx,
@@ -99,6 +126,11 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
   constexpr int NS = D / 32;      // MFMA k-steps over the head dim
   constexpr int NT = D / 16;      // output d-tiles
   constexpr int VSTR = D + 8;     // padded LDS row stride (elements)
+  static_assert(!KV8 || (DT == LL_F16 && !ROPE), "fp8 KV: fp16 queries, rope and the KV write happen before the launch");
+  using KVR = typename FdKv<KV8>::Reg;
+  using KVE = typename FdKv<KV8>::Elem;
+  const KVE* kcE = reinterpret_cast<const KVE*>(kc);
+  const KVE* vcE = reinterpret_cast<const KVE*>(vc);
   static_assert(!GROUPED || (FUSE && 32 * VSTR * 2 >= (16 * D + 16) * 4), "a wave's V tile doubles as its partial record");
   extern __shared__ __attribute__((aligned(16))) uint16_t lds_all[];
   const int lane = threadIdx.x & 63;
@@ -263,7 +295,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
 
   // scores are kept in the log2 domain (one v_exp_f32 per probability; plain expf costs ~15 VALU each): the
   // running maximum m_i is in log2 units and is converted back where the log-sum-exp record is written
-  const float scale2 = scale * 1.44269504088896340736f;
+  const float scale2 = scale * 1.44269504088896340736f * (KV8 ? rp.k_scale : 1.0f);
   const uint16_t* vtr = lds_v + (4 * c + (t >> 2)) * VSTR + (t & 3) * 4;
   float m_i = -INFINITY, d_i = 0.f;
   f32x4 ot[NT];
@@ -284,14 +316,14 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     const int rsrc_ = (TI) < 2 ? r0 : r1;                                                      \
     const int64_t rowA_ = __shfl(rsrc_, ((TI) & 1) * 32 + t, 64);                              \
     const int64_t rowB_ = __shfl(rsrc_, ((TI) & 1) * 32 + 16 + t, 64);                         \
-    const uint16_t* kA_ = kc + rowA_ * k_st + (int64_t)kvh * k_sh + c * 8;                    \
-    const uint16_t* kB_ = kc + rowB_ * k_st + (int64_t)kvh * k_sh + c * 8;                    \
-    const uint16_t* vA_ = vc + rowA_ * v_st + (int64_t)kvh * v_sh + c * 8;                    \
-    const uint16_t* vB_ = vc + rowB_ * v_st + (int64_t)kvh * v_sh + c * 8;                    \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) ka##S[s] = *reinterpret_cast<const Q4*>(kA_ + s * 32); \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) kb##S[s] = *reinterpret_cast<const Q4*>(kB_ + s * 32); \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) va##S[s] = *reinterpret_cast<const Q4*>(vA_ + s * 32); \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) vb##S[s] = *reinterpret_cast<const Q4*>(vB_ + s * 32); \
+    const KVE* kA_ = kcE + rowA_ * k_st + (int64_t)kvh * k_sh + c * 8;                        \
+    const KVE* kB_ = kcE + rowB_ * k_st + (int64_t)kvh * k_sh + c * 8;                        \
+    const KVE* vA_ = vcE + rowA_ * v_st + (int64_t)kvh * v_sh + c * 8;                        \
+    const KVE* vB_ = vcE + rowB_ * v_st + (int64_t)kvh * v_sh + c * 8;                        \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) ka##S[s] = *reinterpret_cast<const KVR*>(kA_ + s * 32); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) kb##S[s] = *reinterpret_cast<const KVR*>(kB_ + s * 32); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) va##S[s] = *reinterpret_cast<const KVR*>(vA_ + s * 32); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) vb##S[s] = *reinterpret_cast<const KVR*>(vB_ + s * 32); \
   }
 
   // The V tile belongs to ONE wave: its LDS operations execute in order, so within a multi-wave (GROUPED) workgroup a
@@ -308,8 +340,8 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     const bool okA = pos0 + t < end, okB = pos0 + 16 + t < end;                                \
     /* S^T tiles: rows = tokens (4c+r), cols = heads (t) */                                    \
     f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};                                \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) sa = mfma16<DT>(ka##S[s], qf[s], sa);       \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) sb = mfma16<DT>(kb##S[s], qf[s], sb);       \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) sa = mfma16<DT>(FdKv<KV8>::frag(ka##S[s]), qf[s], sa); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) sb = mfma16<DT>(FdKv<KV8>::frag(kb##S[s]), qf[s], sb); \
     float sc[8];                                                                               \
     float mx = -INFINITY;                                                                      \
     _Pragma("unroll") for (int r = 0; r < 4; ++r) {                                            \
@@ -341,13 +373,13 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     FD_WAVE_SYNC(); /* previous tile's reads done */                                           \
     if (pos0 + 32 <= end) { /* whole tile inside the context (wave-uniform): no masking */     \
       _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                         \
-        *reinterpret_cast<Q4*>(&lds_v[t * VSTR + s * 32 + c * 8]) = va##S[s];                  \
-        *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + s * 32 + c * 8]) = vb##S[s];           \
+        *reinterpret_cast<Q4*>(&lds_v[t * VSTR + s * 32 + c * 8]) = FdKv<KV8>::frag(va##S[s]); \
+        *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + s * 32 + c * 8]) = FdKv<KV8>::frag(vb##S[s]); \
       }                                                                                        \
     } else {                                                                                   \
       _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                         \
-        *reinterpret_cast<Q4*>(&lds_v[t * VSTR + s * 32 + c * 8]) = okA ? va##S[s] : Q4{0, 0, 0, 0};        \
-        *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + s * 32 + c * 8]) = okB ? vb##S[s] : Q4{0, 0, 0, 0}; \
+        *reinterpret_cast<Q4*>(&lds_v[t * VSTR + s * 32 + c * 8]) = okA ? FdKv<KV8>::frag(va##S[s]) : Q4{0, 0, 0, 0};        \
+        *reinterpret_cast<Q4*>(&lds_v[(16 + t) * VSTR + s * 32 + c * 8]) = okB ? FdKv<KV8>::frag(vb##S[s]) : Q4{0, 0, 0, 0}; \
       }                                                                                        \
     }                                                                                          \
     FD_WAVE_SYNC();                                                                            \
@@ -388,7 +420,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
   }
 #endif
   // two register sets: tile i+1 is in flight while tile i is multiplied
-  Q4 kaA[NS], kbA[NS], vaA[NS], vbA[NS], kaB[NS], kbB[NS], vaB[NS], vbB[NS];
+  KVR kaA[NS], kbA[NS], vaA[NS], vbA[NS], kaB[NS], kbB[NS], vaB[NS], vbB[NS];
   FD_LOAD(A, 0)
   FD_LOAD(B, 1)
   if constexpr (ROPE) {
@@ -441,7 +473,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     if (np > 1 && head_ok) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last tile's V reads are done: the tile becomes the record
       float* rec = reinterpret_cast<float*>(lds_v);
-      const float inv = 1.0f / d_i;
+      const float inv = (KV8 ? rp.v_scale : 1.0f) / d_i;
 #pragma unroll
       for (int dt = 0; dt < NT; ++dt) {
         f32x4 o = ot[dt];
@@ -456,7 +488,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
       // single partition: stage 2 computes (0*0 + 1*(o/d)) / (0*0 + 1) -- the same value
       if (!head_ok) return;
       uint16_t* orow = out + b * o_sb + (int64_t)head * o_sh + 4 * c;
-      const float inv = 1.0f / d_i;
+      const float inv = (KV8 ? rp.v_scale : 1.0f) / d_i;
 #pragma unroll
       for (int dt = 0; dt < NT; ++dt) {
         uint16_t o4[4];
@@ -502,7 +534,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
   }
   if constexpr (!FUSE) {
     if (head_ok) {
-      const float inv = 1.0f / d_i;
+      const float inv = (KV8 ? rp.v_scale : 1.0f) / d_i;
       float* mo = mid_o + (((int64_t)b * hq + head) * nparts + part) * D;
 #pragma unroll
       for (int dt = 0; dt < NT; ++dt) {
@@ -518,7 +550,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     const int64_t hrow = ((int64_t)b * hq + (head_ok ? head : 0)) * nparts;
     if (np > 1) {
       if (head_ok) {
-        const float inv = 1.0f / d_i;
+        const float inv = (KV8 ? rp.v_scale : 1.0f) / d_i;
         float* mo = mid_o + (hrow + part) * D;
 #pragma unroll
         for (int dt = 0; dt < NT; ++dt) {
@@ -544,7 +576,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
       // single partition: stage 2 computes (0*0 + 1*(o/d)) / (0*0 + 1) -- the same value
       if (!head_ok) return;
       uint16_t* orow = out + b * o_sb + (int64_t)head * o_sh + 4 * c;
-      const float inv = 1.0f / d_i;
+      const float inv = (KV8 ? rp.v_scale : 1.0f) / d_i;
 #pragma unroll
       for (int dt = 0; dt < NT; ++dt) {
         uint16_t o4[4];
@@ -679,7 +711,8 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
                      const void* req, const void* seq, float* mid_o, float* mid_lse, int batch, int hq,
                      int hkv, int d, int64_t max_len, float scale, int64_t q_sb, int64_t q_sh,
                      int64_t k_st, int64_t k_sh, int64_t v_st, int64_t v_sh, int64_t o_sb, int64_t o_sh,
-                     int64_t t_sb, int req_w, int seq_w, int32_t* counters, const FdRope* rope, hipStream_t st) {
+                     int64_t t_sb, int req_w, int seq_w, int32_t* counters, const FdRope* rope, hipStream_t st,
+                     bool kv8 = false, float k_scale = 1.0f, float v_scale = 1.0f) {
   const int nparts = ll_flash_decoding_num_partitions(max_len);
   const int groups = hq / hkv;
   const int hgroups = (groups + 15) / 16;
@@ -687,7 +720,9 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
   // one launch when the caller lends a (zeroed, self-cleaning) counter vector and ``out`` takes 8-byte stores
   const bool fuse = counters != nullptr && (o_sb % 4 == 0) && (o_sh % 4 == 0) && ((uintptr_t)out % 8 == 0);
   if (rope && (!fuse || hgroups != 1 || d < 64)) return LL_ERR_SHAPE;
-  const FdRope rp = rope ? *rope : FdRope{};
+  FdRope rp = rope ? *rope : FdRope{};
+  rp.k_scale = k_scale;
+  rp.v_scale = v_scale;
   const bool grouped_ok = fuse && nparts >= 2 && nparts <= FD_GROUP_MAX;
   // split-K partial inputs need the grouped form and two float4 slots per lane: (groups + 2) * d / 4 <= 2 * 64 * nparts
   if (rope && rp.qp && (!grouped_ok || rp.qs < 1 || rp.qs > FD_QS_MAX || (groups + 2) * d / 4 > 128 * nparts || getenv("LL_FD_UNGROUPED") != nullptr))
@@ -695,18 +730,19 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
   // one workgroup per (row, KV head group) with a wave per partition while the context fits FD_GROUP_MAX partitions
   static const bool ungrouped_env = getenv("LL_FD_UNGROUPED") != nullptr;  // A/B knob, read once
   const bool grouped = grouped_ok && !ungrouped_env;
-#define LL_FD1X(DD, FU, RO, GG, GR)                                                                  \
+#define LL_FD1X(DD, FU, RO, GG, GR) LL_FD1XK(DD, FU, RO, GG, GR, false)
+#define LL_FD1XK(DD, FU, RO, GG, GR, K8)                                                             \
   {                                                                                                  \
     constexpr int tile_bytes_ = 32 * (DD + 8) * 2;                                                   \
     if (GR) {                                                                                        \
       static bool attr_ = false;                                                                     \
       if (!attr_) {                                                                                  \
-        (void)hipFuncSetAttribute((const void*)fd_stage1<DT, DD, FU, RO, GG, GR>,                    \
+        (void)hipFuncSetAttribute((const void*)fd_stage1<DT, DD, FU, RO, GG, GR, K8>,                \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, FD_GROUP_MAX * tile_bytes_ + 18 * DD * 2); \
         attr_ = true;                                                                                \
       }                                                                                              \
     }                                                                                                \
-    fd_stage1<DT, DD, FU, RO, GG, GR><<<(GR) ? dim3(1, grid.y, grid.z) : grid, (GR) ? 64 * nparts : 64, \
+    fd_stage1<DT, DD, FU, RO, GG, GR, K8><<<(GR) ? dim3(1, grid.y, grid.z) : grid, (GR) ? 64 * nparts : 64, \
                                         ((GR) ? nparts : 1) * tile_bytes_ + ((GR) ? 18 * DD * 2 : 0), st>>>( \
         (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, table, req, seq, mid_o, mid_lse, hq, hkv, nparts, \
         scale, q_sb, q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w, (uint16_t*)out, o_sb, o_sh, counters, rp); \
@@ -723,6 +759,25 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
     if constexpr (DD >= 64) { LL_FD1G(DD, true) } \
   } else if (fuse) { LL_FD1G(DD, false) }         \
   else LL_FD1X(DD, false, false, 16, false)
+  if (kv8) {
+    // fp8 KV cache: fp16 queries, the one-launch (counter / grouped) forms, head sizes 64 and 128
+    if constexpr (DT == LL_F16) {
+      if (rope || !fuse || (d != 64 && d != 128)) return LL_ERR_SHAPE;
+#define LL_FD8(DD, GG)                                   \
+  if (grouped) LL_FD1XK(DD, true, false, GG, true, true) \
+  else LL_FD1XK(DD, true, false, GG, false, true)
+#define LL_FD8G(DD)                  \
+  if (groups <= 4) { LL_FD8(DD, 4) } \
+  else if (groups <= 8) { LL_FD8(DD, 8) } \
+  else { LL_FD8(DD, 16) }
+      if (d == 64) { LL_FD8G(64) } else { LL_FD8G(128) }
+#undef LL_FD8G
+#undef LL_FD8
+      return LL_LAUNCH_CHECK();
+    } else {
+      return LL_ERR_DTYPE;
+    }
+  }
   switch (d) {
     case 32: LL_FD1D(32); break;
     case 64: LL_FD1D(64); break;
@@ -733,6 +788,7 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
 #undef LL_FD1D
 #undef LL_FD1G
 #undef LL_FD1
+#undef LL_FD1XK
 #undef LL_FD1X
   if (!fuse)
     fd_stage2<DT><<<dim3((unsigned)hq, (unsigned)batch), d, 0, st>>>((uint16_t*)out, mid_o, mid_lse, seq, hq, d,
@@ -745,21 +801,24 @@ static int fd_entry(void* out, const void* q, const void* k_cache, const void* v
                     int hkv, int d, int64_t max_len, float qk_scale, int64_t q_stride_b, int64_t q_stride_h,
                     int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
                     int64_t o_stride_b, int64_t o_stride_h, int64_t table_stride_b, int dtype, int req_width,
-                    int seq_width, int32_t* counters, const FdRope* rope, void* stream) {
+                    int seq_width, int32_t* counters, const FdRope* rope, void* stream, bool kv8 = false,
+                    float k_scale = 1.0f, float v_scale = 1.0f) {
   if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (kv8 && (dtype != LL_F16 || !(k_scale > 0.f) || !(v_scale > 0.f) || !counters)) return kv8 && dtype != LL_F16 ? LL_ERR_DTYPE : LL_ERR_ARG;
   if ((req_width | seq_width) & ~1) return LL_ERR_DTYPE;
   if (batch < 0 || hq <= 0 || hkv <= 0 || hq % hkv != 0 || max_len < 0) return LL_ERR_SHAPE;
   if (batch == 0) return LL_OK;
   // 16-byte fragment loads: every row/head stride and base must be 8-element aligned
-  if ((q_stride_b | q_stride_h | k_stride_t | k_stride_h | v_stride_t | v_stride_h) % 8 != 0 ||
-      !ll_aligned16(q) || !ll_aligned16(k_cache) || !ll_aligned16(v_cache))
+  // (fp8 pool: strides count bytes = elements, pieces are 8 bytes)
+  if ((q_stride_b | q_stride_h | k_stride_t | k_stride_h | v_stride_t | v_stride_h) % 8 != 0 || !ll_aligned16(q) ||
+      (kv8 ? (((uintptr_t)k_cache | (uintptr_t)v_cache) & 7) != 0 : (!ll_aligned16(k_cache) || !ll_aligned16(v_cache))))
     return LL_ERR_ARG;
   hipStream_t st = (hipStream_t)stream;
   if (dtype == LL_F16)
     return launch_fd<LL_F16>(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch,
                              hq, hkv, d, max_len, qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h,
                              v_stride_t, v_stride_h, o_stride_b, o_stride_h, table_stride_b, req_width,
-                             seq_width, counters, rope, st);
+                             seq_width, counters, rope, st, kv8, k_scale, v_scale);
   return launch_fd<LL_BF16>(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch, hq,
                             hkv, d, max_len, qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h,
                             v_stride_t, v_stride_h, o_stride_b, o_stride_h, table_stride_b, req_width,
@@ -777,6 +836,23 @@ extern "C" int ll_flash_decoding(void* out, const void* q, const void* k_cache, 
   return fd_entry(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch, hq, hkv, d, max_len,
                   qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_b,
                   o_stride_h, table_stride_b, dtype, req_width, seq_width, counters, nullptr, stream);
+}
+
+// flash_decoding over an fp8 (OCP e4m3) KV pool written by ll_update_kv_buffer_fp8: k_cache / v_cache are byte
+// tensors (strides in bytes), stored value * k_scale (v_scale) = K (V).  fp16 queries, head size 64 or 128, counters
+// required (one-launch forms only).  Same arithmetic as ll_flash_decoding on the widened values.
+extern "C" int ll_flash_decoding_fp8kv(void* out, const void* q, const void* k_cache, const void* v_cache,
+                                       const int32_t* table, const void* b_req_idx, const void* b_seq_len,
+                                       float* mid_o, float* mid_lse, int batch, int hq, int hkv, int d,
+                                       int64_t max_len, float qk_scale, float k_scale, float v_scale, int64_t q_stride_b,
+                                       int64_t q_stride_h, int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t,
+                                       int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
+                                       int64_t table_stride_b, int req_width, int seq_width, int32_t* counters,
+                                       void* stream) {
+  return fd_entry(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch, hq, hkv, d, max_len,
+                  qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_b,
+                  o_stride_h, table_stride_b, LL_F16, req_width, seq_width, counters, nullptr, stream, true, k_scale,
+                  v_scale);
 }
 
 // Decode-step attention in ONE launch: rope(q, k_new) + KV scatter of the new token + flash_decoding

@@ -51,6 +51,56 @@ extern "C" int ll_update_kv_buffer(const void* vals, const void* select_index, v
   return LL_LAUNCH_CHECK();
 }
 
+// fp8 KV cache (extension): the same scatter with the rows quantised to OCP e4m3 (gfx950's native fp8):
+// head h < k_heads is divided by k_scale, the others by v_scale, clamped to +-448 and rounded to nearest even by
+// v_cvt_pk_fp8_f32.  One block per token, 8 values per thread.
+template <int DT>
+__global__ __launch_bounds__(256) void update_kv_buffer_fp8_kernel(
+    const uint16_t* __restrict__ vals, const void* __restrict__ sel, uint8_t* __restrict__ buf, int heads, int k_heads,
+    int hd, int64_t vst, int64_t vsh, int64_t bst, int64_t bsh, float k_scale, float v_scale, int idx_w) {
+  const int64_t tok = blockIdx.x;
+  const int64_t dst = load_idx_rt(sel, tok, idx_w);
+  const int vph = hd / 8;
+  const int total = heads * vph;
+  for (int i = threadIdx.x; i < total; i += 256) {
+    const int h = i / vph, j = (i % vph) * 8;
+    uint16_t v[8];
+    VecIO<8>::load(vals + tok * vst + (int64_t)h * vsh + j, v);
+    const float sc = h < k_heads ? k_scale : v_scale;
+    float f[8];
+#pragma unroll
+    for (int e = 0; e < 8; ++e) f[e] = fminf(fmaxf(to_f32<DT>(v[e]) / sc, -448.0f), 448.0f);  // a true division: x / s, not x * (1 / s)
+    int lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[0], f[1], 0, false);
+    lo = __builtin_amdgcn_cvt_pk_fp8_f32(f[2], f[3], lo, true);
+    int hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[4], f[5], 0, false);
+    hi = __builtin_amdgcn_cvt_pk_fp8_f32(f[6], f[7], hi, true);
+    *reinterpret_cast<uint2*>(buf + dst * bst + (int64_t)h * bsh + j) = uint2{(uint32_t)lo, (uint32_t)hi};
+  }
+}
+
+extern "C" int ll_update_kv_buffer_fp8(const void* vals, const void* select_index, void* buf, int64_t tokens, int heads,
+                                       int k_heads, int hd, int64_t v_stride_t, int64_t v_stride_h, int64_t b_stride_t,
+                                       int64_t b_stride_h, float k_scale, float v_scale, int dtype, int idx_width,
+                                       void* stream) {
+  if (idx_width != LL_I32 && idx_width != LL_I64) return LL_ERR_DTYPE;
+  if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (tokens < 0 || heads <= 0 || k_heads < 0 || k_heads > heads || hd <= 0 || hd % 8 != 0) return LL_ERR_SHAPE;
+  if (!(k_scale > 0.f) || !(v_scale > 0.f)) return LL_ERR_ARG;
+  if (tokens == 0) return LL_OK;
+  if (!ll_aligned16(vals) || ((uintptr_t)buf & 7) || (v_stride_t % 8) || (v_stride_h % 8) || (b_stride_t % 8) || (b_stride_h % 8))
+    return LL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LL_F16)
+    update_kv_buffer_fp8_kernel<LL_F16><<<dim3((unsigned)tokens), 256, 0, st>>>(
+        (const uint16_t*)vals, select_index, (uint8_t*)buf, heads, k_heads, hd, v_stride_t, v_stride_h, b_stride_t,
+        b_stride_h, k_scale, v_scale, idx_width);
+  else
+    update_kv_buffer_fp8_kernel<LL_BF16><<<dim3((unsigned)tokens), 256, 0, st>>>(
+        (const uint16_t*)vals, select_index, (uint8_t*)buf, heads, k_heads, hd, v_stride_t, v_stride_h, b_stride_t,
+        b_stride_h, k_scale, v_scale, idx_width);
+  return LL_LAUNCH_CHECK();
+}
+
 __global__ void update_kv_index_kernel(int32_t* __restrict__ table, const void* __restrict__ req,
                                        const void* __restrict__ seq, const void* __restrict__ sel,
                                        int64_t n, int64_t sb, int64_t ss, int rw, int sw, int lw) {

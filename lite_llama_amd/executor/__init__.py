@@ -34,6 +34,7 @@ class AttentionMetadata:
     b_req_idx: torch.Tensor | None = None
     b_seq_len: torch.Tensor | None = None
     max_actual_seq_len: int = 0
+    kv_scales: tuple = (1.0, 1.0)                          # fp8 KV pool only (extension): stored value * scale = K / V
 
 
 @dataclass
@@ -89,7 +90,7 @@ class DecodeEngine:
     """
 
     def __init__(self, model, max_batch: int, max_seq_len: int, device="cuda", kv_dtype=torch.float16,
-                 kv_block_size: int | None = None):
+                 kv_block_size: int | None = None, kv_scales: tuple = (1.0, 1.0)):
         """``kv_block_size`` (extension): hand the KV pool out in blocks of that many rows from a device-side
         free stack (:class:`PagedKVPool`) instead of the reference's bump allocator; the kernels read the same per-token
         table either way, so the generated tokens are identical."""
@@ -108,7 +109,7 @@ class DecodeEngine:
                                     device, max_batch, max_seq_len, kv_dtype)
         else:
             self.pool = KVPool(geo.num_layers, max_batch * max_seq_len, at0.num_kv_heads, geo.head_dim, device, kv_dtype)
-        self.info = AttentionMetadata(kv_buffer=self.pool.kv_buffer)
+        self.info = AttentionMetadata(kv_buffer=self.pool.kv_buffer, kv_scales=tuple(float(v) for v in kv_scales))
         self.info.b_req_tokens_table = torch.zeros(max_batch, max_seq_len, dtype=torch.int32, device=device)
         self._graph = None
         self._graph_key = None

@@ -86,6 +86,43 @@ def flash_decoding(
     return out
 
 
+@torch.no_grad()
+def flash_decoding_fp8kv(q, k_cache, v_cache, qk_scale, b_req_tokens_table, b_req_idx, b_seq_len, max_actual_seq_len,
+                         k_scale: float = 1.0, v_scale: float = 1.0):
+    """``flash_decoding`` over an fp8 (OCP e4m3) pool written by ``update_kv_buffer_fp8`` (extension): ``k_cache`` /
+    ``v_cache`` are uint8 / float8_e4m3fn views ``[rows, Hkv, D]``; fp16 queries, ``D`` 64 or 128."""
+    L.require_cuda(q, k_cache, v_cache, b_req_tokens_table, b_req_idx, b_seq_len)
+    assert q.dtype == torch.float16 and k_cache.element_size() == 1 and v_cache.element_size() == 1
+    assert q.shape[-1] == k_cache.shape[-1] == v_cache.shape[-1] and b_req_tokens_table.dtype == torch.int32
+    batchs, num_heads, head_dim = q.shape
+    if q.stride(-1) != 1:
+        q = q.contiguous()
+    assert k_cache.stride(-1) == 1 and v_cache.stride(-1) == 1
+    if b_req_tokens_table.stride(1) != 1:
+        b_req_tokens_table = b_req_tokens_table.contiguous()
+    max_len = int(max_actual_seq_len)
+    nparts = L.lib().ll_flash_decoding_num_partitions(max_len)
+    mid_o = torch.empty((batchs, num_heads, max(nparts, 1), head_dim), dtype=torch.float32, device=q.device)
+    out = torch.empty_like(q, memory_format=torch.contiguous_format)
+    n_kv = k_cache.shape[1]
+    counters = _merge_counters(q.device, batchs * n_kv * ((num_heads // n_kv + 15) // 16))
+    if counters is None:
+        raise L.KernelError("flash_decoding_fp8kv needs the merge counters (not available during this capture)")
+    mid_lse = torch.empty((batchs, num_heads, max(nparts, 1), 32), dtype=torch.float32, device=q.device)
+    L.check(
+        L.lib().ll_flash_decoding_fp8kv(
+            out.data_ptr(), q.data_ptr(), k_cache.data_ptr(), v_cache.data_ptr(), b_req_tokens_table.data_ptr(),
+            b_req_idx.data_ptr(), b_seq_len.data_ptr(), mid_o.data_ptr(), mid_lse.data_ptr(), batchs, num_heads, n_kv,
+            head_dim, max_len, float(qk_scale), float(k_scale), float(v_scale), q.stride(0), q.stride(1),
+            k_cache.stride(0), k_cache.stride(1), v_cache.stride(0), v_cache.stride(1), out.stride(0), out.stride(1),
+            b_req_tokens_table.stride(0), L.index_width(b_req_idx), L.index_width(b_seq_len), L.ptr(counters),
+            L.stream_ptr(),
+        ),
+        "flash_decoding_fp8kv",
+    )
+    return out
+
+
 def decode_attention_supported(q, kv, cos, n_kv_heads: int) -> bool:
     """Shapes the one-launch decode attention serves: head_dim >= 64, at most 16 query heads per KV
     head, dense [heads, head_dim] rows, 16-bit tables of the activation dtype."""

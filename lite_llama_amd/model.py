@@ -32,6 +32,8 @@ from .kernels import (
     skip_rmsnorm,
     swiglu_forward,
     update_kv_buffer,
+    update_kv_buffer_fp8,
+    flash_decoding_fp8kv,
 )
 from .linear import ColumnParallelLinear, LinearBase, MergedColumnLinear, RowParallelLinear
 from .quantization import QuantConfig, get_moe_method
@@ -175,7 +177,19 @@ class PagedAttention(nn.Module):
     def forward(self, xq, xkv, atten_info, layer_index: int, is_prefill: bool, cached: bool = False):
         """``xkv [n, 2*Hkv, D]`` = this step's K heads then V heads (the pool's row layout), possibly
         a strided view of the fused projection output; ``cached``: already scattered to the pool."""
-        if not cached:
+        pool = atten_info.kv_buffer[layer_index]
+        if pool.element_size() == 1:
+            # fp8 KV cache (extension): quantising scatter, then -- decode -- attention over the e4m3 pool; the prefill
+            # attention reads the fresh fp16 q / k / v as always
+            ks, vs = getattr(atten_info, "kv_scales", (1.0, 1.0))
+            if cached:
+                raise ValueError("an fp8 KV pool is written by update_kv_buffer_fp8 only (no fused rope + scatter)")
+            update_kv_buffer_fp8(xkv, atten_info.cur_select_index, pool, self.num_kv_heads, ks, vs)
+            if not is_prefill:
+                return flash_decoding_fp8kv(xq, pool[:, : self.num_kv_heads, :], pool[:, self.num_kv_heads :, :], self.scale,
+                                            atten_info.b_req_tokens_table, atten_info.b_req_idx, atten_info.b_seq_len,
+                                            atten_info.max_actual_seq_len, ks, vs)
+        elif not cached:
             update_kv_buffer(xkv, atten_info.cur_select_index, atten_info.kv_buffer[layer_index])
         if is_prefill:
             xk, xv = xkv[:, : self.num_kv_heads], xkv[:, self.num_kv_heads :]
@@ -215,8 +229,9 @@ class Attention(nn.Module):
     def forward(self, x, atten_info, layer_index, position_embeddings, partials_ok=False):
         batch, seq_len, _ = x.shape
         x2 = x.view(-1, self.hidden_size)
+        fp8_pool = atten_info.kv_buffer[layer_index].element_size() == 1  # extension: e4m3 KV cache, unfused route
         if (seq_len == 1 and not self.use_qk_norm and not _TWO_CALL_ATTENTION and isinstance(position_embeddings, RopeTables)
-                and self._qkv.refresh() and not os.environ.get("LL_NO_QKV_PARTIALS")
+                and not fp8_pool and self._qkv.refresh() and not os.environ.get("LL_NO_QKV_PARTIALS")
                 and decode_attention_partials_supported(atten_info.max_actual_seq_len, self.num_heads, self.num_kv_heads,
                                                         self.head_dim)):
             # decode, int4, TP = 1: the fused q|k|v projection leaves fp32 split-K partials and the one-launch attention
@@ -249,7 +264,8 @@ class Attention(nn.Module):
             xq, _ = skip_rmsnorm(xq, None, self.q_norm_weight, self.eps)
             xk, _ = skip_rmsnorm(xk, None, self.k_norm_weight, self.eps)
         tables = position_embeddings if isinstance(position_embeddings, RopeTables) else None
-        fused = not self.use_qk_norm and xkv.stride(1) == self.head_dim and xq.stride(1) == self.head_dim
+        fused = (not self.use_qk_norm and xkv.stride(1) == self.head_dim and xq.stride(1) == self.head_dim
+                 and not fp8_pool)
         if tables is not None and not fused:
             position_embeddings = tables.materialise()
         if fused and tables is not None and seq_len == 1 and not _TWO_CALL_ATTENTION:
