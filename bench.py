@@ -51,6 +51,9 @@ def parse():
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--scattered", action="store_true", help="context rows in random pool order (gather cost)")
     ap.add_argument("--kv-block-size", type=int, default=0, help="block-granular KV paging on the device (0: the reference's bump allocator)")
+    ap.add_argument("--allreduce", default="auto", choices=["auto", "rccl", "oneshot"],
+                    help="TP collective: RCCL, the one-shot peer-to-peer kernel, or (auto) the kernel if it passes a start-up "
+                         "check against RCCL on this hardware")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--cpu-layers", type=int, default=1, help="decoder layers in the CPU oracle sample")
     return ap.parse_args()
@@ -81,8 +84,13 @@ def gemm_roofline(model, batch, quant, iters=6):
     projection of the model with its real weights -- the same calls the decode step makes (fused [q|k|v],
     fused [gate|up] + swiglu, row-parallel projections in split-K partial mode) -- by HIP events on the
     launch stream around hipGraph replays of the launch list (eager back-to-back launches as fallback)."""
+    from lite_llama_amd.distributed.parallel_state import collective_forced, get_tp_world_size
     from lite_llama_amd.linear import LinearBase, MergedColumnLinear, RowParallelLinear
 
+    # rank 0 times these launches ALONE: nothing in the list may communicate.  At TP = 1 a row-parallel projection runs as
+    # in the step (split-K partial mode); under TP the step's launch is the plain GEMM followed by the all-reduce -- only
+    # the GEMM is timed here (calling the layer itself would issue a collective the other ranks never join)
+    solo = get_tp_world_size() == 1 and not collective_forced()
     merged = [m for mod in model.modules() for m in vars(mod).values() if isinstance(m, MergedColumnLinear)]
     fused_members = set()
     launches_list = []  # (callable, input_size, weights in the launch)
@@ -96,7 +104,7 @@ def gemm_roofline(model, batch, quant, iters=6):
             launches_list.append((fn, mc.layers[0].input_size, sum(l.input_size * l.output_size for l in mc.layers)))
     for m in model.modules():
         if isinstance(m, LinearBase) and m.quant is not None and id(m) not in fused_members:
-            fn = (lambda x, m=m: m(x, partials_ok=True)) if isinstance(m, RowParallelLinear) else m.apply_linear
+            fn = (lambda x, m=m: m(x, partials_ok=True)) if (isinstance(m, RowParallelLinear) and solo) else m.apply_linear
             launches_list.append((fn, m.input_size, m.input_size * m.output_size))
     if not launches_list:
         return None
@@ -270,10 +278,50 @@ def cpu_baseline(geo, batch, ctx, layers, quant):
             "sample_seconds": round(t_all + t_head, 1)}
 
 
+def choose_allreduce(ps, elems, dev, strict):
+    """Enable the one-shot peer-to-peer all-reduce (csrc/tp_allreduce.hip) if -- on THIS hardware, now -- it reproduces
+    RCCL's sums on random payloads of the step's size; every rank takes the same decision (MIN over the group).  Returns
+    the label that goes into the JSON line.  ``strict``: a failed check raises instead of falling back."""
+    import torch.distributed as dist
+
+    why = ""
+    ok = 1
+    try:
+        ps.enable_oneshot_all_reduce(elems)
+        for it in range(4):
+            g = torch.Generator(device=dev).manual_seed(1234 + 17 * it + ps.get_tp_rank())
+            x = (torch.randn(elems, device=dev, generator=g) * 0.25).half()
+            y = x.clone()
+            ps._ONESHOT.all_reduce(x)
+            dist.all_reduce(y, group=ps._TP_GROUP)
+            torch.cuda.synchronize()
+            # RCCL adds fp16 values hop by hop, the kernel adds in fp32 and rounds once: equal up to that rounding
+            if not torch.allclose(x.float(), y.float(), rtol=2e-2, atol=2e-3):
+                ok, why = 0, "sums differ from RCCL's"
+                break
+        if ok and ps.oneshot_error():
+            ok, why = 0, "a peer flag timed out"
+    except Exception as exc:  # mapping refused, allocation failed, ...
+        ok, why = 0, f"{type(exc).__name__}: {exc}"[:200]
+    flag = torch.tensor([ok], device=dev, dtype=torch.int32)
+    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ps._TP_GROUP)
+    if int(flag.item()) == 1:
+        return "oneshot (peer-mapped buffers, checked against RCCL at start-up)"
+    if ps._ONESHOT is not None:
+        ps._ONESHOT.close()
+        ps._ONESHOT = None
+    if strict:
+        raise SystemExit(f"--allreduce oneshot: start-up check failed on this rank or a peer ({why or 'peer'})")
+    print(f"[bench] one-shot all-reduce not used ({why or 'a peer refused'}); RCCL carries the collective", file=sys.stderr)
+    return "rccl (one-shot kernel failed its start-up check)"
+
+
 def main():
     args = parse()
     rank = int(os.environ.get("RANK", 0))
-    local_rank = int(os.environ.get("LOCAL_RANK", 0))
+    # LL_BENCH_DEVICE: debugging knob -- all ranks on one device (with LL_DIST_BACKEND=gloo: RCCL refuses that), to run
+    # the multi-rank code path on a one-GPU box
+    local_rank = int(os.environ.get("LL_BENCH_DEVICE", os.environ.get("LOCAL_RANK", 0)))
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
@@ -299,6 +347,9 @@ def main():
             break
     dp = world // tp
     ps.init_parallel(rank, tp_size=tp, dp_size=dp, master_port=int(os.environ.get("MASTER_PORT", 29500)))
+    allreduce_how = "none (tp1)" if tp == 1 else "rccl"
+    if tp > 1 and args.allreduce != "rccl":
+        allreduce_how = choose_allreduce(ps, args.batch * geo.hidden_size, dev, strict=args.allreduce == "oneshot")
     if world > 1 and not torch.distributed.is_initialized():  # pure DP: still need the timing barrier
         torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
 
@@ -329,7 +380,12 @@ def main():
             marks["t0"] = time.perf_counter()
 
     use_graph = not args.no_graph
-    graph_note = "hipGraph" if use_graph else "eager (--no-graph)"
+    if use_graph and tp > 1 and os.environ.get("LL_DIST_BACKEND") == "gloo" and not allreduce_how.startswith("oneshot"):
+        # debugging set-up (ranks sharing a device, collectives staged through the host): a gloo collective cannot be
+        # recorded, and a refused capture is not recoverable on this stack -- measure eager launches and say so
+        use_graph = False
+        print("[bench] gloo collectives cannot be captured: measuring eager launches", file=sys.stderr, flush=True)
+    graph_note = "hipGraph" if use_graph else "eager (--no-graph or uncapturable backend)"
     graph_error = None
     try:
         out = engine.decode(first, total, use_graph=use_graph, on_step=on_step)
@@ -379,11 +435,12 @@ def main():
                   "fp8": "f16 (fp8-e4m3 weights, fp32 accumulate)", "smoothquant": "int8 (int32 accumulate, f16 epilogue)",
                   "none": "f16 (fp32 accumulate)"}[args.quant],
         "data": "synthetic", "graph": bool(use_graph), "graph_error": graph_error,
+        "allreduce_error": ps.oneshot_error(),  # 0, or 1: a peer flag of the one-shot all-reduce timed out during the run
         "config": {"workload": f"{args.model} {args.quant} decode, batch {args.batch}/replica, ctx {args.ctx}->"
                                f"{args.ctx + total}, {graph_note}" + (", scattered KV rows" if args.scattered else "")
                                + (f", KV paged in blocks of {args.kv_block_size}" if args.kv_block_size else ""),
                    "global_batch": global_batch,
-                   "parallelism": f"dp{dp}xtp{tp}", "build_seconds": round(t_build, 1)},
+                   "parallelism": f"dp{dp}xtp{tp}", "allreduce": allreduce_how, "build_seconds": round(t_build, 1)},
         "step_roofline": {"algorithmic_bytes_per_step_per_gpu": int(step_bytes),
                           "achieved_GBps_per_gpu": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
                           "frac_of_8TBps": round(step_bytes / (elapsed / args.steps) / PEAK_HBM, 4)},

@@ -291,6 +291,27 @@ int ll_kv_alloc(int32_t* state, int64_t n_rows, int64_t need, int contiguous_fir
 int ll_kv_ref_update(int32_t* state, int64_t n_rows, const void* index, int64_t count, int idx_width,
                      int delta, int64_t* free_rows, void* stream);
 
+/* ---- one-shot tensor-parallel all-reduce on peer-mapped buffers (a13) -----------------------
+ * Replaces the ncclAllReduce of lite_llama/distributed/parallel_state.py:208-213 (in-place SUM of the [tokens, hidden]
+ * 16-bit partial sums after every row-parallel projection) for payloads that fit a staging buffer: every rank publishes
+ * its tensor in fine-grained memory its peers have mapped, raises a flag in each peer, waits for the peers' flags in its
+ * own memory and reads the world - 1 peer buffers over its direct xGMI links, summing in fp32 in RANK ORDER (all ranks
+ * get bit-identical results).  One launch, no host call: capturable.  Setup (host, once): ll_tp_shared_alloc the staging
+ * buffer [2][stage_elems] 16-bit and ll_tp_oneshot_flag_words(blocks, world) int32 flag words, exchange
+ * ll_tp_ipc_export handles through any host channel, ll_tp_ipc_open the peers'.  A peer that does not show up within the
+ * spin bound sets bit 0 of the error word (the LAST flag word) and is left out of the sum. */
+int ll_tp_shared_alloc(void** ptr, int64_t bytes);
+int ll_tp_shared_free(void* ptr);
+int ll_tp_ipc_export(void* ptr, void* handle64);
+int ll_tp_ipc_open(const void* handle64, void** ptr);
+int ll_tp_ipc_close(void* ptr);
+int64_t ll_tp_oneshot_flag_words(int blocks, int world);
+/* stage_ptrs / flag_ptrs: HOST arrays of `world` device pointers (entry r = rank r's buffers, mine included);
+ * epoch_done: two int32 in this rank's memory, zero before the first launch.  Every rank issues the same call sequence
+ * (same count, same blocks).  count <= stage_elems, count % 8 == 0, world <= 8. */
+int ll_tp_allreduce_oneshot(void* inout, int64_t count, int dtype, const void* const* stage_ptrs, void* const* flag_ptrs,
+                            int rank, int world, int64_t stage_elems, int blocks, int32_t* epoch_done, void* stream);
+
 /* ---- fp8 KV cache (extension -- the reference's pool is fp16, executor/kv_cache_manager.py:197-216) ----
  * The pool holds OCP e4m3 bytes; stored value * k_scale (v_scale) = K (V) value, static per pool.
  * ll_update_kv_buffer_fp8: a3's scatter with quantisation -- heads [0, k_heads) are K heads (divided by k_scale), the

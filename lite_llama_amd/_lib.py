@@ -63,6 +63,13 @@ SIGNATURES = {
     "ll_kv_ref_update": [P, L, P, L, I, I, P, P],
     "ll_update_kv_buffer_fp8": [P, P, P, L, I, I, I, L, L, L, L, F, F, I, I, P],
     "ll_flash_decoding_fp8kv": [P, P, P, P, P, P, P, P, P, I, I, I, I, L, F, F, F, L, L, L, L, L, L, L, L, L, I, I, P, P],
+    "ll_tp_shared_alloc": [P, L],
+    "ll_tp_shared_free": [P],
+    "ll_tp_ipc_export": [P, P],
+    "ll_tp_ipc_open": [P, P],
+    "ll_tp_ipc_close": [P],
+    "ll_tp_oneshot_flag_words": [I, I],
+    "ll_tp_allreduce_oneshot": [P, L, I, P, P, I, I, L, I, P, P],
     "ll_kv_paged_reset": [P, P, P, L, L, P],
     "ll_kv_paged_extend": [P, P, P, L, P, P, P, I, L, I, L, I, P, L, P, L, P],
     "ll_kv_paged_release": [P, P, P, L, P, P, L, P],
@@ -73,7 +80,7 @@ SIGNATURES = {
     "ll_argmax_split": [P, P, L, L, L, I, P, I, P],
 }
 
-_RETURNS_I64 = {"ll_kv_alloc_scratch_bytes"}
+_RETURNS_I64 = {"ll_kv_alloc_scratch_bytes", "ll_tp_oneshot_flag_words"}
 _lib = None
 
 

@@ -1,0 +1,165 @@
+// One-shot tensor-parallel all-reduce on peer-mapped buffers (the native target for the block's single
+// collective -- lite_llama/distributed/parallel_state.py:208-213 issues ncclAllReduce on a [tokens, hidden] fp16 tensor
+// after every row-parallel projection, 56 per Qwen2.5-7B step).  The payload is small (0.25-0.5 MB), xGMI is
+// point-to-point (every GPU has a direct link to each of its 7 peers): a ring all-reduce pays 2 (N - 1) latency-bound hops,
+// a ONE-SHOT exchange pays one -- every rank publishes its partial sums in a buffer its peers have mapped
+// (hipIpcMemHandle), raises a flag in each peer's memory, waits for the peers' flags in its OWN memory and then reads the
+// N - 1 peer buffers over its N - 1 direct links while adding them up in fp32, in rank order (all ranks produce
+// bit-identical sums).  One launch, no host call, capturable in the decode graph.
+//
+// Protocol per launch (epoch e = *epoch + 1, parity p = e & 1; B = gridDim.x workgroups, workgroup b owns slice b of the
+// payload for all three phases, so no grid-wide barrier is needed):
+//   1. copy slice b of `inout` into my staging half p (write-through stores), __threadfence_system();
+//   2. lane r < world stores e into peer r's flag word [p][b][my rank] (release, system scope);
+//   3. lane r < world spins (bounded) on MY flag word [p][b][r] until it reads e (acquire, system scope);
+//   4. out[i] = fp16( sum_r fp32(stage_r[p][i]) ) for the slice, peers read with system-scope loads;
+//   5. the last workgroup out stores e to *epoch.
+// A staging half is rewritten two launches later; a peer can only be one launch behind (it cannot pass the wait of
+// launch e + 1 before I have raised flag e + 1, which I do after finishing launch e), so nobody is still reading it.
+// Memory: staging and flags live in fine-grained device memory (ll_tp_shared_alloc) so that peer writes become visible
+// inside a running kernel.  A wait that times out sets bit 0 of the error word (flags[2 * B * world]) and the launch
+// falls back to its own partial sums for the missing peer -- the caller checks the word when it synchronises.
+#include "common.h"
+
+namespace {
+
+constexpr int kMaxWorld = 8;
+constexpr int kSpinLimit = 1 << 20;  // ~1 s of polling: far beyond any skew between ranks inside a step
+
+struct PeerTable {
+  const uint16_t* stage[kMaxWorld];
+  int32_t* flags[kMaxWorld];
+};
+
+template <int DT>
+__global__ __launch_bounds__(256) void allreduce_oneshot_kernel(uint16_t* __restrict__ inout, int64_t count, PeerTable peers,
+                                                                int rank, int world, int64_t stage_elems,
+                                                                int32_t* __restrict__ epoch, int32_t* __restrict__ done) {
+  const int nb = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
+  const int e = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
+  const int p = e & 1;
+  const int64_t vecs = (count + 7) / 8;                       // 16-byte pieces
+  const int64_t per = (vecs + nb - 1) / nb;
+  const int64_t v_lo = (int64_t)b * per, v_hi = v_lo + per < vecs ? v_lo + per : vecs;
+  uint16_t* mine = const_cast<uint16_t*>(peers.stage[rank]) + (int64_t)p * stage_elems;
+  // 1. publish my slice
+  for (int64_t v = v_lo + tid; v < v_hi; v += 256) {
+    const i32x4 x = *reinterpret_cast<const i32x4*>(inout + v * 8);
+    __builtin_nontemporal_store(x, reinterpret_cast<i32x4*>(mine + v * 8));
+  }
+  __threadfence_system();
+  __syncthreads();
+  // 2. + 3. flags
+  __shared__ int failed;
+  if (tid == 0) failed = 0;
+  __syncthreads();
+  const int64_t slot = ((int64_t)p * nb + b) * world;
+  if (tid < world) {
+    __hip_atomic_store(peers.flags[tid] + slot + rank, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_SYSTEM);
+    int32_t* my = peers.flags[rank] + slot + tid;
+    int spins = 0;
+    while (__hip_atomic_load(my, __ATOMIC_ACQUIRE, __HIP_MEMORY_SCOPE_SYSTEM) != e) {
+      if (++spins > kSpinLimit) {
+        atomicOr(&failed, 1 << tid);
+        break;
+      }
+      __builtin_amdgcn_s_sleep(2);
+    }
+  }
+  __syncthreads();
+  const int bad = failed;
+  if (bad && tid == 0) atomicOr(peers.flags[rank] + 2 * (int64_t)nb * world, 1);
+  // 4. reduce in rank order
+  for (int64_t v = v_lo + tid; v < v_hi; v += 256) {
+    float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int r = 0; r < world; ++r) {
+      const uint16_t* src = ((bad >> r) & 1) ? nullptr : peers.stage[r] + (int64_t)p * stage_elems + v * 8;
+      if (!src) continue;
+      const i32x4 x = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(src));
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        acc[2 * j] += to_f32<DT>((uint16_t)((uint32_t)x[j] & 0xffffu));
+        acc[2 * j + 1] += to_f32<DT>((uint16_t)((uint32_t)x[j] >> 16));
+      }
+    }
+    i32x4 o;
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      o[j] = (int)((uint32_t)from_f32<DT>(acc[2 * j]) | ((uint32_t)from_f32<DT>(acc[2 * j + 1]) << 16));
+    *reinterpret_cast<i32x4*>(inout + v * 8) = o;
+  }
+  // 5. the last workgroup out advances the epoch
+  __syncthreads();
+  if (tid == 0) {
+    const int old = __hip_atomic_fetch_add(done, 1, __ATOMIC_ACQ_REL, __HIP_MEMORY_SCOPE_AGENT);
+    if (old == nb - 1) {
+      __hip_atomic_store(done, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      __hip_atomic_store(epoch, e, __ATOMIC_RELEASE, __HIP_MEMORY_SCOPE_AGENT);
+    }
+  }
+}
+
+}  // namespace
+
+// Fine-grained device memory (peer stores become visible inside a running kernel), zero-filled.
+extern "C" int ll_tp_shared_alloc(void** ptr, int64_t bytes) {
+  if (!ptr || bytes <= 0) return LL_ERR_ARG;
+  void* p = nullptr;
+  if (hipExtMallocWithFlags(&p, (size_t)bytes, hipDeviceMallocFinegrained) != hipSuccess) {
+    (void)hipGetLastError();
+    return LL_ERR_LAUNCH;
+  }
+  if (hipMemset(p, 0, (size_t)bytes) != hipSuccess || hipDeviceSynchronize() != hipSuccess) {
+    (void)hipFree(p);
+    return LL_ERR_LAUNCH;
+  }
+  *ptr = p;
+  return LL_OK;
+}
+extern "C" int ll_tp_shared_free(void* ptr) { return ptr && hipFree(ptr) != hipSuccess ? LL_ERR_LAUNCH : LL_OK; }
+
+// 64-byte handle of an allocation for another process / its mapping here (peer access enabled lazily).
+extern "C" int ll_tp_ipc_export(void* ptr, void* handle64) {
+  if (!ptr || !handle64) return LL_ERR_ARG;
+  static_assert(sizeof(hipIpcMemHandle_t) == 64, "handle size");
+  return hipIpcGetMemHandle(reinterpret_cast<hipIpcMemHandle_t*>(handle64), ptr) == hipSuccess ? LL_OK : LL_ERR_LAUNCH;
+}
+extern "C" int ll_tp_ipc_open(const void* handle64, void** ptr) {
+  if (!ptr || !handle64) return LL_ERR_ARG;
+  hipIpcMemHandle_t h;
+  __builtin_memcpy(&h, handle64, sizeof(h));
+  return hipIpcOpenMemHandle(ptr, h, hipIpcMemLazyEnablePeerAccess) == hipSuccess ? LL_OK : LL_ERR_LAUNCH;
+}
+extern "C" int ll_tp_ipc_close(void* ptr) { return ptr && hipIpcCloseMemHandle(ptr) != hipSuccess ? LL_ERR_LAUNCH : LL_OK; }
+
+// Flag words a rank needs for `blocks` workgroups: [2][blocks][world] + the error word.
+extern "C" int64_t ll_tp_oneshot_flag_words(int blocks, int world) { return 2ll * blocks * world + 1; }
+
+// In-place SUM over the ranks of a TP group.  stage_ptrs / flag_ptrs: HOST arrays of `world` device pointers (entry r =
+// rank r's staging buffer [2][stage_elems] 16-bit / flag words, mine included; peers' entries come from ll_tp_ipc_open);
+// epoch_done: two int32 in MY memory (launch counter, workgroup ticket), zero before the first launch; every rank must
+// issue the same sequence of calls with the same count and blocks.  count <= stage_elems, count % 8 == 0.
+extern "C" int ll_tp_allreduce_oneshot(void* inout, int64_t count, int dtype, const void* const* stage_ptrs,
+                                       void* const* flag_ptrs, int rank, int world, int64_t stage_elems, int blocks,
+                                       int32_t* epoch_done, void* stream) {
+  if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (world < 1 || world > kMaxWorld || rank < 0 || rank >= world || count < 0 || count > stage_elems || count % 8 != 0 ||
+      blocks < 1 || blocks > 1024)
+    return LL_ERR_SHAPE;
+  if (count == 0) return LL_OK;
+  if (!inout || !stage_ptrs || !flag_ptrs || !epoch_done || !ll_aligned16(inout)) return LL_ERR_ARG;
+  PeerTable t{};
+  for (int r = 0; r < world; ++r) {
+    if (!stage_ptrs[r] || !flag_ptrs[r]) return LL_ERR_ARG;
+    t.stage[r] = (const uint16_t*)stage_ptrs[r];
+    t.flags[r] = (int32_t*)flag_ptrs[r];
+  }
+  hipStream_t st = (hipStream_t)stream;
+  if (dtype == LL_F16)
+    allreduce_oneshot_kernel<LL_F16><<<blocks, 256, 0, st>>>((uint16_t*)inout, count, t, rank, world, stage_elems,
+                                                              epoch_done, epoch_done + 1);
+  else
+    allreduce_oneshot_kernel<LL_BF16><<<blocks, 256, 0, st>>>((uint16_t*)inout, count, t, rank, world, stage_elems,
+                                                               epoch_done, epoch_done + 1);
+  return LL_LAUNCH_CHECK();
+}

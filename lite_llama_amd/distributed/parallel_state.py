@@ -21,6 +21,7 @@ _DP_RANK = 0
 _DP_WORLD_SIZE = 1
 _OWNS_PG = False
 _FORCE_COLLECTIVE = False  # test knob (LL_TP_FORCE_COLLECTIVE): a world of ONE still issues its all-reduces on the backend
+_ONESHOT = None            # peer-mapped one-shot all-reduce state (enable_oneshot_all_reduce), or None: the backend's collective
 
 
 def grid_coordinates(global_rank: int, tp_size: int, dp_size: int) -> tuple[int, int]:
@@ -76,7 +77,10 @@ def init_tensor_parallel(rank: int = 0, world_size: int = 1, master_port: int = 
 
 
 def destroy_parallel() -> None:
-    global _TP_RANK, _TP_WORLD_SIZE, _TP_GROUP, _DP_RANK, _DP_WORLD_SIZE, _OWNS_PG
+    global _TP_RANK, _TP_WORLD_SIZE, _TP_GROUP, _DP_RANK, _DP_WORLD_SIZE, _OWNS_PG, _ONESHOT
+    if _ONESHOT is not None:
+        _ONESHOT.close()
+        _ONESHOT = None
     if _TP_GROUP is not None and _OWNS_PG and dist.is_initialized():
         dist.destroy_process_group()
     _TP_RANK, _TP_WORLD_SIZE, _TP_GROUP, _DP_RANK, _DP_WORLD_SIZE, _OWNS_PG = 0, 1, None, 0, 1, False
@@ -86,6 +90,106 @@ def destroy_parallel() -> None:
 
 def collective_forced() -> bool:
     return _FORCE_COLLECTIVE
+
+
+# ------------------------------------------------------------------------------------- #
+# one-shot all-reduce over peer-mapped buffers (SURVEY 5 / 8e native target; csrc/tp_allreduce.hip)
+# ------------------------------------------------------------------------------------- #
+class _OneShot:
+    """This rank's staging buffer + flag words (fine-grained device memory), the peers' mappings of theirs, and the
+    launch counter.  Built once per TP group; every later all-reduce of a fitting 16-bit tensor is ONE kernel launch with
+    no host work (capturable in the decode graph)."""
+
+    def __init__(self, max_elems: int, blocks: int):
+        import ctypes
+
+        from .. import _lib as L
+
+        lib = L.lib()
+        self.lib, self.L = lib, L
+        self.world, self.rank = _TP_WORLD_SIZE, _TP_RANK
+        self.stage_elems = (max_elems + 7) // 8 * 8
+        self.blocks = blocks
+        self.flag_words = int(lib.ll_tp_oneshot_flag_words(blocks, self.world))
+        self._mine = []
+        for nbytes in (2 * self.stage_elems * 2, self.flag_words * 4):
+            ptr = ctypes.c_void_p()
+            L.check(lib.ll_tp_shared_alloc(ctypes.byref(ptr), nbytes), "tp_shared_alloc")
+            self._mine.append(ptr)
+        handles = []
+        for ptr in self._mine:
+            buf = ctypes.create_string_buffer(64)
+            L.check(lib.ll_tp_ipc_export(ptr, buf), "tp_ipc_export")
+            handles.append(buf.raw)
+        gathered = [None] * self.world
+        dist.all_gather_object(gathered, (self.rank, handles), group=_TP_GROUP)
+        self._opened = []
+        stage, flags = [None] * self.world, [None] * self.world
+        for r, hs in gathered:
+            if r == self.rank:
+                stage[r], flags[r] = self._mine[0].value, self._mine[1].value
+                continue
+            ptrs = []
+            for h in hs:
+                out = ctypes.c_void_p()
+                L.check(lib.ll_tp_ipc_open(ctypes.create_string_buffer(h, 64), ctypes.byref(out)), "tp_ipc_open")
+                ptrs.append(out)
+            self._opened.extend(ptrs)
+            stage[r], flags[r] = ptrs[0].value, ptrs[1].value
+        self.stage_arr = (ctypes.c_void_p * self.world)(*stage)
+        self.flag_arr = (ctypes.c_void_p * self.world)(*flags)
+        self.epoch_done = torch.zeros(2, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+        self._err_view = None
+        dist.barrier(group=_TP_GROUP)  # nobody launches before everybody has mapped everybody
+
+    def fits(self, t: torch.Tensor) -> bool:
+        return (t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and t.is_contiguous() and t.numel() % 8 == 0
+                and 0 < t.numel() <= self.stage_elems and t.data_ptr() % 16 == 0)
+
+    def all_reduce(self, t: torch.Tensor) -> None:
+        import ctypes
+
+        L = self.L
+        L.check(self.lib.ll_tp_allreduce_oneshot(
+            t.data_ptr(), t.numel(), L.dtype_code(t.dtype), ctypes.cast(self.stage_arr, ctypes.c_void_p),
+            ctypes.cast(self.flag_arr, ctypes.c_void_p), self.rank, self.world, self.stage_elems, self.blocks,
+            self.epoch_done.data_ptr(), L.stream_ptr()), "tp_allreduce_oneshot")
+
+    def error(self) -> int:
+        """The device error word (synchronises): bit 0 = a peer's flag did not arrive within the spin bound."""
+        import ctypes
+
+        torch.cuda.synchronize()
+        word = ctypes.c_int32()
+        src = ctypes.c_void_p(self._mine[1].value + 4 * (self.flag_words - 1))
+        rt = ctypes.CDLL("libamdhip64.so")
+        rt.hipMemcpy(ctypes.byref(word), src, 4, 2)  # hipMemcpyDeviceToHost
+        return int(word.value)
+
+    def close(self) -> None:
+        for p in self._opened:
+            self.lib.ll_tp_ipc_close(p)
+        for p in self._mine:
+            self.lib.ll_tp_shared_free(p)
+        self._opened, self._mine = [], []
+
+
+def enable_oneshot_all_reduce(max_elems: int, blocks: int = 64) -> None:
+    """Route ``all_reduce_tp`` of 16-bit tensors of up to ``max_elems`` elements through the one-shot peer-to-peer kernel
+    (opt-in; every rank of the TP group must call this, with the same arguments, after ``init_parallel``).  Larger /
+    other tensors keep the backend's collective."""
+    global _ONESHOT
+    if _TP_WORLD_SIZE <= 1 or _TP_GROUP is None:
+        raise RuntimeError("enable_oneshot_all_reduce needs an initialised tensor-parallel group of more than one rank")
+    if _TP_WORLD_SIZE > 8:
+        raise ValueError("the one-shot all-reduce serves up to 8 ranks (one xGMI hop)")
+    if _ONESHOT is not None:
+        _ONESHOT.close()
+    _ONESHOT = _OneShot(max_elems, blocks)
+
+
+def oneshot_error() -> int:
+    return 0 if _ONESHOT is None else _ONESHOT.error()
 
 
 destroy_tensor_parallel = destroy_parallel
@@ -120,6 +224,9 @@ def divide(a: int, b: int, what: str = "") -> int:
 def all_reduce_tp(tensor: torch.Tensor) -> torch.Tensor:
     """In-place SUM over the TP group; identity when ``world_size == 1``."""
     if _TP_WORLD_SIZE <= 1 and not _FORCE_COLLECTIVE:
+        return tensor
+    if _ONESHOT is not None and _ONESHOT.fits(tensor):
+        _ONESHOT.all_reduce(tensor)
         return tensor
     dist.all_reduce(tensor, op=dist.ReduceOp.SUM, group=_TP_GROUP)
     return tensor

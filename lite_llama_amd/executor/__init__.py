@@ -294,8 +294,19 @@ class DecodeEngine:
             torch.cuda.current_stream().wait_stream(s)
             self._restore(snap)
             graph = torch.cuda.CUDAGraph()
-            with torch.cuda.graph(graph):
-                self._step_body()
+            try:
+                with torch.cuda.graph(graph):
+                    self._step_body()
+            except Exception:
+                # a refused capture (e.g. a collective the backend cannot record) must not leave the stream in capture
+                # mode: the caller falls back to eager launches on this very stream
+                try:
+                    if torch.cuda.is_current_stream_capturing():
+                        graph.capture_end()
+                except Exception:
+                    pass
+                self._restore(snap)
+                raise
             self._restore(snap)  # capture does not execute, but keep the state explicit
             self._graph = graph
             for i in range(max_new_tokens):

@@ -1,0 +1,144 @@
+"""One-shot peer-to-peer all-reduce (SURVEY 5 / 8e native target; a13): two ranks SHARE the box's one GPU -- each maps
+the other's staging buffer and flag words through hipIpcMemHandle, exactly the plumbing of the multi-GPU case -- and run
+the kernel concurrently: results must equal the fp32 sum of the two inputs rounded once (bit-identical on both ranks),
+repeatedly (staging halves and flag epochs alternate), for odd sizes of the slices, inside a captured graph, and the
+tensor-parallel decode must generate the tokens it generates over the backend's collective."""
+
+import os
+import socket
+
+import pytest
+import torch
+import torch.multiprocessing as mp
+
+pytestmark = pytest.mark.gpu
+
+
+def _free_port():
+    s = socket.socket()
+    s.bind(("127.0.0.1", 0))
+    port = s.getsockname()[1]
+    s.close()
+    return port
+
+
+def _worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LL_DIST_BACKEND"] = "gloo"   # host channel for the handle exchange (RCCL refuses two ranks on one device)
+    import torch.distributed as dist
+
+    from lite_llama_amd.distributed import parallel_state as ps
+
+    try:
+        torch.cuda.set_device(0)
+        ps.init_tensor_parallel(rank, world, master_port=port)
+        ps.enable_oneshot_all_reduce(64 * 3584, blocks=32)
+        dev = torch.device("cuda", 0)
+        report = {}
+        for dtype in (torch.float16, torch.bfloat16):
+            for it, n in enumerate([64 * 3584, 8, 1000 * 8, 64 * 3584, 33 * 1024 + 8, 64 * 3584]):
+                g = torch.Generator(device=dev).manual_seed(100 * rank + it)
+                x = (torch.randn(n, device=dev, generator=g) * 0.5).to(dtype)
+                mine = x.clone()
+                parts = [torch.empty_like(x).cpu() for _ in range(world)]
+                dist.all_gather(parts, mine.cpu())                       # host copy of every rank's input (gloo)
+                want = torch.stack([p.float() for p in parts]).sum(0).to(dtype)   # rank order, fp32, one rounding
+                ps.all_reduce_tp(x)
+                torch.cuda.synchronize()
+                report[(str(dtype), it)] = bool(torch.equal(x.cpu(), want))
+        # inside a captured graph: replays keep working (epochs advance on the device)
+        x = torch.zeros(64 * 3584, device=dev, dtype=torch.float16)
+        src = torch.full((64 * 3584,), float(rank + 1), device=dev, dtype=torch.float16)
+        ps.all_reduce_tp(x.copy_(src))           # warm-up outside the capture
+        torch.cuda.synchronize()
+        dist.barrier()
+        graph = torch.cuda.CUDAGraph()
+        with torch.cuda.graph(graph):
+            x.copy_(src)
+            ps.all_reduce_tp(x)
+        ok = True
+        for _ in range(5):
+            graph.replay()
+            torch.cuda.synchronize()
+            ok = ok and bool((x == float(sum(range(1, world + 1)))).all())
+        report["graph"] = ok
+        report["error_word"] = ps.oneshot_error()
+        # a tensor that does not fit keeps the backend's collective (here: gloo on a host copy is not wired for CUDA
+        # tensors, so only check the routing decision)
+        report["fits_big"] = ps._ONESHOT.fits(torch.empty(64 * 3584 + 8, device=dev, dtype=torch.float16))
+        report["fits_f32"] = ps._ONESHOT.fits(torch.empty(64, device=dev, dtype=torch.float32))
+        q.put((rank, True, report))
+    except Exception as exc:  # pragma: no cover
+        import traceback
+
+        q.put((rank, False, repr(exc) + traceback.format_exc()[-2000:]))
+    finally:
+        ps.destroy_parallel()
+
+
+def test_two_ranks_on_one_gpu_exchange_through_ipc():
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, report in results:
+        assert ok is True, (rank, report)
+        bad = [k for k, v in report.items() if k not in ("error_word", "fits_big", "fits_f32") and v is not True]
+        assert not bad, (rank, bad)
+        assert report["error_word"] == 0 and report["fits_big"] is False and report["fits_f32"] is False
+
+
+def _tp_decode_worker(rank, world, port, q, oneshot):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LL_DIST_BACKEND"] = "gloo"
+    from lite_llama_amd.distributed import parallel_state as ps
+
+    try:
+        torch.cuda.set_device(0)
+        ps.init_tensor_parallel(rank, world, master_port=port)
+        if oneshot:
+            ps.enable_oneshot_all_reduce(2 * 7 * 512)
+        from tests.test_distributed_gpu import _run
+
+        first, toks, logits = _run()
+        err = ps.oneshot_error()
+        q.put((rank, True, (first.numpy(), toks.numpy(), logits.numpy(), err)))
+    except Exception as exc:  # pragma: no cover
+        import traceback
+
+        q.put((rank, False, repr(exc) + traceback.format_exc()[-2000:]))
+    finally:
+        ps.destroy_parallel()
+
+
+def test_tp2_decode_over_the_oneshot_kernel_matches_the_backend_collective():
+    """The two-rank int4 decode of tests/test_distributed_gpu.py with its all-reduces (prefill [2 x 7, 512] and decode
+    [2, 512] payloads) on the one-shot kernel: same first tokens, logits within the fp16 rounding of the sums (the kernel adds
+    in fp32 and rounds once, gloo adds fp16 values), both ranks bit-identical."""
+    import numpy as np
+
+    outs = {}
+    for oneshot in (False, True):
+        ctx = mp.get_context("spawn")
+        q = ctx.Queue()
+        port = _free_port()
+        procs = [ctx.Process(target=_tp_decode_worker, args=(r, 2, port, q, oneshot)) for r in range(2)]
+        for p in procs:
+            p.start()
+        results = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
+        for p in procs:
+            p.join(timeout=60)
+        for rank, ok, payload in results:
+            assert ok is True, (rank, payload)
+        assert all(np.array_equal(a, b) for a, b in zip(results[0][2][:3], results[1][2][:3]))   # ranks agree bit for bit
+        assert results[0][2][3] == 0 and results[1][2][3] == 0
+        outs[oneshot] = results[0][2]
+    assert np.array_equal(outs[True][0], outs[False][0])
+    np.testing.assert_allclose(outs[True][2], outs[False][2], rtol=1e-2, atol=1e-2)
