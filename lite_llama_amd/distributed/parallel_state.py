@@ -101,6 +101,9 @@ class _OneShot:
     no host work (capturable in the decode graph)."""
 
     def __init__(self, max_elems: int, blocks: int):
+        """Every rank walks the same sequence of collectives whatever happens locally (a rank that failed to allocate or
+        to map still takes part in the exchanges and the verdict), so a partial failure ends in a common RuntimeError,
+        never in a rank waiting for a peer that left."""
         import ctypes
 
         from .. import _lib as L
@@ -111,36 +114,49 @@ class _OneShot:
         self.stage_elems = (max_elems + 7) // 8 * 8
         self.blocks = blocks
         self.flag_words = int(lib.ll_tp_oneshot_flag_words(blocks, self.world))
-        self._mine = []
-        for nbytes in (2 * self.stage_elems * 2, self.flag_words * 4):
-            ptr = ctypes.c_void_p()
-            L.check(lib.ll_tp_shared_alloc(ctypes.byref(ptr), nbytes), "tp_shared_alloc")
-            self._mine.append(ptr)
+        self._mine, self._opened = [], []
+        problem = None
         handles = []
-        for ptr in self._mine:
-            buf = ctypes.create_string_buffer(64)
-            L.check(lib.ll_tp_ipc_export(ptr, buf), "tp_ipc_export")
-            handles.append(buf.raw)
+        try:
+            for nbytes in (2 * self.stage_elems * 2, self.flag_words * 4):
+                ptr = ctypes.c_void_p()
+                L.check(lib.ll_tp_shared_alloc(ctypes.byref(ptr), nbytes), "tp_shared_alloc")
+                self._mine.append(ptr)
+            for ptr in self._mine:
+                buf = ctypes.create_string_buffer(64)
+                L.check(lib.ll_tp_ipc_export(ptr, buf), "tp_ipc_export")
+                handles.append(buf.raw)
+        except Exception as exc:
+            problem = f"rank {self.rank}: {type(exc).__name__}: {exc}"
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, (self.rank, handles), group=_TP_GROUP)
-        self._opened = []
+        dist.all_gather_object(gathered, (self.rank, handles if problem is None else None, problem), group=_TP_GROUP)
+        failures = [g[2] for g in gathered if g[2]]
         stage, flags = [None] * self.world, [None] * self.world
-        for r, hs in gathered:
-            if r == self.rank:
-                stage[r], flags[r] = self._mine[0].value, self._mine[1].value
-                continue
-            ptrs = []
-            for h in hs:
-                out = ctypes.c_void_p()
-                L.check(lib.ll_tp_ipc_open(ctypes.create_string_buffer(h, 64), ctypes.byref(out)), "tp_ipc_open")
-                ptrs.append(out)
-            self._opened.extend(ptrs)
-            stage[r], flags[r] = ptrs[0].value, ptrs[1].value
+        if not failures:
+            try:
+                for r, hs, _ in gathered:
+                    if r == self.rank:
+                        stage[r], flags[r] = self._mine[0].value, self._mine[1].value
+                        continue
+                    ptrs = []
+                    for h in hs:
+                        out = ctypes.c_void_p()
+                        L.check(lib.ll_tp_ipc_open(ctypes.create_string_buffer(h, 64), ctypes.byref(out)), "tp_ipc_open")
+                        ptrs.append(out)
+                        self._opened.append(out)
+                    stage[r], flags[r] = ptrs[0].value, ptrs[1].value
+            except Exception as exc:
+                problem = f"rank {self.rank}: {type(exc).__name__}: {exc}"
+        # the verdict doubles as the barrier: nobody launches before everybody has mapped everybody
+        verdicts = [None] * self.world
+        dist.all_gather_object(verdicts, problem, group=_TP_GROUP)
+        failures += [v for v in verdicts if v]
+        if failures:
+            self.close()
+            raise RuntimeError("one-shot all-reduce set-up failed: " + "; ".join(sorted(set(failures))))
         self.stage_arr = (ctypes.c_void_p * self.world)(*stage)
         self.flag_arr = (ctypes.c_void_p * self.world)(*flags)
         self.epoch_done = torch.zeros(2, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
-        self._err_view = None
-        dist.barrier(group=_TP_GROUP)  # nobody launches before everybody has mapped everybody
 
     def fits(self, t: torch.Tensor) -> bool:
         return (t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and t.is_contiguous() and t.numel() % 8 == 0

@@ -134,3 +134,18 @@ def test_decode_attention_shape_gate():
     assert not ok(q.transpose(0, 1), kv, cos, 4)                # head rows not dense
     qb, kvb = qkv(8, 2, 64, torch.bfloat16)
     assert ok(qb, kvb, cos.bfloat16(), 2) and not ok(qb, kvb, cos, 2)
+
+
+def test_oneshot_all_reduce_needs_a_tensor_parallel_group():
+    """The opt-in peer-to-peer all-reduce is a property of an initialised TP group of 2..8 ranks; without one the
+    request is refused and ``all_reduce_tp`` stays the identity / the backend's collective."""
+    import pytest
+    import torch
+
+    from lite_llama_amd.distributed import parallel_state as ps
+
+    with pytest.raises(RuntimeError, match="tensor-parallel group"):
+        ps.enable_oneshot_all_reduce(64)
+    assert ps.oneshot_error() == 0
+    x = torch.ones(8)
+    assert ps.all_reduce_tp(x) is x
