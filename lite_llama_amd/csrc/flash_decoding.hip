@@ -725,10 +725,10 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
   rp.v_scale = v_scale;
   const bool grouped_ok = fuse && nparts >= 2 && nparts <= FD_GROUP_MAX;
   // split-K partial inputs need the grouped form and two float4 slots per lane: (groups + 2) * d / 4 <= 2 * 64 * nparts
-  if (rope && rp.qp && (!grouped_ok || rp.qs < 1 || rp.qs > FD_QS_MAX || (groups + 2) * d / 4 > 128 * nparts || getenv("LL_FD_UNGROUPED") != nullptr))
+  static const bool ungrouped_env = getenv("LL_FD_UNGROUPED") != nullptr;  // A/B knob, read once
+  if (rope && rp.qp && (!grouped_ok || rp.qs < 1 || rp.qs > FD_QS_MAX || (groups + 2) * d / 4 > 128 * nparts || ungrouped_env))
     return LL_ERR_SHAPE;
   // one workgroup per (row, KV head group) with a wave per partition while the context fits FD_GROUP_MAX partitions
-  static const bool ungrouped_env = getenv("LL_FD_UNGROUPED") != nullptr;  // A/B knob, read once
   const bool grouped = grouped_ok && !ungrouped_env;
 #define LL_FD1X(DD, FU, RO, GG, GR) LL_FD1XK(DD, FU, RO, GG, GR, false)
 #define LL_FD1XK(DD, FU, RO, GG, GR, K8)                                                             \

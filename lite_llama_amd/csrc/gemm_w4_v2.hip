@@ -765,7 +765,8 @@ extern "C" int ll_w4a16_pack_scales(void* packed, const float* scales, const flo
 
 // exported for gemm_wq.hip's dispatcher
 extern "C" int ll_w4a16_v2_supported(int64_t m, int64_t n, int64_t k, int group_size) {
-  if (getenv("LL_GEMM_V1")) return 0;
+  static const bool v1_forced = getenv("LL_GEMM_V1") != nullptr;  // debug knob, read once
+  if (v1_forced) return 0;
   const int gdiv = group_size / 128;
   return v2_shape_ok(m, n, k) && (group_size % 128 == 0) && ((gdiv & (gdiv - 1)) == 0);
 }
