@@ -9,6 +9,8 @@
 // Grouped GEMM on MFMA 32x32x16: expert weights (fp16, or fp8-e4m3 / int8 with one scale per
 // group_n x group_k block) are the streamed "A" operand in fragment layout exactly as in
 // gemm_wq.hip; the gathered activation rows of one row block are staged through LDS.
+#include <stdlib.h>
+
 #include "common.h"
 
 struct alignas(16) Q4 {
@@ -44,16 +46,35 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const void* __restrict_
     atomicAdd(&counts[e], 1);
   }
   __syncthreads();
-  if (tid == 0) {
-    int pos = 0, blk = 0;
-    for (int e = 0; e < num_experts; ++e) {
-      const int padded = (counts[e] + block_size - 1) / block_size * block_size;
-      starts[e] = pos;
-      pos += padded;
-      blk += padded / block_size;
-      bends[e] = blk;
+  // padded prefix over the experts: a workgroup scan per 1024 experts (thread e owns expert base + e), the running total
+  // carried between rounds -- not one thread walking all experts (that walk was 9 of the kernel's 28 us at E = 128)
+  {
+    __shared__ int wave_tot[16], carry_s;
+    if (tid == 0) carry_s = 0;
+    __syncthreads();
+    for (int base = 0; base < num_experts; base += 1024) {
+      const int e = base + tid;
+      const int padded = e < num_experts ? (counts[e] + block_size - 1) / block_size * block_size : 0;
+      int x = padded;
+      const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+      for (int off = 1; off < 64; off <<= 1) {
+        const int y = __shfl_up(x, off, 64);
+        if (lane >= off) x += y;
+      }
+      if (lane == 63) wave_tot[wave] = x;
+      __syncthreads();
+      int before = carry_s;
+      for (int w = 0; w < wave; ++w) before += wave_tot[w];
+      if (e < num_experts) {
+        starts[e] = before + x - padded;
+        bends[e] = (before + x) / block_size;
+      }
+      __syncthreads();
+      if (tid == 1023) carry_s = before + x;
+      __syncthreads();
     }
-    num_post[0] = pos;
+    if (tid == 0) num_post[0] = carry_s;
   }
   __syncthreads();
   // stable placement (token order kept inside each expert)
@@ -61,10 +82,18 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const void* __restrict_
     // decode-sized batches: the ids sit in LDS and every SLOT finds its rank among the earlier slots of
     // the same expert (all lanes read the same word per step: an LDS broadcast) -- num_slots short
     // iterations instead of one thread per expert walking global memory (57 us -> a few us at 512 slots)
+    // (eight independent LDS reads per round: a one-read-per-iteration loop pays the LDS latency 511 times for the last
+    // slot -- 15 of the kernel's 19 us; reads past slot i are masked, the staging area is padded to a multiple of 8)
     for (int i = tid; i < num_slots; i += 1024) {
       const int e = ids_lds[i];
       int rank = 0;
-      for (int j = 0; j < i; ++j) rank += ids_lds[j] == e;
+      for (int j0 = 0; j0 < i; j0 += 8) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ids_lds[j0 + u];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) rank += (j0 + u < i) & (v[u] == e);
+      }
       sorted_ids[starts[e] + rank] = i;
     }
   } else {
@@ -95,7 +124,7 @@ extern "C" int ll_moe_align_block_size(const void* topk_ids, int ids_width, int6
   const int max_padded = (int)num_slots + num_experts * (block_size - 1);
   const int max_blocks = (max_padded + block_size - 1) / block_size;
   const int stage_ids = num_slots <= 4096 ? 1 : 0;  // the rank scan is quadratic: decode-sized batches only
-  moe_align_kernel<<<1, 1024, (3 * num_experts + (stage_ids ? (int)num_slots : 0)) * sizeof(int), (hipStream_t)stream>>>(
+  moe_align_kernel<<<1, 1024, (3 * num_experts + (stage_ids ? (int)num_slots + 8 : 0)) * sizeof(int), (hipStream_t)stream>>>(
       topk_ids, ids_width, (int)num_slots, num_experts, block_size, sorted_ids, expert_ids, num_post, max_padded,
       max_blocks, stage_ids);
   return LL_LAUNCH_CHECK();
@@ -241,6 +270,134 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(const MoeParams p) {
   }
 }
 
+// Second form (K % 128 == 0, 16-byte aligned weight rows): the 128 x 128 weight tile of a chunk is fetched with FULL-LINE
+// loads -- 8 lanes cover one row's 128 (256) contiguous bytes, the next chunk's loads are in flight under the current
+// chunk's MFMAs -- and handed to the MFMA layout through LDS, instead of every lane picking 8-byte pieces out of its own
+// row at a 2-KB stride (64 cache lines per load instruction, 2.3 TB/s on the Qwen3-30B-A3B expert stack).  The expert
+// stack is read exactly once per step whatever the routing, so this is the kernel's whole cost.  Same arithmetic, same
+// epilogue as the form above.
+template <int WFMT, int MT>
+__global__ __launch_bounds__(256) void moe_gemm_kernel2(const MoeParams p) {
+  constexpr int EB = (WFMT == LL_W_F16) ? 2 : 1;        // bytes per weight element
+  constexpr int A_ROW_BYTES = 256 + 16;
+  constexpr int W_ROW_BYTES = 128 * EB + 16;
+  constexpr int WP = 8 * EB;                             // 16-byte pieces per weight row and chunk
+  constexpr int WPASS = 128 * WP / 256;                  // 4 (8-bit) or 8 (fp16) pieces per thread
+  constexpr int APASS = MT * 32 * 16 / 256;              // activation pieces per thread
+  __shared__ __attribute__((aligned(16))) unsigned char lds_a[MT * 32 * A_ROW_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_w[128 * W_ROW_BYTES];
+  __shared__ int32_t row_slot[MT * 32];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nl = lane & 31, h = lane >> 5;
+  const int pid_m = blockIdx.y;
+  if ((int64_t)pid_m * p.block_m >= p.num_post[0]) return;
+  const int expert = p.expert_ids[pid_m];
+  if (tid < MT * 32) row_slot[tid] = tid < p.block_m ? p.sorted_ids[(int64_t)pid_m * p.block_m + tid] : (int32_t)p.num_slots;
+  __syncthreads();
+
+  const int64_t ntile = (int64_t)blockIdx.x * 128;
+  const int K = (int)p.k;
+  const unsigned char* wbase = (const unsigned char*)p.w + (int64_t)expert * p.w_stride_e * EB;
+  // loader role: piece (row, q) of the tile, pass by pass
+  const unsigned char* wsrc[WPASS];
+  int wdst[WPASS];
+#pragma unroll
+  for (int ps = 0; ps < WPASS; ++ps) {
+    const int i = ps * 256 + tid, row = i / WP, q = i % WP;
+    int64_t nrow = ntile + row;
+    if (nrow >= p.n) nrow = p.n - 1;                     // rows past N feed outputs that are never stored
+    wsrc[ps] = wbase + nrow * p.w_stride_n * EB + q * 16;
+    wdst[ps] = row * W_ROW_BYTES + q * 16;
+  }
+  const uint16_t* asrc[APASS];
+  int adst[APASS];
+  bool aok[APASS];
+#pragma unroll
+  for (int ps = 0; ps < APASS; ++ps) {
+    const int i = ps * 256 + tid, row = i >> 4, q = i & 15;
+    const int32_t slot = row_slot[row];
+    aok[ps] = slot < p.num_slots;
+    asrc[ps] = p.a + (int64_t)(aok[ps] ? slot / p.top_k : 0) * p.a_stride + q * 8;
+    adst[ps] = row * A_ROW_BYTES + q * 16;
+  }
+  // consumer role: weight row n0 + nl of wave wv's 32-row group
+  int64_t crow = ntile + wv * 32 + nl;
+  if (crow >= p.n) crow = p.n - 1;
+  const float* srow = p.w_scale ? p.w_scale + (int64_t)expert * p.s_stride_e + (crow / p.group_n) * p.s_stride_n : nullptr;
+  const unsigned char* wfrag_base = lds_w + (wv * 32 + nl) * W_ROW_BYTES + h * (64 * EB);
+  const unsigned char* afrag_base = lds_a + nl * A_ROW_BYTES + h * 128;
+
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) acc[mt][r] = 0.f;
+
+  i32x4 wreg[WPASS], areg[APASS];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int ps = 0; ps < WPASS; ++ps) wreg[ps] = *reinterpret_cast<const i32x4*>(wsrc[ps] + (int64_t)c * (128 * EB));
+#pragma unroll
+    for (int ps = 0; ps < APASS; ++ps)  // rows without a token all re-read ONE piece (no traffic): their LDS rows are zeroed
+      areg[ps] = *reinterpret_cast<const i32x4*>(aok[ps] ? asrc[ps] + c * 128 : p.a);
+  };
+  const int chunks = K / 128;
+  fetch(0);
+  for (int c = 0; c < chunks; ++c) {
+    __syncthreads();  // the previous chunk's fragment reads are done
+#pragma unroll
+    for (int ps = 0; ps < WPASS; ++ps) *reinterpret_cast<i32x4*>(lds_w + wdst[ps]) = wreg[ps];
+#pragma unroll
+    for (int ps = 0; ps < APASS; ++ps) *reinterpret_cast<i32x4*>(lds_a + adst[ps]) = aok[ps] ? areg[ps] : i32x4{0, 0, 0, 0};
+    __syncthreads();
+    fetch(c + 1 < chunks ? c + 1 : c);  // in flight under this chunk's arithmetic (unconditional: no branch around loads)
+    const int kbase = c * 128 + h * 64;
+    uint32_t sp = 0;
+    if constexpr (WFMT != LL_W_F16) {
+      const float sv = srow[(int64_t)(kbase / p.group_k) * p.s_stride_k];
+      sp = mpk_bcast(WFMT == LL_W_FP8E4M3 ? sv * 256.0f : sv);
+    }
+#pragma unroll
+    for (int s = 0; s < 8; ++s) {
+      Q4 wf;
+      if constexpr (WFMT == LL_W_F16) {
+        wf = *reinterpret_cast<const Q4*>(wfrag_base + s * 16);
+      } else {
+        const uint2 raw = *reinterpret_cast<const uint2*>(wfrag_base + s * 8);
+        if constexpr (WFMT == LL_W_FP8E4M3) {
+          mdq_fp8(raw.x, sp, wf.x, wf.y);
+          mdq_fp8(raw.y, sp, wf.z, wf.w);
+        } else {
+          mdq_i8(raw.x, sp, wf.x, wf.y);
+          mdq_i8(raw.y, sp, wf.z, wf.w);
+        }
+      }
+      const f16x8 wfrag = __builtin_bit_cast(f16x8, wf);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) {
+        const f16x8 afrag = *reinterpret_cast<const f16x8*>(afrag_base + mt * 32 * A_ROW_BYTES + s * 16);
+        acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, afrag, acc[mt], 0, 0, 0);
+      }
+    }
+  }
+
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 32 + nl;
+    const int32_t slot = row_slot[m];
+    if (m >= p.block_m || slot >= p.num_slots) continue;
+    float rw = 1.f;
+    if (p.mul_w) rw = f16_bits_to_f32(p.topk_w[slot]);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t nn = ntile + wv * 32 + 8 * g + 4 * h;
+#pragma unroll
+      for (int e = 0; e < 4; ++e)
+        if (nn + e < p.n) p.c[(int64_t)slot * p.n + nn + e] = f32_to_f16_bits(acc[mt][4 * g + e] * rw);
+    }
+  }
+}
+
 extern "C" int ll_moe_gemm(void* c, const void* a, const void* w, const float* w_scale, const void* topk_w,
                            const int32_t* sorted_ids, const int32_t* expert_ids, const int32_t* num_post,
                            int64_t num_slots, int64_t em, int block_m, int64_t n, int64_t k, int top_k,
@@ -263,8 +420,15 @@ extern "C" int ll_moe_gemm(void* c, const void* a, const void* w, const float* w
   p.s_stride_e = s_stride_e; p.s_stride_n = s_stride_n; p.s_stride_k = s_stride_k;
   dim3 grid((unsigned)((n + 127) / 128), (unsigned)((em + block_m - 1) / block_m));
   hipStream_t st = (hipStream_t)stream;
-#define LL_MOE(WF)                                                    \
-  if (block_m == 64) moe_gemm_kernel<WF, 2><<<grid, 256, 0, st>>>(p); \
+  static const bool v1_forced = getenv("LL_MOE_V1") != nullptr;  // A/B knob, read once
+  const bool lines = !v1_forced && k % 128 == 0 && (w_stride_n * (wfmt == LL_W_F16 ? 2 : 1)) % 16 == 0 &&
+                     (w_stride_e * (wfmt == LL_W_F16 ? 2 : 1)) % 16 == 0 && ll_aligned16(w) && ll_aligned16(a) &&
+                     (wfmt == LL_W_F16 || group_k % 64 == 0);
+#define LL_MOE(WF)                                                                  \
+  if (lines) {                                                                      \
+    if (block_m == 64) moe_gemm_kernel2<WF, 2><<<grid, 256, 0, st>>>(p);            \
+    else moe_gemm_kernel2<WF, 1><<<grid, 256, 0, st>>>(p);                          \
+  } else if (block_m == 64) moe_gemm_kernel<WF, 2><<<grid, 256, 0, st>>>(p);        \
   else moe_gemm_kernel<WF, 1><<<grid, 256, 0, st>>>(p)
   if (wfmt == LL_W_F16) { LL_MOE(LL_W_F16); }
   else if (wfmt == LL_W_FP8E4M3) { LL_MOE(LL_W_FP8E4M3); }
