@@ -24,7 +24,7 @@
 namespace {
 
 constexpr int kMaxWorld = 8;
-constexpr int kSpinLimit = 1 << 20;  // ~1 s of polling: far beyond any skew between ranks inside a step
+constexpr int kSpinLimit = 1 << 23;  // ~10 s of polling: ranks may reach their FIRST collective seconds apart (model build)
 
 struct PeerTable {
   const uint16_t* stage[kMaxWorld];

@@ -105,8 +105,11 @@ def _tp_decode_worker(rank, world, port, q, oneshot):
         ps.init_tensor_parallel(rank, world, master_port=port)
         if oneshot:
             ps.enable_oneshot_all_reduce(2 * 7 * 512)
+        import torch.distributed as dist
+
         from tests.test_distributed_gpu import _run
 
+        dist.barrier()  # start the decode together (the kernel's own patience is ~10 s)
         first, toks, logits = _run()
         err = ps.oneshot_error()
         q.put((rank, True, (first.numpy(), toks.numpy(), logits.numpy(), err)))
