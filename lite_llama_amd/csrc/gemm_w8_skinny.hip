@@ -1,0 +1,286 @@
+// Decode-shaped (M <= 64) GEMMs over 8-bit weights -- a9 w8a16_matmul (lite_llama/kernels/quantization/w8a16.py:28-207: fp8
+// e4m3 / int8 weights, one fp32 scale per group_n x group_k block, fp16 activations) and a10 smoothquant_matmul
+// (w8a8.py:28-217: per-token int8 activations x per-channel int8 weights, exact int32 accumulation) -- as a split-K
+// weight-streaming kernel in the form of moe.hip::moe_gemm_kernel2: the 128 x 128 weight tile of a chunk is fetched with
+// FULL-LINE loads (8 lanes per 128-byte row, the next chunk's loads in flight under the current chunk's MFMAs) and handed
+// to the MFMA layout through LDS.  The generic engine (gemm_wq.hip::wgemm_kernel) lets every lane pick 16-byte pieces
+// out of its own weight row at a K-byte stride and reaches 1.4 TB/s on the Llama-3-8B W8A8 shapes; it keeps every shape
+// this kernel does not take (M > 64, K % 128 != 0, odd scale groups).
+//
+// grid = (N / 128 tiles, S splits): a workgroup owns chunks [y * cps, (y + 1) * cps) of its tile and leaves an fp32 (int32
+// for a10) partial [S][M][N]; dense8_finish adds the S partials in split order and applies the epilogue (a9: + bias;
+// a10: * a_scale[m] * w_scale[n] + bias, optionally the raw int32 sums) -- integer sums are exact in any order, the
+// fp32 sums are rounded once per split and once at the end.
+#include <stdlib.h>
+
+#include "common.h"
+
+namespace {
+
+struct alignas(16) Q4 {
+  uint32_t x, y, z, w;
+};
+
+constexpr int D8_FP8 = 1, D8_I8 = 2, D8_I8I8 = 3;
+
+__device__ __forceinline__ uint32_t d8_mul(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) * __builtin_bit_cast(f16x2, b));
+}
+__device__ __forceinline__ uint32_t d8_add(uint32_t a, uint32_t b) {
+  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) + __builtin_bit_cast(f16x2, b));
+}
+__device__ __forceinline__ uint32_t d8_bcast(float v) {
+  const uint32_t h = f32_to_f16_bits(v);
+  return h | (h << 16);
+}
+// 4 int8 -> 2 x (2 fp16) * s: bias to unsigned, place each byte under the 1024 exponent, remove 1152 (w8a16.py:66-74 semantics)
+__device__ __forceinline__ void d8_i8(uint32_t w, uint32_t s, uint32_t& o0, uint32_t& o1) {
+  const uint32_t u = w ^ 0x80808080u;
+  o0 = d8_mul(d8_add(__builtin_amdgcn_perm(0x64646464u, u, 0x04010400u), 0xE480E480u), s);
+  o1 = d8_mul(d8_add(__builtin_amdgcn_perm(0x64646464u, u, 0x04030402u), 0xE480E480u), s);
+}
+// 4 fp8 e4m3 bytes -> 2 x (2 fp16) * (s * 256): the reference's bit surgery (w8a16.py:48-62)
+__device__ __forceinline__ void d8_fp8(uint32_t w, uint32_t s256, uint32_t& o0, uint32_t& o1) {
+  uint32_t p0 = __builtin_amdgcn_perm(0u, w, 0x010C000Cu);
+  uint32_t p1 = __builtin_amdgcn_perm(0u, w, 0x030C020Cu);
+  p0 = (p0 & 0x80008000u) | ((p0 >> 1) & 0x3F803F80u);
+  p1 = (p1 & 0x80008000u) | ((p1 >> 1) & 0x3F803F80u);
+  o0 = d8_mul(p0, s256);
+  o1 = d8_mul(p1, s256);
+}
+
+struct D8Params {
+  void* part;             // [S][M][N] fp32 (a9) or int32 (a10)
+  const void* x;          // fp16 [M, K] (a9) or int8 [M, K] (a10), row stride x_stride elements
+  const unsigned char* w; // [N, K] bytes, row stride w_stride
+  const float* scales;    // a9: [ceil(N / gn)][ceil(K / gk)] block scales (strides s_stride_n / s_stride_k)
+  int64_t m, n, k, x_stride, w_stride, s_stride_n, s_stride_k, group_k;
+  int group_n, cps, chunks;
+};
+
+template <int WFMT, int MT>
+__global__ __launch_bounds__(256) void dense8_kernel(const D8Params p) {
+  constexpr bool I8A = WFMT == D8_I8I8;
+  constexpr int AB = I8A ? 1 : 2;                       // bytes per activation element
+  constexpr int A_ROW_BYTES = 128 * AB + 16, W_ROW_BYTES = 128 + 16;
+  constexpr int AP = 8 * AB;                             // 16-byte pieces per activation row and chunk
+  constexpr int APASS = (MT * 32 * AP + 255) / 256;
+  __shared__ __attribute__((aligned(16))) unsigned char lds_a[MT * 32 * A_ROW_BYTES];
+  __shared__ __attribute__((aligned(16))) unsigned char lds_w[128 * W_ROW_BYTES];
+  const int tid = threadIdx.x, lane = tid & 63, wv = tid >> 6;
+  const int nl = lane & 31, h = lane >> 5;
+  const int64_t ntile = (int64_t)blockIdx.x * 128;
+  const int c_lo = blockIdx.y * p.cps, c_hi = c_lo + p.cps < p.chunks ? c_lo + p.cps : p.chunks;
+  if (c_lo >= c_hi) return;  // (never: the host sizes the splits so that every one has a chunk)
+
+  const unsigned char* wsrc[4];
+  int wdst[4];
+#pragma unroll
+  for (int ps = 0; ps < 4; ++ps) {
+    const int i = ps * 256 + tid, row = i >> 3, q = i & 7;
+    int64_t nrow = ntile + row;
+    if (nrow >= p.n) nrow = p.n - 1;                     // rows past N feed outputs that are never stored
+    wsrc[ps] = p.w + nrow * p.w_stride + q * 16;
+    wdst[ps] = row * W_ROW_BYTES + q * 16;
+  }
+  const unsigned char* asrc[APASS];
+  int adst[APASS];
+  bool aok[APASS];
+#pragma unroll
+  for (int ps = 0; ps < APASS; ++ps) {
+    const int i = ps * 256 + tid, row = i / AP, q = i % AP;
+    aok[ps] = i < MT * 32 * AP && row < p.m;
+    asrc[ps] = (const unsigned char*)p.x + ((int64_t)(aok[ps] ? row : 0) * p.x_stride) * AB + q * 16;
+    adst[ps] = (i < MT * 32 * AP ? row : 0) * A_ROW_BYTES + q * 16;
+  }
+  int64_t crow = ntile + wv * 32 + nl;
+  if (crow >= p.n) crow = p.n - 1;
+  const float* srow = I8A ? nullptr : p.scales + (crow / p.group_n) * p.s_stride_n;
+  const unsigned char* wfrag_base = lds_w + (wv * 32 + nl) * W_ROW_BYTES + h * 64;
+  const unsigned char* afrag_base = lds_a + nl * A_ROW_BYTES + h * (64 * AB);
+
+  f32x16 accf[MT];
+  i32x16 acci[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int r = 0; r < 16; ++r) {
+      accf[mt][r] = 0.f;
+      acci[mt][r] = 0;
+    }
+
+  i32x4 wreg[4], areg[APASS];
+  auto fetch = [&](int c) {
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) wreg[ps] = *reinterpret_cast<const i32x4*>(wsrc[ps] + (int64_t)c * 128);
+#pragma unroll
+    for (int ps = 0; ps < APASS; ++ps)  // rows without a token all re-read ONE piece: their LDS rows are zeroed
+      areg[ps] = *reinterpret_cast<const i32x4*>(aok[ps] ? asrc[ps] + (int64_t)c * (128 * AB) : (const unsigned char*)p.x);
+  };
+  fetch(c_lo);
+  for (int c = c_lo; c < c_hi; ++c) {
+    __syncthreads();  // the previous chunk's fragment reads are done
+#pragma unroll
+    for (int ps = 0; ps < 4; ++ps) *reinterpret_cast<i32x4*>(lds_w + wdst[ps]) = wreg[ps];
+#pragma unroll
+    for (int ps = 0; ps < APASS; ++ps)
+      if (ps * 256 + tid < MT * 32 * AP) *reinterpret_cast<i32x4*>(lds_a + adst[ps]) = aok[ps] ? areg[ps] : i32x4{0, 0, 0, 0};
+    __syncthreads();
+    fetch(c + 1 < c_hi ? c + 1 : c);  // in flight under this chunk's arithmetic (unconditional: no branch around loads)
+    if constexpr (I8A) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+        const i32x4 wfrag = *reinterpret_cast<const i32x4*>(wfrag_base + s * 16);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const i32x4 afrag = *reinterpret_cast<const i32x4*>(afrag_base + mt * 32 * A_ROW_BYTES + s * 16);
+          acci[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(wfrag, afrag, acci[mt], 0, 0, 0);
+        }
+      }
+    } else {
+      const int kbase = c * 128 + h * 64;
+      const float sv = srow[(int64_t)(kbase / p.group_k) * p.s_stride_k];
+      const uint32_t sp = d8_bcast(WFMT == D8_FP8 ? sv * 256.0f : sv);
+#pragma unroll
+      for (int s = 0; s < 8; ++s) {
+        const uint2 raw = *reinterpret_cast<const uint2*>(wfrag_base + s * 8);
+        Q4 wf;
+        if constexpr (WFMT == D8_FP8) {
+          d8_fp8(raw.x, sp, wf.x, wf.y);
+          d8_fp8(raw.y, sp, wf.z, wf.w);
+        } else {
+          d8_i8(raw.x, sp, wf.x, wf.y);
+          d8_i8(raw.y, sp, wf.z, wf.w);
+        }
+        const f16x8 wfrag = __builtin_bit_cast(f16x8, wf);
+#pragma unroll
+        for (int mt = 0; mt < MT; ++mt) {
+          const f16x8 afrag = *reinterpret_cast<const f16x8*>(afrag_base + mt * 32 * A_ROW_BYTES + s * 16);
+          accf[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, afrag, accf[mt], 0, 0, 0);
+        }
+      }
+    }
+  }
+
+  // partial [split][m][n]: D[n][m] -- lane = column m (nl), rows n = 8g + 4h + e
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+    const int m = mt * 32 + nl;
+    if (m >= p.m) continue;
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const int64_t nn = ntile + wv * 32 + 8 * g + 4 * h;
+      if (nn >= p.n) continue;  // N % 4 == 0 (checked on the host): a group of four is in or out as a whole
+      const int64_t off = ((int64_t)blockIdx.y * p.m + m) * p.n + nn;
+      if constexpr (I8A)
+        *reinterpret_cast<i32x4*>((int32_t*)p.part + off) =
+            i32x4{acci[mt][4 * g], acci[mt][4 * g + 1], acci[mt][4 * g + 2], acci[mt][4 * g + 3]};
+      else
+        *reinterpret_cast<f32x4*>((float*)p.part + off) =
+            f32x4{accf[mt][4 * g], accf[mt][4 * g + 1], accf[mt][4 * g + 2], accf[mt][4 * g + 3]};
+    }
+  }
+}
+
+// out[m][n] = epilogue(sum_s part[s][m][n]); one thread per 4 outputs
+template <bool I8A>
+__global__ __launch_bounds__(256) void dense8_finish(uint16_t* __restrict__ out, const void* __restrict__ part, int splits,
+                                                     int64_t m, int64_t n, const uint16_t* __restrict__ bias,
+                                                     const float* __restrict__ a_scale, const float* __restrict__ w_scale,
+                                                     int32_t* __restrict__ acc_out) {
+  const int64_t i = ((int64_t)blockIdx.x * 256 + threadIdx.x) * 4;
+  if (i >= m * n) return;
+  const int64_t row = i / n, col = i - row * n;
+  float v[4];
+  // eight partial planes per round, requested together (a one-load-per-iteration loop pays the memory latency S times);
+  // the sums are still formed in split order
+  if constexpr (I8A) {
+    i32x4 a = {0, 0, 0, 0};
+    for (int s0 = 0; s0 < splits; s0 += 8) {
+      i32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        t[u] = *reinterpret_cast<const i32x4*>((const int32_t*)part + (int64_t)(s0 + u < splits ? s0 + u : s0) * m * n + i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < splits) a += t[u];
+    }
+    if (acc_out) *reinterpret_cast<i32x4*>(acc_out + i) = a;
+    const float as = a_scale[row];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = ((float)a[e] * as) * w_scale[col + e];  // (acc.f32 * a_scale[m]) * w_scale[n], w8a8.py:118-120
+  } else {
+    f32x4 a = {0.f, 0.f, 0.f, 0.f};
+    for (int s0 = 0; s0 < splits; s0 += 8) {
+      f32x4 t[8];
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        t[u] = *reinterpret_cast<const f32x4*>((const float*)part + (int64_t)(s0 + u < splits ? s0 + u : s0) * m * n + i);
+#pragma unroll
+      for (int u = 0; u < 8; ++u)
+        if (s0 + u < splits) a += t[u];
+    }
+#pragma unroll
+    for (int e = 0; e < 4; ++e) v[e] = a[e];
+  }
+  uint16_t o[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) o[e] = f32_to_f16_bits(bias ? v[e] + f16_bits_to_f32(bias[col + e]) : v[e]);
+  *reinterpret_cast<uint2*>(out + i) = uint2{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
+}
+
+int d8_splits(int64_t n, int64_t k) {
+  const int tiles = (int)((n + 127) / 128), chunks = (int)(k / 128);
+  int s = (768 + tiles - 1) / tiles;   // ~3 resident workgroups per CU ...
+  if (s > chunks / 2) s = chunks / 2;  // ... of at least two chunks each (the tile prefetch needs something to hide behind)
+  if (s < 1) s = 1;
+  return s;
+}
+
+}  // namespace
+
+// shapes the skinny engine takes (the dispatchers of gemm_wq.hip ask; also sizes the partial planes in ll_gemm_workspace)
+extern "C" int64_t ll_dense8_partial_words(int64_t m, int64_t n, int64_t k) {
+  if (m < 1 || m > 64 || n < 4 || n % 4 != 0 || k < 128 || k % 128 != 0) return 0;
+  return (int64_t)d8_splits(n, k) * m * n;
+}
+
+// wfmt: 1 fp8 e4m3 / 2 int8 (fp16 activations, block scales) / 3 int8 x int8 (per-token / per-channel scales).
+// Returns 1 when the launch was issued, 0 when the shape is not served (nothing happened), < 0 on a launch error.
+extern "C" int ll_dense8_try(void* out, const void* x, const void* w, const float* scales, const float* a_scale,
+                             const void* bias, int32_t* acc_out, int64_t m, int64_t n, int64_t k, int group_n,
+                             int64_t group_k, int wfmt, int64_t x_stride, int64_t w_stride, int64_t s_stride_n,
+                             int64_t s_stride_k, void* partials, void* stream) {
+  static const bool off = getenv("LL_DENSE8_OFF") != nullptr;  // A/B knob, read once
+  if (off || !partials || ll_dense8_partial_words(m, n, k) == 0) return 0;
+  if (w_stride % 16 != 0 || !ll_aligned16(w) || !ll_aligned16(x) || !ll_aligned16(out) || !ll_aligned16(partials)) return 0;
+  if (wfmt == D8_I8I8 ? (x_stride % 16 != 0) : (x_stride % 8 != 0 || (group_k < k && group_k % 64 != 0))) return 0;
+  D8Params p{};
+  p.part = partials; p.x = x; p.w = (const unsigned char*)w; p.scales = scales;
+  p.m = m; p.n = n; p.k = k; p.x_stride = x_stride; p.w_stride = w_stride;
+  p.s_stride_n = s_stride_n; p.s_stride_k = s_stride_k; p.group_n = group_n > 0 ? group_n : 1;
+  p.group_k = group_k > 0 ? group_k : k;
+  p.chunks = (int)(k / 128);
+  const int splits = d8_splits(n, k);
+  p.cps = (p.chunks + splits - 1) / splits;
+  const int used = (p.chunks + p.cps - 1) / p.cps;  // every launched split has at least one chunk
+  dim3 grid((unsigned)((n + 127) / 128), (unsigned)used);
+  hipStream_t st = (hipStream_t)stream;
+#define LL_D8(WF)                                                        \
+  if (m > 32) dense8_kernel<WF, 2><<<grid, 256, 0, st>>>(p);             \
+  else dense8_kernel<WF, 1><<<grid, 256, 0, st>>>(p)
+  if (wfmt == D8_FP8) { LL_D8(D8_FP8); }
+  else if (wfmt == D8_I8) { LL_D8(D8_I8); }
+  else if (wfmt == D8_I8I8) { LL_D8(D8_I8I8); }
+  else return 0;
+#undef LL_D8
+  const int64_t quads = m * n / 4;
+  const dim3 fgrid((unsigned)((quads + 255) / 256));
+  if (wfmt == D8_I8I8)
+    dense8_finish<true><<<fgrid, 256, 0, st>>>((uint16_t*)out, partials, used, m, n, (const uint16_t*)bias, a_scale, scales,
+                                               acc_out);
+  else
+    dense8_finish<false><<<fgrid, 256, 0, st>>>((uint16_t*)out, partials, used, m, n, (const uint16_t*)bias, nullptr,
+                                                nullptr, nullptr);
+  return hipGetLastError() == hipSuccess ? 1 : LL_ERR_LAUNCH;
+}

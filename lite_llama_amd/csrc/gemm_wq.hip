@@ -652,6 +652,13 @@ extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweig
                                   int group_size, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
                                   float* workspace, int32_t* counters, int epilogue, void* stream);
 
+// the decode-shaped 8-bit engine (gemm_w8_skinny.hip): served shapes leave S fp32 / int32 partial planes in the workspace
+extern "C" int64_t ll_dense8_partial_words(int64_t m, int64_t n, int64_t k);
+extern "C" int ll_dense8_try(void* out, const void* x, const void* w, const float* scales, const float* a_scale,
+                             const void* bias, int32_t* acc_out, int64_t m, int64_t n, int64_t k, int group_n,
+                             int64_t group_k, int wfmt, int64_t x_stride, int64_t w_stride, int64_t s_stride_n,
+                             int64_t s_stride_k, void* partials, void* stream);
+
 extern "C" int ll_gemm_workspace(int64_t m, int64_t n, int64_t k, int64_t* workspace_floats,
                                  int64_t* counter_ints) {
   const Plan pl = make_plan(m, n, k);
@@ -661,6 +668,8 @@ extern "C" int ll_gemm_workspace(int64_t m, int64_t n, int64_t k, int64_t* works
   if (f2 > f) f = f2;
   if (c2 > c) c = c2;
   ll_w4a16_v3_workspace(m, n, k, &f2, &c2);
+  const int64_t f3 = ll_dense8_partial_words(m, n, k);
+  if (f3 > f) f = f3;
   if (workspace_floats) *workspace_floats = f > f2 ? f : f2;
   if (counter_ints) *counter_ints = c > c2 ? c : c2;
   return LL_OK;
@@ -753,6 +762,12 @@ extern "C" int ll_w8a16_matmul(void* out, const void* x, const void* qweight, co
   if (k % 16 != 0 || x_stride_m % 8 != 0 || qw_stride_n % 16 != 0) return LL_ERR_SHAPE;
   if (!ll_aligned16(x) || !ll_aligned16(qweight)) return LL_ERR_ARG;
   if (m == 0) return LL_OK;
+  {  // decode shapes: full-line weight tiles, split-K partials in the workspace (gemm_w8_skinny.hip)
+    const int r = ll_dense8_try(out, x, qweight, scales, nullptr, bias, nullptr, m, n, k, group_n, group_k,
+                                wfmt == LL_W_FP8E4M3 ? 1 : 2, x_stride_m, qw_stride_n, s_stride_n, s_stride_k, workspace,
+                                stream);
+    if (r != 0) return r > 0 ? LL_OK : r;
+  }
   GemmParams p{};
   p.out = out; p.x = x; p.w = qweight; p.scales = scales; p.bias = bias;
   p.workspace = workspace; p.counters = counters;
@@ -770,6 +785,11 @@ extern "C" int ll_w8a8_matmul(void* out, const int8_t* qa, const float* a_scale,
   if (k % 16 != 0 || qw_stride_n % 16 != 0) return LL_ERR_SHAPE;
   if (!ll_aligned16(qa) || !ll_aligned16(qweight)) return LL_ERR_ARG;
   if (m == 0) return LL_OK;
+  {
+    const int r = ll_dense8_try(out, qa, qweight, w_scale, a_scale, bias, acc_out, m, n, k, 1, k, 3, k, qw_stride_n, 0, 0,
+                                workspace, stream);
+    if (r != 0) return r > 0 ? LL_OK : r;
+  }
   GemmParams p{};
   p.out = out; p.x = qa; p.w = qweight; p.scales = w_scale; p.bias = bias; p.a_scale = a_scale;
   p.acc_out = acc_out; p.workspace = (float*)workspace; p.counters = counters;
