@@ -306,6 +306,8 @@ int ll_tp_ipc_export(void* ptr, void* handle64);
 int ll_tp_ipc_open(const void* handle64, void** ptr);
 int ll_tp_ipc_close(void* ptr);
 int64_t ll_tp_oneshot_flag_words(int blocks, int world);
+/* host read-back of the error word (the last of flag_words); synchronises the device */
+int ll_tp_error_word(const void* flags, int64_t flag_words, int32_t* host_out);
 /* stage_ptrs / flag_ptrs: HOST arrays of `world` device pointers (entry r = rank r's buffers, mine included);
  * epoch_done: two int32 in this rank's memory, zero before the first launch.  Every rank issues the same call sequence
  * (same count, same blocks).  count <= stage_elems, count % 8 == 0, world <= 8. */

@@ -132,6 +132,14 @@ extern "C" int ll_tp_ipc_open(const void* handle64, void** ptr) {
 }
 extern "C" int ll_tp_ipc_close(void* ptr) { return ptr && hipIpcCloseMemHandle(ptr) != hipSuccess ? LL_ERR_LAUNCH : LL_OK; }
 
+// The error word of a flag allocation (its LAST word), read back by the host; synchronises the device.
+extern "C" int ll_tp_error_word(const void* flags, int64_t flag_words, int32_t* host_out) {
+  if (!flags || !host_out || flag_words < 1) return LL_ERR_ARG;
+  if (hipDeviceSynchronize() != hipSuccess) return LL_ERR_LAUNCH;
+  return hipMemcpy(host_out, (const int32_t*)flags + flag_words - 1, sizeof(int32_t), hipMemcpyDeviceToHost) == hipSuccess
+             ? LL_OK : LL_ERR_LAUNCH;
+}
+
 // Flag words a rank needs for `blocks` workgroups: [2][blocks][world] + the error word.
 extern "C" int64_t ll_tp_oneshot_flag_words(int blocks, int world) { return 2ll * blocks * world + 1; }
 

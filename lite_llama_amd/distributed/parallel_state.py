@@ -175,11 +175,8 @@ class _OneShot:
         """The device error word (synchronises): bit 0 = a peer's flag did not arrive within the spin bound."""
         import ctypes
 
-        torch.cuda.synchronize()
         word = ctypes.c_int32()
-        src = ctypes.c_void_p(self._mine[1].value + 4 * (self.flag_words - 1))
-        rt = ctypes.CDLL("libamdhip64.so")
-        rt.hipMemcpy(ctypes.byref(word), src, 4, 2)  # hipMemcpyDeviceToHost
+        self.L.check(self.lib.ll_tp_error_word(self._mine[1], self.flag_words, ctypes.byref(word)), "tp_error_word")
         return int(word.value)
 
     def close(self) -> None:
