@@ -1,8 +1,8 @@
 """Headline benchmark: decode throughput of Qwen2.5-7B W4A16 (group 128) at batch 64 on MI355X.
 
-    python bench.py [--gpus N --steps K --warmup W]
+    python bench.py [--gpus N --steps K --warmup W]        # N > 1: starts its own N ranks (one per GPU)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N --master-addr 127.0.0.1 \
-        --master-port P bench.py --gpus N --steps K --warmup W
+        --master-port P bench.py --gpus N --steps K --warmup W   # the same, ranks started by the caller
 
 A "step" is ONE decode step of the whole batch (one new token per sequence) through the HIP hot
 path, replayed from a hipGraph: embedding -> 28 x [skip_rmsnorm, w4a16 q/kv, rope, KV scatter,
@@ -143,21 +143,125 @@ def gemm_roofline(model, batch, quant, iters=6):
     avg_s = e0.elapsed_time(e1) * 1e-3 / (iters * nl)
     bytes_per_launch = nbytes / nl
     achieved = bytes_per_launch / avg_s
-    traffic = None
+    traffic, traffic_source = None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if os.path.exists(tpath):
+    if quant == "int4" and solo and os.path.exists(tpath):  # the stored counters are those of the int4 engine at TP = 1 only
         try:
-            traffic = json.load(open(tpath)).get("wgemm_bytes_per_launch")
+            tj = json.load(open(tpath))
+            traffic = tj.get("wgemm_bytes_per_launch")
+            traffic_source = ("stored profile value, not a live counter: " + tj.get("summary", "profiles/pmc_traffic.json")
+                              + " (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)")
         except Exception:
             traffic = None
+    kernel = {
+        "int4": "wgemm3_kernel (w4a16 dequant-GEMM over pre-packed weights, decode engine; gemm_w4_v3.hip)",
+        "int8": "dense8_kernel + dense8_finish (w8a16 int8, split-K weight streaming; gemm_w8_skinny.hip)",
+        "fp8": "dense8_kernel + dense8_finish (w8a16 fp8-e4m3, split-K weight streaming; gemm_w8_skinny.hip)",
+        "smoothquant": "quantize_activations_int8 + dense8_kernel (int8 x int8 MFMA) + dense8_finish (gemm_w8_skinny.hip)",
+    }[quant] if batch <= 64 else "wgemm_kernel (generic engine, M > 64; gemm_wq.hip)"
     return {
-        "bound": "hbm",
-        "kernel": "wgemm3_kernel (w4a16 dequant-GEMM over pre-packed weights, decode engine)" if quant == "int4" else "wgemm_kernel",
+        "bound": "hbm", "kernel": kernel,
+        "covers": "the dense linear projections (attention q|k|v / o" + ("" if getattr(model.geo, "num_experts", 0) else ", gate|up, down")
+                  + "); one launch = one projection incl. its activation quantiser / finish kernels where the format has them",
         "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-        "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic,
+        "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic, "traffic_source": traffic_source,
         "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
         "launches_timed": launches, "timed_as": how,
     }
+
+
+def moe_roofline(model, batch, iters=6):
+    """Config 5's dominant kernel is the grouped expert GEMM (moe_gemm_kernel2), not the attention projections: time the
+    routed block of every layer (moe_align + gate|up GEMM + silu_and_mul + down GEMM + moe_sum) on random routing and price
+    it against the expert bytes the batch touches (n_e(B) experts x 3 x H x I bytes per layer)."""
+    from lite_llama_amd.model import SparseMoeBlock
+
+    blocks = [m for m in model.modules() if isinstance(m, SparseMoeBlock)]
+    if not blocks:
+        return None
+    geo = model.geo
+    dev = next(model.parameters()).device
+    x = torch.randn(batch, geo.hidden_size, device=dev, dtype=torch.float16) * 0.5
+    routes = [b._route(x) for b in blocks[:1]][0]
+    for b in blocks[:2]:
+        b.quant_method.apply(b, x, routes[0].half(), routes[1])
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        for b in blocks:
+            b.quant_method.apply(b, x, routes[0].half(), routes[1])
+    e1.record()
+    torch.cuda.synchronize()
+    avg_s = e0.elapsed_time(e1) * 1e-3 / (iters * len(blocks))
+    hit = int(torch.unique(routes[1]).numel())
+    nbytes = hit * 3 * geo.hidden_size * blocks[0].moe_intermediate_size * 1.0
+    return {"bound": "hbm", "kernel": "moe_gemm_kernel2 x2 inside the routed block (moe_align + grouped gate|up GEMM + silu_and_mul + "
+                                      "grouped down GEMM + moe_sum; moe.hip), eager launches",
+            "achieved": round(nbytes / avg_s / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
+            "frac": round(nbytes / avg_s / PEAK_HBM, 4), "traffic": None, "bytes_per_block": int(nbytes),
+            "experts_hit": hit, "avg_block_us": round(avg_s * 1e6, 2), "blocks_timed": iters * len(blocks)}
+
+
+def measured_copy_bandwidth(dev, nbytes=1 << 30, iters=10):
+    """Device-to-device copy of a 1-GiB buffer (read + write bytes per second) -- the achievable HBM rate on THIS box,
+    printed next to the nominal peak the roofline divides by."""
+    a = torch.empty(nbytes // 2, dtype=torch.float16, device=dev)
+    b = torch.empty_like(a)
+    b.copy_(a)
+    torch.cuda.synchronize()
+    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    e0.record()
+    for _ in range(iters):
+        b.copy_(a)
+    e1.record()
+    torch.cuda.synchronize()
+    return 2.0 * nbytes * iters / (e0.elapsed_time(e1) * 1e-3)
+
+
+def parity_check(geo, quant_name, sample):
+    """The exact launch sequence the timed step makes for ONE decoder layer of the headline workload (fused q|k|v as
+    split-K partials -> one-launch attention -> o partials -> add-and-normalise over partials -> gate|up + swiglu -> down
+    partials -> norm -> lm_head), on the weights / K,V / tokens of the CPU oracle sample, against the oracle's logits.
+    Outside the timed region; the oracle is the checker here, never the thing measured."""
+    import types
+    from lite_llama_amd.model import CausalLM, tiny_geometry
+    from lite_llama_amd.quantization import QuantConfig
+
+    p, layers = sample["params"], sample["layers"]
+    g1 = tiny_geometry(name=geo.name + "-parity", hidden_size=geo.hidden_size, intermediate_size=geo.intermediate_size,
+                       num_layers=layers, num_heads=geo.num_heads, num_kv_heads=geo.num_kv_heads, head_dim=geo.head_dim,
+                       vocab_size=geo.vocab_size, rope_theta=geo.rope_theta, rms_norm_eps=geo.rms_norm_eps, qkv_bias=True)
+    m = CausalLM(g1)
+    m.load_state_dict(p, strict=True)
+    m = m.to("cuda")
+    if quant_name != "none":
+        m.quantize_(QuantConfig.for_runtime_scheme(quant_name))
+    info_c = sample["info"]
+    ctx = int(sample["pos"][0, 0])
+    m.rotary_emb.ensure(ctx + 8, "cuda")
+    kv = [k.clone().cuda() for k in sample["kv_before"]]
+    info = types.SimpleNamespace(kv_buffer=kv, cur_select_index=info_c.cur_select_index.cuda(),
+                                 b_req_tokens_table=info_c.b_req_tokens_table.cuda(), b_start_loc=None,
+                                 b_req_idx=info_c.b_req_idx.cuda(), b_seq_len=info_c.b_seq_len.cuda(),
+                                 max_actual_seq_len=info_c.max_actual_seq_len)
+    with torch.no_grad():
+        got = m(sample["ids"].cuda(), sample["pos"].cuda(), info).float().cpu()
+    ref = sample["logits"].float()
+    err = (got - ref).abs()
+    tol = 1e-1 if quant_name == "smoothquant" else 3e-2
+    ok = bool(torch.all(err <= tol + tol * ref.abs()))
+    rows = info_c.cur_select_index.long()
+    kv_got, kv_ref = kv[0][rows.cuda()].float().cpu(), sample["kv_after"][0][rows].float()
+    kv_err = float((kv_got - kv_ref).abs().max())
+    kv_ok = bool(torch.all((kv_got - kv_ref).abs() <= 2e-2 + 2e-2 * kv_ref.abs()))  # BASELINE.md section 4: rope / KV rows at 2e-2
+    same_tok = int((got[:, -1].argmax(-1) == ref[:, -1].argmax(-1)).sum())
+    del m
+    torch.cuda.empty_cache()
+    return {"ok": ok and kv_ok, "tolerance": f"|got - ref| <= {tol} + {tol} |ref| (logits), 2e-2 + 2e-2 |ref| (new K/V rows)", "max_abs_err_logits": round(float(err.max()), 5),
+            "max_abs_err_new_kv_rows": round(kv_err, 5), "argmax_agree": f"{same_tok}/{got.shape[0]}",
+            "what": f"{layers} decoder layer(s) + final norm + lm_head at the headline shape (batch {got.shape[0]}, ctx {ctx}), "
+                    "HIP step vs CPU oracle on identical weights / K,V / tokens"}
 
 
 def cpu_baseline_protocol(gen_len=256, prompt_len=32, threads=None):
@@ -261,6 +365,7 @@ def cpu_baseline(geo, batch, ctx, layers, quant):
                                  b_seq_len=torch.full((batch,), ctx + 1, dtype=torch.int32), max_actual_seq_len=ctx + 1)
     ids = torch.randint(0, V, (batch, 1))
     pos = torch.full((batch, 1), ctx)
+    kv_before = [k.clone() for k in kv]
     t0 = time.perf_counter()
     logits = om.forward(ids, pos, info)
     O.greedy_argmax(logits[:, -1])
@@ -272,10 +377,12 @@ def cpu_baseline(geo, batch, ctx, layers, quant):
     t_head = time.perf_counter() - t0
     per_layer = max(t_all - t_head, 1e-9) / layers
     step_s = per_layer * geo.num_layers + t_head
+    sample = {"params": p, "layers": layers, "info": info, "ids": ids, "pos": pos, "logits": logits, "kv_before": kv_before,
+              "kv_after": kv}
     return {"value": round(batch / step_s, 2), "unit": "tokens/s", "cores": torch.get_num_threads(), "kind": "port",
             "sample": f"oracle decode step, batch {batch}, ctx {ctx}: {layers} of {geo.num_layers} layers timed "
                       f"({per_layer:.2f} s/layer) + lm_head/argmax ({t_head:.2f} s), extrapolated to full depth",
-            "sample_seconds": round(t_all + t_head, 1)}
+            "sample_seconds": round(t_all + t_head, 1)}, sample
 
 
 def choose_allreduce(ps, elems, dev, strict):
@@ -306,7 +413,7 @@ def choose_allreduce(ps, elems, dev, strict):
     flag = torch.tensor([ok], device=dev, dtype=torch.int32)
     dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ps._TP_GROUP)
     if int(flag.item()) == 1:
-        return "oneshot (peer-mapped buffers, checked against RCCL at start-up)"
+        return f"oneshot (peer-mapped buffers, checked against the {ps._backend()} collective at start-up)"
     if ps._ONESHOT is not None:
         ps._ONESHOT.close()
         ps._ONESHOT = None
@@ -316,8 +423,34 @@ def choose_allreduce(ps, elems, dev, strict):
     return "rccl (one-shot kernel failed its start-up check)"
 
 
+def self_launch(args) -> int:
+    """``python bench.py --gpus N`` without a launcher: start the N ranks ourselves (the reference's TP entry point spawns
+    its workers itself too, lite_llama/cli.py:37-112, 397-476) -- one process per GPU under torch.distributed.run on a free
+    local port, stdout / stderr passed through, exit status = the job's.  On a box with fewer than N devices the ranks share
+    device 0 (debugging set-up: collectives staged through gloo or carried by the one-shot kernel over IPC mappings); the
+    JSON line says so in ``config.parallelism_note``."""
+    import socket
+    import subprocess
+
+    env = dict(os.environ)
+    ndev = torch.cuda.device_count()
+    if ndev < args.gpus:
+        env.setdefault("LL_BENCH_DEVICE", "0")
+        env.setdefault("LL_DIST_BACKEND", "gloo")
+        env["LL_BENCH_SHARED_DEVICE"] = f"{args.gpus} ranks share {max(ndev, 1)} device(s): debugging set-up, not a scaling point"
+    with socket.socket() as sk:
+        sk.bind(("127.0.0.1", 0))
+        port = sk.getsockname()[1]
+    env.setdefault("OMP_NUM_THREADS", "8")
+    cmd = [sys.executable, "-m", "torch.distributed.run", "--nnodes=1", f"--nproc-per-node={args.gpus}", "--master-addr",
+           "127.0.0.1", "--master-port", str(port), os.path.abspath(__file__), *sys.argv[1:]]
+    return subprocess.call(cmd, env=env)
+
+
 def main():
     args = parse()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))
     # LL_BENCH_DEVICE: debugging knob -- all ranks on one device (with LL_DIST_BACKEND=gloo: RCCL refuses that), to run
     # the multi-rank code path on a one-GPU box
@@ -325,8 +458,6 @@ def main():
     world = int(os.environ.get("WORLD_SIZE", 1))
     if world != args.gpus and world > 1:
         raise SystemExit(f"--gpus {args.gpus} but WORLD_SIZE={world}")
-    if args.gpus > 1 and world == 1:
-        raise SystemExit("launch multi-GPU runs with torch.distributed.run (see module docstring)")
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
 
@@ -351,7 +482,8 @@ def main():
     if tp > 1 and args.allreduce != "rccl":
         allreduce_how = choose_allreduce(ps, args.batch * geo.hidden_size, dev, strict=args.allreduce == "oneshot")
     if world > 1 and not torch.distributed.is_initialized():  # pure DP: still need the timing barrier
-        torch.distributed.init_process_group("nccl", rank=rank, world_size=world, device_id=dev)
+        kw = {"device_id": dev} if ps._backend() == "nccl" else {}
+        torch.distributed.init_process_group(ps._backend(), rank=rank, world_size=world, **kw)
 
     quant = None if args.quant == "none" else QuantConfig.for_runtime_scheme(args.quant)
     t_build = time.perf_counter()
@@ -440,23 +572,47 @@ def main():
                                f"{args.ctx + total}, {graph_note}" + (", scattered KV rows" if args.scattered else "")
                                + (f", KV paged in blocks of {args.kv_block_size}" if args.kv_block_size else ""),
                    "global_batch": global_batch,
-                   "parallelism": f"dp{dp}xtp{tp}", "allreduce": allreduce_how, "build_seconds": round(t_build, 1)},
+                   "parallelism": f"dp{dp}xtp{tp}", "allreduce": allreduce_how, "ranks": world,
+                   "collective_backend": ("none" if world == 1 else ps._backend() + (" (= RCCL)" if ps._backend() == "nccl" else "")),
+                   "parallelism_note": os.environ.get("LL_BENCH_SHARED_DEVICE"), "build_seconds": round(t_build, 1)},
         "step_roofline": {"algorithmic_bytes_per_step_per_gpu": int(step_bytes),
                           "achieved_GBps_per_gpu": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
                           "frac_of_8TBps": round(step_bytes / (elapsed / args.steps) / PEAK_HBM, 4)},
     }
     if rank == 0:
         rf = gemm_roofline(model, args.batch, args.quant) if quant is not None else None
+        if geo.num_experts and quant is not None:
+            try:  # the dominant kernel of a MoE model is the grouped expert GEMM; the dense projections stay as a second object
+                mrf = moe_roofline(model, args.batch)
+            except Exception as exc:
+                mrf = {"error": f"{type(exc).__name__}: {exc}"}
+            result["roofline_dense_projections"] = rf
+            rf = mrf
         result["roofline"] = rf
+        try:
+            d2d = measured_copy_bandwidth(dev)
+            result["hbm"] = {"peak_GBps_nominal": PEAK_HBM / 1e9, "measured_d2d_copy_GBps": round(d2d / 1e9, 1),
+                             "note": "1-GiB device-to-device copy, read + write bytes; roofline fractions divide by the nominal peak"}
+        except Exception as exc:
+            result["hbm"] = {"peak_GBps_nominal": PEAK_HBM / 1e9, "error": f"{type(exc).__name__}: {exc}"}
         if world == 1 and not args.no_cpu_baseline:
             try:  # SURVEY 8(d) / BASELINE configs[0]: the reference's CPU-runnable case, its protocol
                 result["cpu_baseline"] = cpu_baseline_protocol()
             except Exception as exc:  # never lose the GPU line to a host-side hiccup
                 result["cpu_baseline"] = {"error": f"{type(exc).__name__}: {exc}"}
             try:  # second, labelled entry: the CPU oracle (checker port) on a slice of the headline workload
-                result["cpu_baseline"]["oracle_port"] = cpu_baseline(geo, args.batch, args.ctx, args.cpu_layers, args.quant)
+                port, sample = cpu_baseline(geo, args.batch, args.ctx, args.cpu_layers, args.quant)
+                result["cpu_baseline"]["oracle_port"] = port
             except Exception as exc:
+                sample = None
                 result["cpu_baseline"]["oracle_port"] = {"error": f"{type(exc).__name__}: {exc}"}
+            if sample is not None and not geo.num_experts:
+                try:  # the oracle's layer vs the HIP layer on the same inputs (outside the timed region)
+                    pc = parity_check(geo, args.quant, sample)
+                except Exception as exc:
+                    pc = {"ok": False, "error": f"{type(exc).__name__}: {exc}"}
+                result["parity_check"] = pc["ok"]
+                result["parity_detail"] = pc
         print(json.dumps(result), flush=True)
     if world > 1:
         torch.distributed.barrier()

@@ -8,6 +8,15 @@ dev = "cuda"
 shapes = [("qkv", 4608, 3584, 0), ("o", 3584, 3584, 0), ("gate|up", 37888, 3584, 1), ("down", 3584, 18944, 0)]
 if os.environ.get("SHAPES"):
     shapes = [(f"s{i}", *map(int, t.split("x")), 0) for i, t in enumerate(os.environ["SHAPES"].split(","))]
+PARTIALS = bool(os.environ.get("PARTIALS"))  # the step's own form of the row-parallel / q|k|v launches
+
+
+def gemm(x, w, s, epi):
+    if PARTIALS and not epi:
+        return Q.w4a16_matmul_partials(x, w, s, group_size=128)
+    return Q.w4a16_matmul_prepacked(x, w, s, group_size=128, gate_up_swiglu=bool(epi))
+
+
 for name, n, k, epi in shapes:
     copies = 3
     ws = [(torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64, device=dev).to(torch.int32),
@@ -21,11 +30,11 @@ for name, n, k, epi in shapes:
         os.environ["LL_GEMM3_TL_WAVE"] = str(wave)
         os.environ.pop("LL_GEMM3_TIMELINE", None)
         for i in range(copies):
-            Q.w4a16_matmul_prepacked(x, pw[i], ps[i], group_size=128, gate_up_swiglu=bool(epi))
+            gemm(x, pw[i], ps[i], epi)
         torch.cuda.synchronize()
         tl.zero_()
         os.environ["LL_GEMM3_TIMELINE"] = hex(tl.data_ptr())
-        Q.w4a16_matmul_prepacked(x, pw[0], ps[0], group_size=128, gate_up_swiglu=bool(epi))
+        gemm(x, pw[0], ps[0], epi)
         torch.cuda.synchronize()
         os.environ.pop("LL_GEMM3_TIMELINE", None)
         t = tl.view(1024, 64).cpu().double()
@@ -42,11 +51,11 @@ for name, n, k, epi in shapes:
         os.environ["LL_GEMM3_TL_WAVE"] = str(wave)
         os.environ.pop("LL_GEMM3_TIMELINE", None)
         for i in range(copies):
-            Q.w4a16_matmul_prepacked(x, pw[i], ps[i], group_size=128, gate_up_swiglu=bool(epi))
+            gemm(x, pw[i], ps[i], epi)
         torch.cuda.synchronize()
         tl.zero_()
         os.environ["LL_GEMM3_TIMELINE"] = hex(tl.data_ptr())
-        Q.w4a16_matmul_prepacked(x, pw[0], ps[0], group_size=128, gate_up_swiglu=bool(epi))
+        gemm(x, pw[0], ps[0], epi)
         torch.cuda.synchronize()
         os.environ.pop("LL_GEMM3_TIMELINE", None)
         t = tl.view(1024, 64).cpu().double()

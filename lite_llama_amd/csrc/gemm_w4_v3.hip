@@ -58,6 +58,11 @@ struct V3Lds {
   static_assert(BYTES <= 160 * 1024, "LDS");
 };
 #define V3_SPIN_LIMIT (1 << 18)
+#ifdef V3_ABLATE
+#define V3_ABL(B) ((V3_ABLATE & (B)) != 0)  // debug / timing builds only
+#else
+#define V3_ABL(B) false
+#endif
 
 typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
@@ -72,6 +77,7 @@ struct V3Params {
   int32_t* counters;
   int64_t m, n, k;
   int64_t x_stride;
+  uint32_t x_cstride;  // bytes between the activation tiles of consecutive 128-k chunks (256 for a row-major [m][k] matrix)
   uint32_t w_bytes, s_bytes, x_bytes;
   int nblocks, chunks, total_units, upw, slots;
   int gt, gbase, grem, glead;  // tile-group split, see v3_plan
@@ -173,19 +179,34 @@ __device__ __forceinline__ const void* v3_uniform_ptr(const void* p) {  // prova
   const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
   return (const void*)(((uint64_t)hi << 32) | lo);
 }
+// NT: the non-temporal cache policy for data this CU reads once (the weight stream) -- never for the activation tile,
+// which every workgroup re-reads from L2
+#ifndef V3_NT_W
+#define V3_NT_W 1
+#endif
+template <bool NT = false>
 __device__ __forceinline__ void v3_dma16(uint32_t lds_dst, const void* sbase, uint32_t voff) {
   uint32_t keep;
   lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
   sbase = v3_uniform_ptr(sbase);
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
+template <bool NT = false>
 __device__ __forceinline__ void v3_dma4(uint32_t lds_dst, const void* sbase, uint32_t voff) {
   uint32_t keep;
   lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
   sbase = v3_uniform_ptr(sbase);
-  asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
-               : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+  if constexpr (NT)
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3 nt\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
+  else
+    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
+                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
 template <int N>
 __device__ __forceinline__ void v3_vmcnt() {
@@ -245,19 +266,19 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
         const char* wb = (const char*)p.wp + (size_t)(uint32_t)((blk * q.chunks + lc.c) * (V3_BN * V3_CK / 2));
         const char* sb = (const char*)p.sp + (size_t)(uint32_t)(((lc.c >> p.gshift) * (int)p.n + blk * V3_BN) * 8);
 #pragma unroll
-        for (int j = 0; j < 4; ++j) v3_dma16(dst + f * V3_W_BLOCK + (4 * L + j) * 1024, wb, voff[j]);
+        for (int j = 0; j < 4; ++j) v3_dma16<(V3_NT_W & 1) != 0>(dst + f * V3_W_BLOCK + (4 * L + j) * 1024, wb, voff[j]);
 #pragma unroll
-        for (int j = 0; j < 2; ++j) v3_dma4(dst + f * V3_W_BLOCK + 8192 + (2 * L + j) * 256, sb, voff[4 + j]);
+        for (int j = 0; j < 2; ++j) v3_dma4<(V3_NT_W & 2) != 0>(dst + f * V3_W_BLOCK + 8192 + (2 * L + j) * 256, sb, voff[4 + j]);
       }
 #endif
     } else {
-      const char* xb = (const char*)p.x + (size_t)(uint32_t)(lc.c * (V3_CK * 2));
+      const char* xb = (const char*)p.x + (size_t)((uint32_t)lc.c * p.x_cstride);
 #if !(defined(V3_ABLATE) && (V3_ABLATE & 1))
 #pragma unroll
       for (int j = 0; j < 8; ++j) v3_dma16(dst + (8 * L + j) * 1024, xb, voff[j]);
 #endif
     }
-    v3_walk_next(lc, q);
+    if (!V3_ABL(256)) v3_walk_next(lc, q);
     ++issued;
     if constexpr (KIND == 0) dst = dst + LD::W_SLOT == LD::OFF_W + R * LD::W_SLOT ? LD::OFF_W : dst + LD::W_SLOT;
     else dst = dst + V3_X_SLOT == LD::OFF_X + R * V3_X_SLOT ? LD::OFF_X : dst + V3_X_SLOT;
@@ -284,11 +305,11 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
     if (u < 12) { V3_TL(5 + 3 * u) }
     v3_barrier();
     if (u < 12) { V3_TL(6 + 3 * u) }
-    if (v3_walk_ends(cc)) {  // the consumers' k-half exchange: 1 barrier, or 3 for 256-row tiles with two batch halves
+    if (V3_ABL(128) ? (u + 1 == cnt) : v3_walk_ends(cc)) {  // the consumers' k-half exchange: 1 barrier, or 3 for 256-row tiles with two batch halves
       const int nb = NF == 1 ? 1 : (p.m > 32 ? 3 : 1);
       for (int f = 0; f < nb; ++f) v3_barrier();
     }
-    v3_walk_next(cc, q);
+    if (!V3_ABL(128)) v3_walk_next(cc, q);
   }
 }
 
@@ -657,9 +678,9 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     v3_barrier();                                                                           \
     if (done < 40) { V3_TL(4 + done) }                                                      \
     if (pending) post_pending(); /* the previous segment's slab stores are a unit old */    \
-    const bool se_ = v3_walk_ends(cc);                                                      \
+    const bool se_ = V3_ABL(128) ? (done + 1 == cnt) : v3_walk_ends(cc);                    \
     if (se_) segment_end(cc.t, seg_lo, cc.c);                                               \
-    v3_walk_next(cc, q);                                                                    \
+    if (!V3_ABL(128)) v3_walk_next(cc, q);                                                  \
     if (se_) seg_lo = cc.c;                                                                 \
     ++done;                                                                                 \
   }
@@ -853,6 +874,11 @@ extern "C" int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* w
   p.out = (uint16_t*)out; p.x = (const uint16_t*)x; p.wp = wpacked; p.sp = spacked; p.bias = (const uint16_t*)bias;
   p.workspace = workspace; p.counters = counters;
   p.m = m; p.n = n; p.k = k; p.x_stride = x_stride_m;
+  p.x_cstride = V3_CK * 2;
+  if (getenv("LL_GEMM3_XCM")) {  // experiment: chunk-major activations [k/128][64][128]
+    p.x_stride = V3_CK;
+    p.x_cstride = V3_BM * V3_CK * 2;
+  }
   p.w_bytes = (uint32_t)(n * k / 2);
   p.s_bytes = (uint32_t)(n * (k / group_size) * 8);
   p.x_bytes = (uint32_t)((m - 1) * x_stride_m * 2 + k * 2);
