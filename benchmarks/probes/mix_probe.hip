@@ -1,0 +1,98 @@
+// Mixed-stream probe (round 3): the decode GEMM's per-unit memory traffic without the GEMM.  One 256-thread workgroup
+// per CU: waves 0/1 stream "weights" from a big HBM buffer (4 x 1 KB + 2 x 256 B per unit each), waves 2/3 re-read an
+// L2-resident "activation" matrix (8 x 1 KB per unit each, the [64 x 128] tile of chunk c: 64 rows x 256 B at a 7168-B
+// stride), all by LDS-DMA, DEPTH units in flight per wave, no barriers.  Prints us per unit.
+#include <hip/hip_runtime.h>
+#include <stdint.h>
+#include <stdio.h>
+typedef __attribute__((address_space(3))) void lds_void;
+typedef const __attribute__((address_space(1))) void glb_void;
+
+template <int DEPTH, int MODE, int XDIV, int CONS = 0>  // MODE 1: weights only, 2: activations only, 3: both; XDIV: activation tile every XDIV-th unit;
+// CONS (needs 768 threads): 1 = eight more waves read 9 KB of LDS per unit each (the consumers' fragment reads), 2 = all twelve waves meet at a barrier per unit, 3 = both
+__global__ __launch_bounds__(768) void mix(const unsigned char* w, const unsigned char* x, int units, int* out) {
+  extern __shared__ unsigned char lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  unsigned char* myl = lds + (wv & 3) * 32768;
+  if (wv >= 4) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 acc = {0, 0, 0, 0};
+    for (int u = 0; u < units; ++u) {
+      if (CONS & 1) {
+#pragma unroll
+        for (int j = 0; j < 9; ++j) acc ^= *(const i32x4*)(lds + ((u * 9 + j + wv) % 120) * 1024 + lane * 16);
+      }
+      if (CONS & 2) asm volatile("s_barrier" ::: "memory");
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+    return;
+  }
+  if (wv < 2) {
+    if (!(MODE & 1)) return;
+    const unsigned char* p = w + ((size_t)blockIdx.x * units) * 9216 + wv * 4096;
+    for (int u = 0; u < units; ++u) {
+      unsigned char* dst = myl + (u % DEPTH) * 4608;
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void*)(p + j * 1024 + lane * 16), (lds_void*)(dst + j * 1024), 16, 0, 2);
+#pragma unroll
+      for (int j = 0; j < 2; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void*)(p + 8192 + wv * 512 + j * 256 + lane * 4), (lds_void*)(dst + 4096 + j * 256), 4, 0, 2);
+      p += 9216;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(6 * (DEPTH - 1)) : "memory");
+      if (CONS & 2) asm volatile("s_barrier" ::: "memory");
+    }
+  } else {
+    if (!(MODE & 2)) return;
+    const int L = wv - 2;
+    for (int u = 0; u < units; ++u) {
+      if (XDIV > 1 && (u % XDIV)) { if (CONS & 2) asm volatile("s_barrier" ::: "memory"); continue; }
+      const int c = (u + blockIdx.x * 3) % 28;
+      unsigned char* dst = myl + (u % DEPTH) * 8192;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) {
+        const int r = (8 * L + j) * 4 + (lane >> 4);
+        __builtin_amdgcn_global_load_lds((glb_void*)(x + (size_t)r * 7168 + c * 256 + (lane & 15) * 16), (lds_void*)(dst + j * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(8 * (DEPTH - 1)) : "memory");
+      if (CONS & 2) asm volatile("s_barrier" ::: "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lds[threadIdx.x] == 0x7f) out[0] = 1;
+}
+
+int main() {
+  const size_t big = (size_t)2 << 30;
+  unsigned char *d, *x; int* out;
+  hipMalloc(&d, big); hipMalloc(&x, 1 << 20); hipMalloc(&out, 4);
+  hipMemset(d, 1, big); hipMemset(x, 1, 1 << 20);
+  hipEvent_t e0, e1; hipEventCreate(&e0); hipEventCreate(&e1);
+  auto run = [&](const char* name, auto kern, int units, int threads = 256) {
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 128 * 1024);
+    kern<<<256, threads, 128 * 1024>>>(d, x, units, out);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) kern<<<256, threads, 128 * 1024>>>(d + (size_t)(i % 3) * 256 * units * 9216, x, units, out);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / reps;
+    printf("%-40s units %3d: %8.2f us  %6.3f us/unit  (HBM %5.2f TB/s)\n", name, units, us, us / units, 256.0 * units * 9216 / us / 1e6);
+  };
+  run("weights only   depth 3", mix<3, 1, 1>, 64);
+  run("activ.  only   depth 3", mix<3, 2, 1>, 64);
+  run("both           depth 3", mix<3, 3, 1>, 64);
+  run("both           depth 2", mix<2, 3, 1>, 64);
+  run("both           depth 4", mix<4, 3, 1>, 64);
+  run("both, x every 2nd unit (NF=2) depth 3", mix<3, 3, 2>, 64);
+  run("both, x every 4th unit (NF=4) depth 3", mix<3, 3, 4>, 64);
+  run("both d3 + LDS reads by 8 waves", mix<3, 3, 1, 1>, 64, 768);
+  run("both d3 + barrier per unit (12 waves)", mix<3, 3, 1, 2>, 64, 768);
+  run("both d3 + LDS reads + barrier", mix<3, 3, 1, 3>, 64, 768);
+  run("weights only d3 + LDS reads + barrier", mix<3, 1, 1, 3>, 64, 768);
+  run("both d3 + LDS reads + barrier, 16 units", mix<3, 3, 1, 3>, 16, 768);
+  run("both           depth 3, 16 units", mix<3, 3, 1>, 16);
+  run("weights only   depth 3, 16 units", mix<3, 1, 1>, 16);
+  return 0;
+}

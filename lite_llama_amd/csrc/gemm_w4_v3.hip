@@ -208,6 +208,60 @@ __device__ __forceinline__ void v3_dma4(uint32_t lds_dst, const void* sbase, uin
     asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
                  : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
 }
+// One statement per unit and loader wave (M0 saved / restored once, the pieces' LDS addresses in scalar registers): a weight
+// loader's four 1-KB pieces + two 256-B scale pieces, an activation loader's eight 1-KB pieces.
+#define V3_STR2(X) #X
+#define V3_STR(X) V3_STR2(X)
+#if (V3_NT_W & 1)
+#define V3_W_POLICY " nt"
+#else
+#define V3_W_POLICY ""
+#endif
+#if (V3_NT_W & 2)
+#define V3_S_POLICY " nt"
+#else
+#define V3_S_POLICY ""
+#endif
+__device__ __forceinline__ void v3_dma_w(uint32_t dw, uint32_t ds, const void* wb, const void* sb, const uint32_t (&voff)[8]) {
+  uint32_t keep;
+  dw = __builtin_amdgcn_readfirstlane(dw);
+  ds = __builtin_amdgcn_readfirstlane(ds);
+  wb = v3_uniform_ptr(wb);
+  sb = v3_uniform_ptr(sb);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %7, %13" V3_W_POLICY "\n\t"
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %13" V3_W_POLICY "\n\t"
+      "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %13" V3_W_POLICY "\n\t"
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %13" V3_W_POLICY "\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %11, %14" V3_S_POLICY "\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %12, %14" V3_S_POLICY "\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(dw), "s"(dw + 1024), "s"(dw + 2048), "s"(dw + 3072), "s"(ds), "s"(ds + 256), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]),
+        "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "s"(wb), "s"(sb)
+      : "memory");
+}
+__device__ __forceinline__ void v3_dma_x(uint32_t dx, const void* xb, const uint32_t (&voff)[8]) {
+  uint32_t keep;
+  dx = __builtin_amdgcn_readfirstlane(dx);
+  xb = v3_uniform_ptr(xb);
+  asm volatile(
+      "s_mov_b32 %0, m0\n\t"
+      "s_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %17\n\t"
+      "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %17\n\t"
+      "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %11, %17\n\t"
+      "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %12, %17\n\t"
+      "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %13, %17\n\t"
+      "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %14, %17\n\t"
+      "s_mov_b32 m0, %7\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %15, %17\n\t"
+      "s_mov_b32 m0, %8\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %16, %17\n\t"
+      "s_mov_b32 m0, %0"
+      : "=&s"(keep)
+      : "s"(dx), "s"(dx + 1024), "s"(dx + 2048), "s"(dx + 3072), "s"(dx + 4096), "s"(dx + 5120), "s"(dx + 6144), "s"(dx + 7168),
+        "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "v"(voff[6]), "v"(voff[7]), "s"(xb)
+      : "memory");
+}
 template <int N>
 __device__ __forceinline__ void v3_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -218,7 +272,8 @@ __device__ __forceinline__ void v3_wait_units(int k) {
   if (k <= 0) v3_vmcnt<0>();
   else if (k == 1) v3_vmcnt<OPS>();
   else if (k == 2) v3_vmcnt<2 * OPS>();
-  else v3_vmcnt<3 * OPS>();
+  else if (k == 3 || 4 * OPS > 63) v3_vmcnt<3 * OPS>();
+  else v3_vmcnt<(4 * OPS > 63 ? 3 : 4) * OPS>();
 }
 #if defined(V3_ABLATE) && (V3_ABLATE & 64)
 __device__ __forceinline__ void v3_barrier() { asm volatile("" ::: "memory"); }  // debug: no unit barriers
@@ -265,17 +320,13 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
         const int blk = lc.t * NF + f;
         const char* wb = (const char*)p.wp + (size_t)(uint32_t)((blk * q.chunks + lc.c) * (V3_BN * V3_CK / 2));
         const char* sb = (const char*)p.sp + (size_t)(uint32_t)(((lc.c >> p.gshift) * (int)p.n + blk * V3_BN) * 8);
-#pragma unroll
-        for (int j = 0; j < 4; ++j) v3_dma16<(V3_NT_W & 1) != 0>(dst + f * V3_W_BLOCK + (4 * L + j) * 1024, wb, voff[j]);
-#pragma unroll
-        for (int j = 0; j < 2; ++j) v3_dma4<(V3_NT_W & 2) != 0>(dst + f * V3_W_BLOCK + 8192 + (2 * L + j) * 256, sb, voff[4 + j]);
+        v3_dma_w(dst + f * V3_W_BLOCK + 4 * L * 1024, dst + f * V3_W_BLOCK + 8192 + 2 * L * 256, wb, sb, voff);
       }
 #endif
     } else {
       const char* xb = (const char*)p.x + (size_t)((uint32_t)lc.c * p.x_cstride);
 #if !(defined(V3_ABLATE) && (V3_ABLATE & 1))
-#pragma unroll
-      for (int j = 0; j < 8; ++j) v3_dma16(dst + (8 * L + j) * 1024, xb, voff[j]);
+      v3_dma_x(dst + 8 * L * 1024, xb, voff);
 #endif
     }
     if (!V3_ABL(256)) v3_walk_next(lc, q);
@@ -285,17 +336,30 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
   };
   const int wv = KIND == 0 ? 8 + L : 10 + L;  // (timeline builds)
   (void)wv;
-  // Prologue: only the units the consumers need to START are requested before the first barrier (requesting the
-  // whole ring first costs its issue time -- the memory pipeline accepts ~37 KB/us -- before the first MFMA); the
-  // ring then fills two units per step until it runs D ahead.
-  const int pre = cnt < AHEAD ? cnt : AHEAD;
+  // Prologue (round 3): the whole ring depth is requested at once, in unit order -- a wave's operations return in order, so
+  // unit 0 lands first -- and the consumers start on unit 0 as soon as IT has landed (barrier P0); with operands read one
+  // unit ahead (RA) they multiply unit 0 while units 1, 2 land and meet the loaders again at B0.  (Round 2 requested two
+  // units, waited for both, and refilled the ring two units per step: first unit finished 4.2-4.8 us after entry.)
+  const int pre = cnt < 1 + AHEAD ? cnt : 1 + AHEAD;  // what the consumers' first two steps need; the rest of the ring after P0
   for (int i = 0; i < pre; ++i) issue();
   V3_TL(2)
-  v3_wait_units<OPS>(issued - (cnt < AHEAD ? cnt : AHEAD));  // units < AHEAD have landed
-  v3_barrier();
+  v3_wait_units<OPS>(issued - 1);  // unit 0 has landed
+  v3_barrier();                    // P0
   V3_TL(3)
   V3Walk cc = v3_walk_begin(q);
-  for (int u = 0; u < cnt; ++u) {
+  int u0 = 0;
+  if constexpr (RG::RA) {
+    // the consumers' first step: unit 0 alone (no operands read ahead)
+    const int fill = cnt < D ? cnt : D;
+    while (issued < fill) issue();
+    const int need = cnt < 1 + AHEAD ? cnt : 1 + AHEAD;
+    v3_wait_units<OPS>(issued - need);
+    v3_barrier();  // B0
+    if (V3_ABL(128) ? (1 == cnt) : v3_walk_ends(cc)) v3_barrier();  // k-half exchange (128-row tiles: one barrier)
+    if (!V3_ABL(128)) v3_walk_next(cc, q);
+    u0 = 1;
+  }
+  for (int u = u0; u < cnt; ++u) {
     const int want = cnt < u + 1 + D ? cnt : u + 1 + D;
     if (issued < want) issue();
     if (issued < want) issue();
@@ -365,6 +429,9 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 
   if (wv >= 8) {
     // ======================================== loaders ======================================== //
+#ifdef V3_LOADER_PRIO
+    __builtin_amdgcn_s_setprio(V3_LOADER_PRIO);
+#endif
     if (wv < 10) v3_loader<0, NF>(p, q, cnt, lane, wv - 8);
     else v3_loader<1, NF>(p, q, cnt, lane, wv - 10);
     return;
@@ -659,9 +726,26 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   int seg_lo = cc.c;
   int wnext = LD::OFF_W + RG::RA * LD::W_SLOT, xnext = LD::OFF_X + RG::RA * V3_X_SLOT;  // ring slots of the next unit to READ
   V3Ops<MT, NF> opA, opB;
-  v3_barrier();  // the first units have landed
+  v3_barrier();  // P0: unit 0 has landed
   V3_TL(3)
-  if constexpr (RG::RA) read_ops(opA, LD::OFF_W, LD::OFF_X);
+  if constexpr (RG::RA) {
+    // first step: unit 0 is multiplied as soon as it is there (its operands are read now, not one unit ahead); the loaders
+    // meet the consumers again at B0 with units <= 2 landed, and the steady loop starts at unit 1
+    read_ops(opA, LD::OFF_W, LD::OFF_X);
+    compute(opA);
+    v3_barrier();  // B0
+    V3_TL(4)
+    const bool se0 = V3_ABL(128) ? (1 == cnt) : v3_walk_ends(cc);
+    if (se0) segment_end(cc.t, seg_lo, cc.c);
+    if (!V3_ABL(128)) v3_walk_next(cc, q);
+    if (se0) seg_lo = cc.c;
+    done = 1;
+    if (done < cnt) {
+      read_ops(opA, wnext, xnext);
+      wnext += LD::W_SLOT;
+      xnext += V3_X_SLOT;
+    }
+  }
 
   // One unit.  RA = 1 (128-row tiles): the operands of unit `done` are in CUR (read during the previous unit); the
   // operands of the next unit are read into NXT first -- they landed before the barrier that ended the previous
@@ -684,7 +768,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     if (se_) seg_lo = cc.c;                                                                 \
     ++done;                                                                                 \
   }
-  for (;;) {
+  if (done < cnt) for (;;) {
     V3_STEP(opA, opB)
     if (done >= cnt) break;
     if constexpr (RG::RA) {
