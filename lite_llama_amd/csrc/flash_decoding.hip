@@ -115,6 +115,29 @@ struct FdKv<true> {
   }
 };
 
+// K/V gathers: FD_NT = 1 asks for the non-temporal policy (A/B knob).  Measured SLOWER here (round 3, same box: 20.5 vs
+// 18.7 us at batch 64 x ctx 512): a row's 128-byte lines are fetched as two 64-byte halves by consecutive instructions, and
+// an nt load bypasses the L1 that serves the second half
+#ifndef FD_NT
+#define FD_NT 0
+#endif
+typedef unsigned fd_u32x2 __attribute__((ext_vector_type(2)));
+typedef unsigned fd_u32x4 __attribute__((ext_vector_type(4)));
+__device__ __forceinline__ Q4 fd_gather(const Q4* p) {
+#if FD_NT
+  return __builtin_bit_cast(Q4, __builtin_nontemporal_load(reinterpret_cast<const fd_u32x4*>(p)));
+#else
+  return *p;
+#endif
+}
+__device__ __forceinline__ Q2 fd_gather(const Q2* p) {
+#if FD_NT
+  return __builtin_bit_cast(Q2, __builtin_nontemporal_load(reinterpret_cast<const fd_u32x2*>(p)));
+#else
+  return *p;
+#endif
+}
+
 template <int DT, int D, bool FUSE, bool ROPE, int GS, bool GROUPED, bool KV8 = false>
 __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
@@ -320,10 +343,10 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     const KVE* kB_ = kcE + rowB_ * k_st + (int64_t)kvh * k_sh + c * 8;                        \
     const KVE* vA_ = vcE + rowA_ * v_st + (int64_t)kvh * v_sh + c * 8;                        \
     const KVE* vB_ = vcE + rowB_ * v_st + (int64_t)kvh * v_sh + c * 8;                        \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) ka##S[s] = *reinterpret_cast<const KVR*>(kA_ + s * 32); \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) kb##S[s] = *reinterpret_cast<const KVR*>(kB_ + s * 32); \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) va##S[s] = *reinterpret_cast<const KVR*>(vA_ + s * 32); \
-    _Pragma("unroll") for (int s = 0; s < NS; ++s) vb##S[s] = *reinterpret_cast<const KVR*>(vB_ + s * 32); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) ka##S[s] = fd_gather(reinterpret_cast<const KVR*>(kA_ + s * 32)); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) kb##S[s] = fd_gather(reinterpret_cast<const KVR*>(kB_ + s * 32)); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) va##S[s] = fd_gather(reinterpret_cast<const KVR*>(vA_ + s * 32)); \
+    _Pragma("unroll") for (int s = 0; s < NS; ++s) vb##S[s] = fd_gather(reinterpret_cast<const KVR*>(vB_ + s * 32)); \
   }
 
   // The V tile belongs to ONE wave: its LDS operations execute in order, so within a multi-wave (GROUPED) workgroup a

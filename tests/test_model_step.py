@@ -267,6 +267,118 @@ def test_full_width_decode_layer_matches_oracle():
 
 
 @pytest.mark.gpu
+def test_quantisers_on_the_device_equal_the_cpu_quantisers_bit_for_bit():
+    """The load-time quantisers run wherever the weight lives (methods/*.py convert_from_fp16).  On the device torch turns
+    ``x / 14.0`` into a multiplication by the reciprocal: scales 1 ulp off and ~1 nibble in 1400 one step off against the
+    reference's CPU quantisers (found by the headline-shape layer test below: a 0.026 outlier in a new V row = one int4
+    step x an activation of 3.6).  ``params._div_const`` keeps the division exact; codes, scales and zero points must be
+    IDENTICAL on both devices and equal to the oracle's."""
+    from lite_llama_amd.quantization import params as P
+    from oracle import oracle as O
+
+    g = torch.Generator().manual_seed(77)
+    w = (torch.randn(1536, 3584, generator=g) * 0.02).half()
+    for fn, ofn in ((lambda t: P.quantize_int4_groupwise(t, 128), lambda t: O.quantize_int4_groupwise(t, 128)),
+                    (P.quantize_int8_per_channel, O.quantize_int8_per_channel),
+                    (P.quantize_fp8_per_channel, O.quantize_fp8_per_channel),
+                    (lambda t: P.quantize_int8_groupwise(t, 128), None)):
+        on_cpu, on_gpu = fn(w), fn(w.cuda())
+        for a, b in zip(on_cpu, on_gpu):
+            assert torch.equal(a, b.cpu())
+        if ofn is not None:
+            for a, b in zip(on_cpu, ofn(w)):
+                assert torch.equal(a, b)
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("B,CTX,expect_partials", [(64, 549, True), (64, 1000, True), (128, 549, False)])
+def test_headline_shape_decode_layer_matches_oracle(B, CTX, expect_partials, monkeypatch):
+    """The ASSEMBLED layer of the headline workload (round-2 review, "what's weak" 1): Qwen2.5-7B widths, int4 g128,
+    batch 64 at a context of 549 / 1000 tokens -- the launch sequence bench.py times (fused q|k|v left as split-K
+    partials -> one-launch attention over 5 / 8 partitions -> o partials -> add-and-normalise over partials ->
+    gate|up + swiglu on 256-row tiles -> down partials -> norm) through ``model.py`` with ``partials_ok=True`` --
+    against ``oracle/model.py`` on identical weights / K,V / tokens: logits at 3e-2, the new KV rows at 2e-2, greedy
+    tokens.  Batch 128 takes the generic engines (M > 64: no pre-packed stream, no partials) through the same caller.
+    The test also asserts WHICH route ran (a silent fall-back to the generic route would still pass the numbers)."""
+    from lite_llama_amd.model import CausalLM, tiny_geometry
+    from lite_llama_amd.quantization import QuantConfig
+    from oracle.model import OracleModel
+    import lite_llama_amd.model as M
+    import lite_llama_amd.kernels.quantization as Q
+
+    H, I, L, HQ, HKV, D, V = 3584, 18944, 1, 28, 4, 128, 4096
+    g = torch.Generator().manual_seed(4321 + B + CTX)
+    geo = tiny_geometry(hidden_size=H, intermediate_size=I, num_layers=L, num_heads=HQ, num_kv_heads=HKV,
+                        head_dim=D, vocab_size=V, rope_theta=1000000.0, qkv_bias=True)
+    m = CausalLM(geo)
+    params = {}
+    for name, t in m.state_dict().items():
+        if name.endswith("norm_weight") or name.endswith("layernorm_weight"):
+            params[name] = (1 + 0.1 * torch.randn(t.shape, generator=g)).half()
+        elif name.endswith("bias"):
+            params[name] = (0.01 * torch.randn(t.shape, generator=g)).half()
+        else:
+            params[name] = (0.02 * torch.randn(t.shape, generator=g)).half()
+    m.load_state_dict(params, strict=True)
+    m = m.to("cuda")
+    m.quantize_(QuantConfig.int4_groupwise(128))
+    m.rotary_emb.ensure(CTX + 8, "cuda")
+
+    rows = B * (CTX + 1)
+    kv_cpu = [(torch.randn(rows, 2 * HKV, D, generator=g) * 0.5).half() for _ in range(L)]
+    table = torch.arange(rows, dtype=torch.int32).view(B, CTX + 1)
+    ids = torch.randint(0, V, (B, 1), generator=g)
+    pos = torch.full((B, 1), CTX)
+
+    def info_on(dev, kv):
+        return types.SimpleNamespace(
+            kv_buffer=kv, cur_select_index=table[:, CTX].contiguous().to(dev), b_req_tokens_table=table.clone().to(dev),
+            b_start_loc=None, b_req_idx=torch.arange(B, dtype=torch.int32, device=dev),
+            b_seq_len=torch.full((B,), CTX + 1, dtype=torch.int32, device=dev), max_actual_seq_len=CTX + 1)
+
+    calls = {"attn_partials": 0, "norm_partials": 0, "gemm_partials": 0, "prepacked": 0}
+    real_attn, real_norm = M.decode_attention_partials, M.skip_rmsnorm_partials
+    real_part, real_pre = Q.w4a16_matmul_partials, Q.w4a16_matmul_prepacked
+
+    def count(key, fn):
+        def wrapped(*a, **k):
+            out = fn(*a, **k)
+            if out is not None:
+                calls[key] += 1
+            return out
+        return wrapped
+
+    monkeypatch.setattr(M, "decode_attention_partials", count("attn_partials", real_attn))
+    monkeypatch.setattr(M, "skip_rmsnorm_partials", count("norm_partials", real_norm))
+    import lite_llama_amd.quantization.methods as QM
+    monkeypatch.setattr(QM, "w4a16_matmul_partials", count("gemm_partials", real_part))
+    monkeypatch.setattr(QM, "w4a16_matmul_prepacked", count("prepacked", real_pre))
+
+    kv_gpu = [k.clone().cuda() for k in kv_cpu]
+    with torch.no_grad():
+        got = m(ids.cuda(), pos.cuda(), info_on("cuda", kv_gpu))
+    if expect_partials:
+        # q|k|v, o and down as split-K partials; the attention and both norms consume them; gate|up on the pre-packed stream
+        assert calls == {"attn_partials": 1, "norm_partials": 2, "gemm_partials": 3, "prepacked": 1}, calls
+    else:
+        assert calls == {"attn_partials": 0, "norm_partials": 0, "gemm_partials": 0, "prepacked": 0}, calls
+    om = OracleModel({k: v.clone() for k, v in params.items()}, H, I, L, HQ, HKV, D, V, eps=geo.rms_norm_eps,
+                     rope_theta=geo.rope_theta, quant="int4")
+    kv_ref = [k.clone() for k in kv_cpu]
+    ref = om.forward(ids, pos, info_on("cpu", kv_ref))
+    new_rows = table[:, CTX].long()
+    torch.testing.assert_close(kv_gpu[0][new_rows.cuda()].float().cpu(), kv_ref[0][new_rows].float(), rtol=2e-2, atol=2e-2)
+    old_rows = table[:, :CTX].reshape(-1)[:: 97].long()  # the context rows are untouched
+    assert torch.equal(kv_gpu[0][old_rows.cuda()].cpu(), kv_cpu[0][old_rows])
+    torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=3e-2, atol=3e-2)
+    # greedy tokens: equal wherever the oracle's top two logits are further apart than the tolerance
+    top2 = ref[:, -1].float().topk(2, -1).values
+    decided = (top2[:, 0] - top2[:, 1]) > 6e-2
+    assert decided.sum() >= B // 2
+    assert torch.equal(torch.argmax(got[:, -1], -1).cpu()[decided], torch.argmax(ref[:, -1], -1)[decided])
+
+
+@pytest.mark.gpu
 def test_engine_sampling_path_graph_equals_eager():
     """Non-greedy decode through the sampler kernels inside the captured step: with a vanishing top_p the
     nucleus is the single most probable token, so the stochastic path must reproduce greedy decoding
