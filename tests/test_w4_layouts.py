@@ -36,6 +36,111 @@ def test_known_answer_words():
     assert W.native_pack(qk.T.copy()).view(np.uint32)[0, 0] == 0x87654321
 
 
+# ------------------------------------------------------------------------------------------------------------------ #
+# Literal fixture (round-2 review item 7): a 16 x 16 linear in two groups of 8 input channels whose checkpoint WORDS are
+# written out below -- derived by hand from the formats' published packing rules, NOT produced by oracle/w4_layouts.py or
+# by this repo's packers (plain generating loops: tests/golden/gen_literal_w4_words.py; three words are re-derived in the
+# comments so a reader can check them with pencil and paper).  Still "unpinned against the libraries" (no AutoAWQ /
+# AutoGPTQ wheel or real checkpoint shard exists in the image); what it pins is the restated algorithm against an
+# independent transcription of the same public rules:
+#   values      q[k][n] = (5k + 3n + (k n mod 7)) mod 16,   z[g][n] = 1 + (2g + 3n) mod 15,   s[g][n] = (1 + g + n) / 256
+#   AutoAWQ     qweight [K, N/8]: nibble i of word j of row k holds column 8j + (0, 2, 4, 6, 1, 3, 5, 7)[i]; qzeros alike
+#   AutoGPTQ    qweight [K/8, N]: nibble i of word r of column n holds input channel 8r + i; qzeros [K/g, N/8] sequential,
+#               holding z - 1 (v1 checkpoints)
+#   meaning     W[k][n] = (q[k][n] - z[k // 8][n]) * s[k // 8][n]
+LIT_K, LIT_N, LIT_G = 16, 16, 8
+LIT_AWQ_QW = [  # row 0: columns 0..7 = 0 3 6 9 12 15 2 5 -> nibbles (LSB first) 0 6 C 2 3 9 F 5 -> 0x5F932C60
+    [0x5F932C60, 0xD71BA4E8], [0xA919D5D5, 0x32A2FE6E], [0xFC9F174A, 0x96C941E4], [0x4FA550BF, 0xFA5094FA],
+    [0x992B92B4, 0x5E70EE70], [0xEC31DB29, 0xB2073186], [0x3FB71D9E, 0x162E840C], [0x82C65F93, 0x0A4ED71B],
+    [0xDC4C0808, 0x65D52191], [0x2FC24A7D, 0xC9FC7417], [0x72D883E2, 0x2D83C72D], [0xCC5EC5E7, 0x81A311A3],
+    [0x1F640E5C, 0xE53A64B9], [0x62EA40C1, 0x4951B73F], [0xB5F982C6, 0x3D710A4E], [0x0F7F3B3B, 0x980854C4]]
+LIT_AWQ_QZ = [[0x71A44D71, 0x1A4DD71A], [0x93C66F93, 0x3C6FF93C]]
+LIT_GPTQ_QW = [  # column 0: input channels 0..7 = 0 5 10 15 4 9 14 3 -> 0x3E94FA50
+    [0x3E94FA50, 0x671B5F93, 0x992BB4D6, 0xCB32A919, 0xFDB2075C, 0x2FC9FC9F, 0x51D951D2, 0x83E94FA5,
+     0xBC60A4E8, 0xEE70092B, 0x1087FE6E, 0x42075CA1, 0x741E41E4, 0xA62EA627, 0xD83E94FA, 0x01B5F93D],
+    [0xB61C72D8, 0xF9A4E82C, 0x3CC5EE70, 0x7FE65DC4, 0xB20E53A8, 0xF52FC2FC, 0x3840C840, 0x0B61C72D,
+     0x4EF93D71, 0x811A33C5, 0xC43BA219, 0x0753A8FD, 0x4A741741, 0x8D951D95, 0x50B61C72, 0x934E82C6]]
+LIT_GPTQ_QZ = [  # group 0, columns 0..7: z = 1 4 7 10 13 1 4 7 -> stored z - 1 = 0 3 6 9 C 0 3 6 -> 0x630C9630
+    [0x630C9630, 0x0C9630C9], [0x852EB852, 0x2EB852EB]]
+
+
+def _literal_dense():
+    """The checkpoint's dense meaning [K, N] (fp32), from the closed forms above -- plain loops, no packer involved."""
+    q = [[(5 * k + 3 * n + (k * n) % 7) % 16 for n in range(LIT_N)] for k in range(LIT_K)]
+    z = [[1 + (2 * g + 3 * n) % 15 for n in range(LIT_N)] for g in range(LIT_K // LIT_G)]
+    sc = [[(1 + g + n) / 256.0 for n in range(LIT_N)] for g in range(LIT_K // LIT_G)]
+    w = np.array([[np.float32(q[k][n] - z[k // LIT_G][n]) * np.float32(sc[k // LIT_G][n]) for n in range(LIT_N)]
+                  for k in range(LIT_K)], dtype=np.float32)
+    return q, z, np.array(sc, dtype=np.float16), w
+
+
+def _words(rows):
+    return np.array(rows, dtype=np.uint32).view(np.int32)
+
+
+def test_literal_words_decode_to_the_closed_forms():
+    """The words above really say what the comments claim: decode them here with plain indexing (AWQ order map, GPTQ
+    sequential nibbles and its ``zeros - 1``) and compare with the closed forms."""
+    q, z, _, _ = _literal_dense()
+    order = (0, 2, 4, 6, 1, 3, 5, 7)
+    for k in range(LIT_K):
+        for j in range(LIT_N // 8):
+            for i in range(8):
+                assert (LIT_AWQ_QW[k][j] >> (4 * i)) & 0xF == q[k][8 * j + order[i]]
+    for g in range(LIT_K // LIT_G):
+        for j in range(LIT_N // 8):
+            for i in range(8):
+                assert (LIT_AWQ_QZ[g][j] >> (4 * i)) & 0xF == z[g][8 * j + order[i]]
+                assert ((LIT_GPTQ_QZ[g][j] >> (4 * i)) & 0xF) + 1 == z[g][8 * j + i]
+    for r in range(LIT_K // 8):
+        for n in range(LIT_N):
+            for i in range(8):
+                assert (LIT_GPTQ_QW[r][n] >> (4 * i)) & 0xF == q[8 * r + i][n]
+
+
+@pytest.mark.parametrize("fmt", ["awq", "gptq"])
+def test_oracle_conversion_of_the_literal_checkpoint(fmt):
+    """oracle/w4_layouts.py (the restated converters) on the literal words -> native layout whose pinned dequantiser
+    gives exactly the dense meaning; and its packers reproduce the literal words from the values."""
+    q, z, sc, want = _literal_dense()
+    if fmt == "awq":
+        qw, qz = _words(LIT_AWQ_QW), _words(LIT_AWQ_QZ)
+        nat = W.awq_to_native(qw, qz, sc, LIT_G)
+        packed = W.awq_pack(np.array(q), np.array(z))
+    else:
+        qw, qz = _words(LIT_GPTQ_QW), _words(LIT_GPTQ_QZ)
+        nat = W.gptq_to_native(qw, qz, sc, LIT_G, True)
+        packed = W.gptq_pack(np.array(q), np.array(z), True)
+    assert np.array_equal(packed[0], qw) and np.array_equal(packed[1], qz)
+    got = O.dequant_int4(torch.from_numpy(nat[0]), torch.from_numpy(nat[1]), torch.from_numpy(nat[2]), LIT_G).numpy()
+    assert np.array_equal(got, want.T)
+    # the native word of output row n, first word: input channels 0..7 sequential, LSB first
+    for n in range(LIT_N):
+        assert int(nat[0].view(np.uint32)[n, 0]) == sum(q[i][n] << (4 * i) for i in range(8))
+
+
+@pytest.mark.gpu
+@pytest.mark.parametrize("fmt", ["awq", "gptq"])
+def test_hip_conversion_of_the_literal_checkpoint(fmt):
+    """The device conversion (csrc/w4_layouts.hip) on the literal words, then ``w4a16_matmul`` with a one-hot activation
+    per input channel: row k of the product IS the dense row k -- (q - z) * s rounded once to fp16."""
+    from lite_llama_amd.kernels import w4a16_matmul
+    from lite_llama_amd.quantization import awq_to_w4a16, gptq_to_w4a16
+
+    q, z, sc, want = _literal_dense()
+    t = lambda a: torch.from_numpy(a).cuda()  # noqa: E731
+    if fmt == "awq":
+        nat = awq_to_w4a16(t(_words(LIT_AWQ_QW)), t(_words(LIT_AWQ_QZ)), t(sc), LIT_G)
+    else:
+        nat = gptq_to_w4a16(t(_words(LIT_GPTQ_QW)), t(_words(LIT_GPTQ_QZ)), t(sc), None, LIT_G, "gptq")
+    for n in range(LIT_N):
+        assert int(nat[0].cpu().numpy().view(np.uint32)[n, 0]) == sum(q[i][n] << (4 * i) for i in range(8))
+    assert np.array_equal(nat[1].cpu().numpy(), sc.astype(np.float32).T) and np.array_equal(nat[2].cpu().numpy(), np.array(z, dtype=np.float32).T)
+    eye = torch.eye(LIT_K, dtype=torch.float16, device="cuda")
+    dense = w4a16_matmul(eye, nat[0], nat[1], nat[2], group_size=LIT_G).float().cpu().numpy()
+    assert np.array_equal(dense, want.astype(np.float16).astype(np.float32))
+
+
 @pytest.mark.parametrize("fmt", ["awq", "gptq", "gptq_v2"])
 def test_oracle_conversion_preserves_the_checkpoint_meaning(fmt):
     k, n, g = 256, 72, 64
