@@ -57,7 +57,7 @@ struct V3Lds {
   static constexpr int BYTES = OFF_R + 8 * 4096;
   static_assert(BYTES <= 160 * 1024, "LDS");
 };
-#define V3_SPIN_LIMIT (1 << 18)
+#define V3_SPIN_LIMIT (1 << 24)  // ~10 s of polling, then the launch aborts (never a silent partial sum)
 #ifdef V3_ABLATE
 #define V3_ABL(B) ((V3_ABLATE & (B)) != 0)  // debug / timing builds only
 #else
@@ -526,6 +526,10 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         }
         if (__builtin_amdgcn_readfirstlane(seen) >= c_lo) break;
         __builtin_amdgcn_s_sleep(4);
+        // A contributor that has not delivered after ~10 s is not coming (its workgroup was never resident, or died):
+        // abort the launch -- the host sees a launch failure at its next synchronisation -- rather than sum what is
+        // there and leave the counters non-zero for the next launch.
+        if (spin == V3_SPIN_LIMIT - 1) __builtin_trap();
       }
       if (lane < NM) __hip_atomic_store(ctr + lane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
       V3_TL(52)

@@ -96,6 +96,8 @@ __global__ __launch_bounds__(kMaxBatch) void paged_reserve_kernel(
   if (i == 0) state[0] = top - total;
 }
 
+// Caller contract (not checked on the device: the entry points carry no request-table size): request indices are inside
+// the tables and no request is listed twice in one call.
 // Rows of positions [p_lo, p_hi) of every request on a [n][grid_len] grid: token_table[req][p] = row and
 // select_out[i * grid_len + (p - p_base)] = row; positions the request holds no block for (pads, refused requests)
 // get junk-block rows in select_out and leave the token table alone.
@@ -103,7 +105,7 @@ __global__ void paged_rows_kernel(const int32_t* __restrict__ block_table, int64
                                   const int32_t* __restrict__ req_blocks, const int32_t* __restrict__ req_idx,
                                   const int32_t* __restrict__ lens, int len_bias, int n, int block_size, int grid_len,
                                   int from_end, int32_t* __restrict__ token_table, int64_t tt_stride,
-                                  int32_t* __restrict__ select_out, int64_t num_blocks) {
+                                  int32_t* __restrict__ select_out, int64_t num_blocks, int32_t* __restrict__ state) {
   const int64_t idx = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= (int64_t)n * grid_len) return;
   const int i = (int)(idx / grid_len), g = (int)(idx - (int64_t)i * grid_len);
@@ -113,7 +115,9 @@ __global__ void paged_rows_kernel(const int32_t* __restrict__ block_table, int64
   const int p = from_end ? len - grid_len + g : g;
   const int64_t junk = (num_blocks - 1) * block_size + (p >= 0 ? p % block_size : 0);
   int64_t row = junk;
-  if (p >= 0 && p < len) {
+  if (p >= 0 && p < len && p >= tt_stride) {
+    atomicOr(&state[1], 2);  // beyond the request's token-table row (max_seq_len not a multiple of block_size): junk row, flagged
+  } else if (p >= 0 && p < len) {
     const int b = p / block_size;
     if (b < req_blocks[req]) {
       row = (int64_t)block_table[(int64_t)req * bt_stride + b] * block_size + p % block_size;
@@ -173,7 +177,7 @@ extern "C" int ll_kv_paged_extend(int32_t* free_stack, int32_t* state, int32_t* 
   const int64_t total = n * grid_len;
   paged_rows_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, st>>>(
       block_table, bt_stride, req_blocks, req_idx, lens, len_bias, (int)n, block_size, (int)grid_len, from_end,
-      token_table, tt_stride, select_out, num_blocks);
+      token_table, tt_stride, select_out, num_blocks, state);
   return LL_LAUNCH_CHECK();
 }
 

@@ -17,8 +17,10 @@
 // A staging half is rewritten two launches later; a peer can only be one launch behind (it cannot pass the wait of
 // launch e + 1 before I have raised flag e + 1, which I do after finishing launch e), so nobody is still reading it.
 // Memory: staging and flags live in fine-grained device memory (ll_tp_shared_alloc) so that peer writes become visible
-// inside a running kernel.  A wait that times out sets bit 0 of the error word (flags[2 * B * world]) and the launch
-// falls back to its own partial sums for the missing peer -- the caller checks the word when it synchronises.
+// inside a running kernel.  A wait that times out (~10 s of polling) is FATAL for the job, never silent: the launch sets bit
+// 0 of the sticky error word (flags[2 * B * world]) and writes NaN over its slice of the tensor -- the poison reaches the
+// logits of this and every later step -- and the callers (DecodeEngine.decode, bench.py, parallel_state.oneshot_error)
+// read the word when they synchronise and raise.  (Round 2 summed what had arrived and went on.)
 #include "common.h"
 
 namespace {
@@ -69,12 +71,15 @@ __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(uint16_t* __rest
   __syncthreads();
   const int bad = failed;
   if (bad && tid == 0) atomicOr(peers.flags[rank] + 2 * (int64_t)nb * world, 1);
-  // 4. reduce in rank order
-  for (int64_t v = v_lo + tid; v < v_hi; v += 256) {
+  // 4. reduce in rank order (a missing peer: poison the slice)
+  if (bad) {
+    const int nan2 = DT == LL_F16 ? 0x7e007e00 : 0x7fc07fc0;
+    for (int64_t v = v_lo + tid; v < v_hi; v += 256) *reinterpret_cast<i32x4*>(inout + v * 8) = i32x4{nan2, nan2, nan2, nan2};
+  }
+  for (int64_t v = v_lo + tid; v < v_hi && !bad; v += 256) {
     float acc[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
     for (int r = 0; r < world; ++r) {
-      const uint16_t* src = ((bad >> r) & 1) ? nullptr : peers.stage[r] + (int64_t)p * stage_elems + v * 8;
-      if (!src) continue;
+      const uint16_t* src = peers.stage[r] + (int64_t)p * stage_elems + v * 8;
       const i32x4 x = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(src));
 #pragma unroll
       for (int j = 0; j < 4; ++j) {

@@ -159,13 +159,20 @@ class _OneShot:
         self.epoch_done = torch.zeros(2, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
 
     def fits(self, t: torch.Tensor) -> bool:
-        return (t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and t.is_contiguous() and t.numel() % 8 == 0
-                and 0 < t.numel() <= self.stage_elems and t.data_ptr() % 16 == 0)
+        """Decided from what is IDENTICAL on every rank of the group (dtype, element count) -- never from this rank's
+        storage (alignment, strides): ranks taking different collectives for one call would hang."""
+        return (t.is_cuda and t.dtype in (torch.float16, torch.bfloat16) and t.numel() % 8 == 0
+                and 0 < t.numel() <= self.stage_elems)
 
     def all_reduce(self, t: torch.Tensor) -> None:
         import ctypes
 
         L = self.L
+        if not t.is_contiguous() or t.data_ptr() % 16 != 0:  # this rank's storage is unusual: same collective, via a copy
+            tmp = t.contiguous().clone()
+            self.all_reduce(tmp)
+            t.copy_(tmp)
+            return
         L.check(self.lib.ll_tp_allreduce_oneshot(
             t.data_ptr(), t.numel(), L.dtype_code(t.dtype), ctypes.cast(self.stage_arr, ctypes.c_void_p),
             ctypes.cast(self.flag_arr, ctypes.c_void_p), self.rank, self.world, self.stage_elems, self.blocks,
@@ -203,6 +210,15 @@ def enable_oneshot_all_reduce(max_elems: int, blocks: int = 64) -> None:
 
 def oneshot_error() -> int:
     return 0 if _ONESHOT is None else _ONESHOT.error()
+
+
+def check_collective_errors() -> None:
+    """Raise if the one-shot all-reduce ever lost a peer (sticky device error word; synchronises).  Called by the engine
+    at the end of a decode and by the bench: a timed-out flag poisons the activations with NaN on the device, this turns
+    it into an exception on the host."""
+    if _ONESHOT is not None and _ONESHOT.error():
+        raise RuntimeError(f"tensor-parallel rank {_TP_RANK}: a peer's flag of the one-shot all-reduce did not arrive within "
+                           "the spin bound; the step's activations were poisoned with NaN (a rank died or stalled)")
 
 
 destroy_tensor_parallel = destroy_parallel

@@ -287,7 +287,9 @@ class DecodeEngine:
             # warm-up on a side stream (workspace growth, library init), fenced both ways
             # (cuda_graph.py:110-115); state is restored afterwards
             snap = self._snapshot()
-            s = torch.cuda.Stream()
+            s = getattr(self, "_warm_stream", None)  # ONE warm-up stream per engine: eager scratch is kept per stream
+            if s is None:
+                s = self._warm_stream = torch.cuda.Stream()
             s.wait_stream(torch.cuda.current_stream())
             with torch.cuda.stream(s):
                 self._step_body()
@@ -320,7 +322,21 @@ class DecodeEngine:
                 info.max_actual_seq_len = int(info.max_actual_seq_len)  # eager: exact value
                 self._step_body()
                 info.max_actual_seq_len += 1
+        self._check_device_errors()
         return self._out[:, 1:]
+
+    def _check_device_errors(self) -> None:
+        """Sticky device-side error words, read where the host synchronises anyway (end of a decode): a lost peer of the
+        one-shot all-reduce, an exhausted / misused block pool.  Nothing to read (and no synchronisation) otherwise."""
+        from ..distributed import parallel_state as ps
+
+        if ps._ONESHOT is not None:
+            ps.check_collective_errors()
+        if self.paged:
+            err = self.pool.error
+            if err:
+                raise RuntimeError(f"paged KV pool reported error bits {err:#x} (1: a call found too few free blocks, "
+                                   "2: a request outgrew its block-table / token-table row)")
 
     def _snapshot(self):
         info = self.info

@@ -166,6 +166,14 @@ class MergedColumnLinear:
         self._key = self._snapshot()
         return ok
 
+    def invalidate(self) -> None:
+        """A checkpoint was copied THROUGH the members' parameters (views of the merged storage: the storage itself is up
+        to date, no version counter moved): drop the layouts derived from it."""
+        if self._holder is not None:
+            for attr in ("_w4_prepacked", "_w4_packed"):
+                if hasattr(self._holder, attr):
+                    delattr(self._holder, attr)
+
     def __call__(self, x: torch.Tensor):
         """-> one output view per member (column blocks of the merged ``[..., sum N]`` result)."""
         out = self._holder.quant_method.apply(self._holder, x)

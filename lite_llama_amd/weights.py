@@ -332,6 +332,20 @@ def load_weights(model: nn.Module, weights: Iterable[tuple[str, torch.Tensor]], 
             filled[target_name] = params[target_name].numel()
 
     _verify_coverage(params, filled)
+    invalidate_derived_layouts(model)
+
+
+def invalidate_derived_layouts(model: nn.Module) -> None:
+    """Drop every load-time layout derived from a parameter (the int4 decode engine's pre-packed weights / scale pairs,
+    merged q|k|v and gate|up storages): ``view.copy_`` writes through ``param.data`` and bumps no version counter, so the
+    caches' (pointer, version) keys cannot see a checkpoint loaded after a warm-up forward."""
+    for mod in model.modules():
+        for attr in ("_w4_prepacked", "_w4_packed"):
+            if hasattr(mod, attr):
+                delattr(mod, attr)
+        for val in list(vars(mod).values()):
+            if hasattr(val, "invalidate") and hasattr(val, "refresh"):
+                val.invalidate()
 
 
 def _verify_coverage(params: Mapping[str, nn.Parameter], filled: Mapping[str, int]) -> None:

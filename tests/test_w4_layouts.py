@@ -122,9 +122,8 @@ def test_oracle_conversion_of_the_literal_checkpoint(fmt):
 @pytest.mark.gpu
 @pytest.mark.parametrize("fmt", ["awq", "gptq"])
 def test_hip_conversion_of_the_literal_checkpoint(fmt):
-    """The device conversion (csrc/w4_layouts.hip) on the literal words, then ``w4a16_matmul`` with a one-hot activation
-    per input channel: row k of the product IS the dense row k -- (q - z) * s rounded once to fp16."""
-    from lite_llama_amd.kernels import w4a16_matmul
+    """The device conversion (csrc/w4_layouts.hip) on the literal words: native words, scales and zero points as derived by
+    hand, and the checkpoint's dense meaning (q - z) * s exactly."""
     from lite_llama_amd.quantization import awq_to_w4a16, gptq_to_w4a16
 
     q, z, sc, want = _literal_dense()
@@ -136,9 +135,10 @@ def test_hip_conversion_of_the_literal_checkpoint(fmt):
     for n in range(LIT_N):
         assert int(nat[0].cpu().numpy().view(np.uint32)[n, 0]) == sum(q[i][n] << (4 * i) for i in range(8))
     assert np.array_equal(nat[1].cpu().numpy(), sc.astype(np.float32).T) and np.array_equal(nat[2].cpu().numpy(), np.array(z, dtype=np.float32).T)
-    eye = torch.eye(LIT_K, dtype=torch.float16, device="cuda")
-    dense = w4a16_matmul(eye, nat[0], nat[1], nat[2], group_size=LIT_G).float().cpu().numpy()
-    assert np.array_equal(dense, want.astype(np.float16).astype(np.float32))
+    # the dense meaning of what the device produced, through the (reference-pinned) native dequantiser -- the decode GEMM
+    # itself does not take groups of 8 (its smallest group is 32, like the reference's tests)
+    got = O.dequant_int4(nat[0].cpu(), nat[1].cpu(), nat[2].cpu(), LIT_G).numpy()
+    assert np.array_equal(got, want.T)
 
 
 @pytest.mark.parametrize("fmt", ["awq", "gptq", "gptq_v2"])
