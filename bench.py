@@ -467,15 +467,22 @@ def main():
     from lite_llama_amd.quantization import QuantConfig
 
     geo = GEOMETRY[args.model]
-    # TP degree: the largest divisor of the GPU count that the reference's sharding rules allow
-    # (tp | Hq, tp | Hkv, shard sizes multiples of the int4 group); remaining GPUs are data-parallel
-    # replicas (no collective between them).
-    tp = 1
-    for cand in (8, 4, 2, 1):
-        if world % cand == 0 and geo.num_heads % cand == 0 and geo.num_kv_heads % cand == 0 and \
-                (geo.intermediate_size // cand) % 128 == 0 and (geo.q_size // cand) % 128 == 0:
-            tp = cand
-            break
+    # TP degree: the largest divisor of the GPU count that has a shard plan -- the reference's equal cuts where its rules
+    # hold (tp | Hq, tp | Hkv, shards multiples of the scale group), else the extension plan of distributed/partition.py
+    # (KV heads replicated for tp > Hkv, whole scale groups per rank): Qwen2.5-7B runs TP = 8 on it.  MoE geometries keep
+    # the reference rule.  Remaining GPUs are data-parallel replicas (no collective between them).
+    from lite_llama_amd.distributed.partition import admissible_tp, make_plan
+    if geo.num_experts:
+        tp = 1
+        for cand in (8, 4, 2, 1):
+            if world % cand == 0 and geo.num_heads % cand == 0 and geo.num_kv_heads % cand == 0 and \
+                    (geo.moe_intermediate_size // cand) % 128 == 0:
+                tp = cand
+                break
+        plan_note = None
+    else:
+        tp = admissible_tp(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, world)
+        plan_note = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, tp).describe()
     dp = world // tp
     ps.init_parallel(rank, tp_size=tp, dp_size=dp, master_port=int(os.environ.get("MASTER_PORT", 29500)))
     allreduce_how = "none (tp1)" if tp == 1 else "rccl"
@@ -574,6 +581,7 @@ def main():
                    "global_batch": global_batch,
                    "parallelism": f"dp{dp}xtp{tp}", "allreduce": allreduce_how, "ranks": world,
                    "collective_backend": ("none" if world == 1 else ps._backend() + (" (= RCCL)" if ps._backend() == "nccl" else "")),
+                   "shard_plan": plan_note,
                    "parallelism_note": os.environ.get("LL_BENCH_SHARED_DEVICE"), "build_seconds": round(t_build, 1)},
         "step_roofline": {"algorithmic_bytes_per_step_per_gpu": int(step_bytes),
                           "achieved_GBps_per_gpu": round(step_bytes / (elapsed / args.steps) / 1e9, 1),

@@ -45,8 +45,10 @@ class ReplicatedLinear(LinearBase):
 class ColumnParallelLinear(LinearBase):
     """Output features split across TP ranks; no communication."""
 
-    def __init__(self, input_size, output_size, *, bias=False, quant=None, what="output features"):
-        local_out = divide(output_size, get_tp_world_size(), what)
+    def __init__(self, input_size, output_size, *, bias=False, quant=None, what="output features", local_size=None):
+        """``local_size`` (extension, distributed/partition.py): this rank's share of the output features when the cut is
+        not the reference's equal division; ``None`` -> ``output_size / tp`` and its error behaviour."""
+        local_out = divide(output_size, get_tp_world_size(), what) if local_size is None else int(local_size)
         _check_shard_alignment(quant, local_out, what)
         super().__init__(input_size, local_out, bias=bias, quant=quant)
         self.full_output_size = output_size
@@ -55,10 +57,10 @@ class ColumnParallelLinear(LinearBase):
 class RowParallelLinear(LinearBase):
     """Contracted features split across TP ranks; partial sums are all-reduced."""
 
-    def __init__(self, input_size, output_size, *, bias=False, quant=None, what="input features"):
+    def __init__(self, input_size, output_size, *, bias=False, quant=None, what="input features", local_size=None):
         if bias:
             raise ValueError("RowParallelLinear cannot carry a bias: it would be added once per rank")
-        local_in = divide(input_size, get_tp_world_size(), what)
+        local_in = divide(input_size, get_tp_world_size(), what) if local_size is None else int(local_size)
         _check_shard_alignment(quant, local_in, what)
         super().__init__(local_in, output_size, quant=quant)
         self.full_input_size = input_size

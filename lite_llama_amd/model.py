@@ -23,6 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .distributed.parallel_state import all_reduce_tp, divide, get_tp_rank, get_tp_world_size
+from .distributed.partition import ShardPlan, make_plan, set_active_plan
 from .kernels.attention import decode_attention, decode_attention_partials, decode_attention_partials_supported
 from .kernels.norm_act import PartialSums, rope_and_cache, skip_rmsnorm_partials
 from .kernels import (
@@ -86,6 +87,21 @@ GEOMETRY = {
     "qwen3-30b-a3b": ModelGeometry("qwen3-30b-a3b", 2048, 48, 32, 4, 128, 6144, 151936, use_qk_norm=True,
                                    num_experts=128, num_experts_per_tok=8, moe_intermediate_size=768),
 }
+
+
+def shard_plan(geo: ModelGeometry, quant: QuantConfig | None, tp: int | None = None) -> ShardPlan | None:
+    """The tensor-parallel cut of this geometry: ``None`` when the reference's equal division applies (its code path and
+    error messages stay in charge), else the extension plan of distributed/partition.py (KV-head replication, whole scale
+    groups per rank).  MoE geometries keep the reference rule."""
+    tp = get_tp_world_size() if tp is None else tp
+    if tp == 1 or geo.num_experts:
+        return None
+    try:
+        plan = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, tp,
+                         unit=max(quant.group_k, 1) if quant is not None and quant.group_k < geo.intermediate_size else 128)
+    except ValueError:
+        return None  # no plan: the reference's divide() raises its own error below
+    return None if plan.uniform else plan
 
 
 def tiny_geometry(**kw) -> ModelGeometry:
@@ -207,8 +223,15 @@ class Attention(nn.Module):
     def __init__(self, geo: ModelGeometry, quant: QuantConfig | None):
         super().__init__()
         tp = get_tp_world_size()
-        self.num_heads = divide(geo.num_heads, tp, "attention heads")
-        self.num_kv_heads = divide(geo.num_kv_heads, tp, "key/value heads")
+        plan = shard_plan(geo, quant)
+        if plan is None:
+            self.num_heads = divide(geo.num_heads, tp, "attention heads")
+            self.num_kv_heads = divide(geo.num_kv_heads, tp, "key/value heads")
+            lq = lkv = None
+        else:  # extension: uneven query heads, replicated KV heads
+            self.num_heads = plan.q_heads[get_tp_rank()][1]
+            self.num_kv_heads = plan.kv_heads[get_tp_rank()][1]
+            lq, lkv = self.num_heads * geo.head_dim, 2 * self.num_kv_heads * geo.head_dim
         self.head_dim = geo.head_dim
         self.hidden_size = geo.hidden_size
         self.q_size = self.num_heads * self.head_dim
@@ -216,10 +239,10 @@ class Attention(nn.Module):
         self.eps = geo.rms_norm_eps
         self.use_qk_norm = geo.use_qk_norm
         self.q_proj = ColumnParallelLinear(geo.hidden_size, geo.q_size, bias=geo.qkv_bias, quant=quant,
-                                           what="query features")
+                                           what="query features", local_size=lq)
         self.kv_proj = ColumnParallelLinear(geo.hidden_size, 2 * geo.kv_size, bias=geo.qkv_bias, quant=quant,
-                                            what="key/value features")
-        self.o_proj = RowParallelLinear(geo.q_size, geo.hidden_size, quant=quant, what="query features")
+                                            what="key/value features", local_size=lkv)
+        self.o_proj = RowParallelLinear(geo.q_size, geo.hidden_size, quant=quant, what="query features", local_size=lq)
         if self.use_qk_norm:
             self.q_norm_weight = nn.Parameter(torch.ones(self.head_dim, dtype=torch.float16), requires_grad=False)
             self.k_norm_weight = nn.Parameter(torch.ones(self.head_dim, dtype=torch.float16), requires_grad=False)
@@ -308,9 +331,11 @@ class FusedMLP(nn.Module):
     def __init__(self, geo: ModelGeometry, quant: QuantConfig | None):
         super().__init__()
         h, i = geo.hidden_size, geo.intermediate_size
-        self.gate_proj = ColumnParallelLinear(h, i, quant=quant, what="MLP intermediate")
-        self.up_proj = ColumnParallelLinear(h, i, quant=quant, what="MLP intermediate")
-        self.down_proj = RowParallelLinear(i, h, quant=quant, what="MLP intermediate")
+        plan = shard_plan(geo, quant)
+        li = None if plan is None else plan.inter[get_tp_rank()][1]
+        self.gate_proj = ColumnParallelLinear(h, i, quant=quant, what="MLP intermediate", local_size=li)
+        self.up_proj = ColumnParallelLinear(h, i, quant=quant, what="MLP intermediate", local_size=li)
+        self.down_proj = RowParallelLinear(i, h, quant=quant, what="MLP intermediate", local_size=li)
         object.__setattr__(self, "_gate_up", MergedColumnLinear([self.gate_proj, self.up_proj], interleave=True))
 
     def forward(self, x, partials_ok=False):
@@ -400,6 +425,8 @@ class CausalLM(nn.Module):
         super().__init__()
         self.geo = geo
         self.quant = quant
+        self.shard_plan = shard_plan(geo, quant)  # None: the reference's equal cuts
+        set_active_plan(self.shard_plan, geo.num_heads, geo.num_kv_heads, geo.intermediate_size)
         self.embed_tokens = nn.Embedding(geo.vocab_size, geo.hidden_size, dtype=torch.float16)
         self.embed_tokens.weight.requires_grad_(False)
         self.layers = nn.ModuleList(DecoderLayer(geo, quant) for _ in range(geo.num_layers))
@@ -452,16 +479,25 @@ class CausalLM(nn.Module):
         def randn(*shape, std=0.02):
             return (torch.randn(*shape, generator=g, device=device, dtype=torch.float32) * std).to(torch.float16)
 
-        def shard(full, dim):
-            return full if tp == 1 else full.chunk(tp, dim=dim)[rank].contiguous()
+        plan = shard_plan(self.geo, quant if quant is not None else self.quant)
 
-        def fill_linear(lin: LinearBase, full_out: int, full_in: int, shard_dim: int | None):
+        def shard(full, dim, kind=None):
+            """This rank's slice: the reference's equal chunk, or -- extension plan -- the range of its query heads ("q"),
+            its KV head ("kv") or its MLP intermediate channels ("inter")."""
+            if tp == 1:
+                return full
+            if plan is None or kind is None:
+                return full.chunk(tp, dim=dim)[rank].contiguous()
+            start, count = {"q": plan.q_range, "kv": plan.kv_range, "inter": plan.inter_range}[kind](rank)
+            return full.narrow(dim, start, count).contiguous()
+
+        def fill_linear(lin: LinearBase, full_out: int, full_in: int, shard_dim: int | None, kind=None):
             w = randn(full_out, full_in)
-            w = w if shard_dim is None else shard(w, shard_dim)
+            w = w if shard_dim is None else shard(w, shard_dim, kind)
             lin.weight = nn.Parameter(w, requires_grad=False)
             if lin.bias is not None:
                 b = randn(full_out, std=0.01)
-                lin.bias = nn.Parameter(b if shard_dim != 0 else shard(b, 0), requires_grad=False)
+                lin.bias = nn.Parameter(b if shard_dim != 0 else shard(b, 0, kind), requires_grad=False)
             lin.quant, lin.quant_method = None, get_linear_method_for(None)
             if quant is not None:
                 lin.quantize_(quant)
@@ -477,19 +513,19 @@ class CausalLM(nn.Module):
             layer.post_attention_layernorm_weight.copy_(
                 (1 + 0.1 * torch.randn(geo.hidden_size, generator=g, device=device)).half())
             at = layer.self_attn
-            fill_linear(at.q_proj, geo.q_size, geo.hidden_size, 0)
+            fill_linear(at.q_proj, geo.q_size, geo.hidden_size, 0, "q")
             # fused kv: each rank takes its slice of k_proj and of v_proj and fuses locally
             # (weights.py:99,166-169): rank r's rows are [K_r ; V_r]
             kw, vw = randn(geo.kv_size, geo.hidden_size), randn(geo.kv_size, geo.hidden_size)
-            kv = torch.cat([shard(kw, 0), shard(vw, 0)], dim=0)
+            kv = torch.cat([shard(kw, 0, "kv"), shard(vw, 0, "kv")], dim=0)
             at.kv_proj.weight = nn.Parameter(kv, requires_grad=False)
             if at.kv_proj.bias is not None:
                 kb, vb = randn(geo.kv_size, std=0.01), randn(geo.kv_size, std=0.01)
-                at.kv_proj.bias = nn.Parameter(torch.cat([shard(kb, 0), shard(vb, 0)]), requires_grad=False)
+                at.kv_proj.bias = nn.Parameter(torch.cat([shard(kb, 0, "kv"), shard(vb, 0, "kv")]), requires_grad=False)
             at.kv_proj.quant, at.kv_proj.quant_method = None, get_linear_method_for(None)
             if quant is not None:
                 at.kv_proj.quantize_(quant)
-            fill_linear(at.o_proj, geo.hidden_size, geo.q_size, 1)
+            fill_linear(at.o_proj, geo.hidden_size, geo.q_size, 1, "q")
             if geo.use_qk_norm:
                 at.q_norm_weight.copy_((1 + 0.1 * torch.randn(geo.head_dim, generator=g, device=device)).half())
                 at.k_norm_weight.copy_((1 + 0.1 * torch.randn(geo.head_dim, generator=g, device=device)).half())
@@ -509,9 +545,9 @@ class CausalLM(nn.Module):
                     blk.quantize_experts_(quant)
             else:
                 mlp = layer.mlp
-                fill_linear(mlp.gate_proj, geo.intermediate_size, geo.hidden_size, 0)
-                fill_linear(mlp.up_proj, geo.intermediate_size, geo.hidden_size, 0)
-                fill_linear(mlp.down_proj, geo.hidden_size, geo.intermediate_size, 1)
+                fill_linear(mlp.gate_proj, geo.intermediate_size, geo.hidden_size, 0, "inter")
+                fill_linear(mlp.up_proj, geo.intermediate_size, geo.hidden_size, 0, "inter")
+                fill_linear(mlp.down_proj, geo.hidden_size, geo.intermediate_size, 1, "inter")
         self.quant = quant
         return self
 

@@ -23,6 +23,7 @@ import torch
 import torch.nn as nn
 
 from .distributed.parallel_state import get_tp_rank, get_tp_world_size
+from .distributed.partition import plan_range
 
 FP8_BLOCK = 128                     # block-fp8 checkpoints: one fp32 scale per 128 x 128 weights (weight_utils.py:58-71)
 SCALE_SUFFIX = "weight_scale_inv"
@@ -139,6 +140,9 @@ def shard_dim(param_name: str) -> int | None:
 def _narrow_for_rank(name: str, tensor: torch.Tensor, dim: int) -> torch.Tensor:
     world = get_tp_world_size()
     size = tensor.shape[dim]
+    ext = plan_range(_module_of(name), size, get_tp_rank())  # extension plan in force (distributed/partition.py)?
+    if ext is not None:
+        return tensor.narrow(dim, ext[0], ext[1])
     if size % world != 0:
         raise ValueError(f"{name}: dimension {dim} of size {size} does not divide across {world} tensor-parallel ranks")
     return tensor.narrow(dim, get_tp_rank() * (size // world), size // world)
@@ -174,14 +178,14 @@ def tp_shard_int4(param_name: str, tensor: torch.Tensor, group_size: int) -> tor
         if cut == 0:
             return tensor
         k = tensor.shape[0]
-        if (k // world) % group_size != 0:
+        if plan_range(_module_of(param_name), k, get_tp_rank()) is None and (k // world) % group_size != 0:
             raise ValueError(f"{param_name}: {k} input channels over {world} ranks do not end on a group boundary")
         if not torch.equal(tensor.view(-1).to(torch.int64), torch.arange(k, device=tensor.device) // group_size):
             raise NotImplementedError(
                 f"{param_name}: an activation-ordered (desc_act) row-parallel linear cannot be cut along its input "
                 "channels (a rank's channels belong to arbitrary groups)")
         part = _narrow_for_rank(param_name, tensor, 0)
-        return part - get_tp_rank() * (k // world // group_size)
+        return part - part.view(-1)[0]  # rebased to the rank's first group (channels are in group order, checked above)
     return _narrow_for_rank(param_name, tensor, tensor.dim() - 1 if cut == 0 else 0)
 
 

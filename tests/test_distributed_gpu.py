@@ -21,21 +21,25 @@ def _free_port():
     return port
 
 
-def _geometry():
+def _geometry(which="tp2"):
     from lite_llama_amd.model import tiny_geometry
 
+    if which == "tp8":  # Qwen2.5-7B's head layout (28 / 4 heads of 128) and an intermediate of twelve 128-groups: outside the
+        # reference's rules at TP = 8 -> extension plan (4 + 3 query heads per rank, KV heads on two ranks, 2,2,2,2,1,1,1,1 groups)
+        return tiny_geometry(hidden_size=512, intermediate_size=1536, num_layers=2, num_heads=28, num_kv_heads=4, head_dim=128,
+                             vocab_size=640, qkv_bias=True)
     return tiny_geometry(hidden_size=512, intermediate_size=1024, num_layers=2, num_heads=8, num_kv_heads=2, head_dim=64,
                          vocab_size=640, qkv_bias=True)
 
 
-def _run(tp_rank_env=None):
+def _run(which="tp2"):
     """prefill 2 sequences + 6 greedy decode steps (eager); returns (first tokens, tokens, logits of the first decode step)."""
     from lite_llama_amd.executor import DecodeEngine
     from lite_llama_amd.model import CausalLM
     from lite_llama_amd.quantization import QuantConfig
 
     quant = QuantConfig.int4_groupwise(128)
-    model = CausalLM(_geometry(), quant).init_synthetic(seed=9, quant=quant, device="cuda")
+    model = CausalLM(_geometry(which), quant).init_synthetic(seed=9, quant=quant, device="cuda")
     eng = DecodeEngine(model, max_batch=2, max_seq_len=32)
     g = torch.Generator().manual_seed(4)
     ids = torch.randint(0, 640, (2, 7), generator=g).cuda()
@@ -54,7 +58,7 @@ def _run(tp_rank_env=None):
     return first.cpu(), toks.cpu(), grabbed[0]
 
 
-def _worker(rank, world, port, q):
+def _worker(rank, world, port, q, which="tp2"):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["LL_DIST_BACKEND"] = "gloo"
@@ -64,7 +68,7 @@ def _worker(rank, world, port, q):
         torch.cuda.set_device(0)
         ps.init_tensor_parallel(rank, world, master_port=port)
         assert ps.get_tp_world_size() == world
-        first, toks, logits = _run()
+        first, toks, logits = _run(which)
         q.put((rank, True, first.numpy(), (toks.numpy(), logits.numpy())))  # by value: a shared-memory tensor handle dies with the worker
     except Exception as exc:  # pragma: no cover
         import traceback
@@ -101,3 +105,35 @@ def test_tp2_sharded_int4_decode_matches_tp1():
     # greedy paths agree while the top-2 margin is not inside that noise
     agree = (toks0 == ref_toks).float().mean().item()
     assert agree >= 0.75, (toks0, ref_toks)
+
+
+@pytest.mark.gpu
+def test_tp8_extension_plan_int4_decode_matches_tp1():
+    """EIGHT ranks on the one GPU, a geometry the reference refuses at TP = 8 (28 / 4 heads, an intermediate that does not
+    divide into eight group-aligned parts): the extension plan of distributed/partition.py -- 4 + 3 query heads per rank,
+    every KV head replicated on two ranks (each rank's pool holds ONE KV head), whole 128-groups per rank -- decodes the
+    tokens of the unsharded model; the first decode step's logits agree at 1e-2 (sixteen fp16 partial sums per layer)."""
+    from lite_llama_amd.distributed.partition import make_plan
+
+    assert not make_plan(28, 4, 128, 1536, 8).uniform
+    world = 8
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "tp8")) for r in range(world)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, a, b in results:
+        assert ok is True, (rank, a)
+    t = torch.from_numpy
+    ref_first, ref_toks, ref_logits = _run("tp8")  # tp = 1 in this process
+    for rank, _, first, (toks, logits) in results:
+        assert torch.equal(t(first), t(results[0][2])) and torch.equal(t(toks), t(results[0][3][0]))
+        assert torch.equal(t(logits), t(results[0][3][1]))
+    assert torch.equal(t(results[0][2]), ref_first)
+    torch.testing.assert_close(t(results[0][3][1]), ref_logits, rtol=1e-2, atol=1e-2)
+    agree = (t(results[0][3][0]) == ref_toks).float().mean().item()
+    assert agree >= 0.75, (results[0][3][0], ref_toks)
