@@ -299,7 +299,8 @@ int ll_kv_ref_update(int32_t* state, int64_t n_rows, const void* index, int64_t 
  * get bit-identical results).  One launch, no host call: capturable.  Setup (host, once): ll_tp_shared_alloc the staging
  * buffer [2][stage_elems] 16-bit and ll_tp_oneshot_flag_words(blocks, world) int32 flag words, exchange
  * ll_tp_ipc_export handles through any host channel, ll_tp_ipc_open the peers'.  A peer that does not show up within the
- * spin bound sets bit 0 of the error word (the LAST flag word) and is left out of the sum. */
+ * spin bound (~10 s) sets bit 0 of the STICKY error word (the LAST flag word) and the launch overwrites its slice with NaN:
+ * a lost peer poisons the step instead of producing a plausible partial sum; read the word with ll_tp_error_word. */
 int ll_tp_shared_alloc(void** ptr, int64_t bytes);
 int ll_tp_shared_free(void* ptr);
 int ll_tp_ipc_export(void* ptr, void* handle64);
@@ -313,6 +314,16 @@ int ll_tp_error_word(const void* flags, int64_t flag_words, int32_t* host_out);
  * (same count, same blocks).  count <= stage_elems, count % 8 == 0, world <= 8. */
 int ll_tp_allreduce_oneshot(void* inout, int64_t count, int dtype, const void* const* stage_ptrs, void* const* flag_ptrs,
                             int rank, int world, int64_t stage_elems, int blocks, int32_t* epoch_done, void* stream);
+/* The block's collective fused with its neighbours (models/linear.py:160-161 RowParallelLinear.forward = all_reduce(GEMM),
+ * then kernels/skip_rmsnorm.py:192-234): y = skip_rmsnorm(all_reduce_tp(fp16(sum of the S fp32 split-K partials
+ * [S][rows][n] that ll_w4a16_matmul_prepacked leaves with epilogue 2)), residual, weight), residual updated in place.
+ * Same peer buffers, flag words, epoch counter and `blocks` as ll_tp_allreduce_oneshot (the two may alternate within a
+ * step); sums in fp32 in rank order -- bit-identical on all ranks and to GEMM -> ll_tp_allreduce_oneshot ->
+ * ll_skip_rmsnorm.  rows * n <= stage_elems, n % 8 == 0, n <= 8192, 1 <= s_count <= 64. */
+int ll_tp_allreduce_norm_partials(void* y, const float* partials, int s_count, void* residual, const void* weight,
+                                  int64_t rows, int64_t n, float eps, int dtype, const void* const* stage_ptrs,
+                                  void* const* flag_ptrs, int rank, int world, int64_t stage_elems, int blocks,
+                                  int32_t* epoch_done, void* stream);
 
 /* ---- fp8 KV cache (extension -- the reference's pool is fp16, executor/kv_cache_manager.py:197-216) ----
  * The pool holds OCP e4m3 bytes; stored value * k_scale (v_scale) = K (V) value, static per pool.

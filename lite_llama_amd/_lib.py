@@ -71,6 +71,7 @@ SIGNATURES = {
     "ll_tp_oneshot_flag_words": [I, I],
     "ll_tp_error_word": [P, L, P],
     "ll_tp_allreduce_oneshot": [P, L, I, P, P, I, I, L, I, P, P],
+    "ll_tp_allreduce_norm_partials": [P, P, I, P, P, L, L, F, I, P, P, I, I, L, I, P, P],
     "ll_kv_paged_reset": [P, P, P, L, L, P],
     "ll_kv_paged_extend": [P, P, P, L, P, P, P, I, L, I, L, I, P, L, P, L, P],
     "ll_kv_paged_release": [P, P, P, L, P, P, L, P],

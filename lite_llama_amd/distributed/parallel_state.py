@@ -178,6 +178,22 @@ class _OneShot:
             ctypes.cast(self.flag_arr, ctypes.c_void_p), self.rank, self.world, self.stage_elems, self.blocks,
             self.epoch_done.data_ptr(), L.stream_ptr()), "tp_allreduce_oneshot")
 
+    def fits_rows(self, rows: int, n: int, dtype) -> bool:
+        """Rank-invariant admission of the fused projection -> all-reduce -> norm launch."""
+        return dtype in (torch.float16, torch.bfloat16) and n % 8 == 0 and n <= 8192 and 0 < rows * n <= self.stage_elems
+
+    def all_reduce_norm_partials(self, parts: torch.Tensor, residual: torch.Tensor, weight: torch.Tensor, eps: float,
+                                 out: torch.Tensor) -> None:
+        import ctypes
+
+        L = self.L
+        s, m, n = parts.shape
+        L.check(self.lib.ll_tp_allreduce_norm_partials(
+            out.data_ptr(), parts.data_ptr(), s, residual.data_ptr(), weight.data_ptr(), m, n, float(eps),
+            L.dtype_code(out.dtype), ctypes.cast(self.stage_arr, ctypes.c_void_p), ctypes.cast(self.flag_arr, ctypes.c_void_p),
+            self.rank, self.world, self.stage_elems, self.blocks, self.epoch_done.data_ptr(), L.stream_ptr()),
+            "tp_allreduce_norm_partials")
+
     def error(self) -> int:
         """The device error word (synchronises): bit 0 = a peer's flag did not arrive within the spin bound."""
         import ctypes
@@ -206,6 +222,16 @@ def enable_oneshot_all_reduce(max_elems: int, blocks: int = 64) -> None:
     if _ONESHOT is not None:
         _ONESHOT.close()
     _ONESHOT = _OneShot(max_elems, blocks)
+
+
+def fused_reduce_norm_available(rows: int, n: int, dtype) -> bool:
+    """True when a row-parallel projection may hand its split-K partials to the fused all-reduce + add-and-normalise
+    launch (one-shot kernel enabled for this TP group, payload fits its staging buffer)."""
+    return _TP_WORLD_SIZE > 1 and _ONESHOT is not None and _ONESHOT.fits_rows(rows, n, dtype)
+
+
+def all_reduce_norm_partials(parts, residual, weight, eps, out) -> None:
+    _ONESHOT.all_reduce_norm_partials(parts, residual, weight, eps, out)
 
 
 def oneshot_error() -> int:

@@ -53,13 +53,19 @@ class PartialSums:
     projection, :func:`skip_rmsnorm_partials`.  ``materialise()`` gives the tensor the projection would have
     returned."""
 
-    __slots__ = ("parts", "shape", "dtype")
+    __slots__ = ("parts", "shape", "dtype", "tp_reduce")
 
-    def __init__(self, parts: torch.Tensor, shape, dtype):
-        self.parts, self.shape, self.dtype = parts, tuple(shape), dtype
+    def __init__(self, parts: torch.Tensor, shape, dtype, tp_reduce: bool = False):
+        """``tp_reduce``: the sums are this RANK's share of a row-parallel projection -- the consumer adds the ranks'
+        shares too (fused one-shot all-reduce, csrc/tp_allreduce.hip::allreduce_norm_partials_kernel)."""
+        self.parts, self.shape, self.dtype, self.tp_reduce = parts, tuple(shape), dtype, tp_reduce
 
     def materialise(self) -> torch.Tensor:
-        return self.parts.sum(0).to(self.dtype).view(self.shape)
+        out = self.parts.sum(0).to(self.dtype).view(self.shape)
+        if self.tp_reduce:
+            from ..distributed.parallel_state import all_reduce_tp
+            out = all_reduce_tp(out.contiguous())
+        return out
 
 
 @torch.no_grad()
@@ -77,6 +83,12 @@ def skip_rmsnorm_partials(X: PartialSums, residual, weight, eps=1e-5):
     if weight.dtype != X.dtype:
         weight = weight.to(X.dtype)
     Y = torch.empty((m, n), dtype=X.dtype, device=residual.device)
+    if X.tp_reduce:
+        # tensor parallelism: the partials are this rank's share; one launch adds them, exchanges the fp16 sums with the
+        # peers (one-shot all-reduce over peer-mapped buffers, fp32 adds in rank order) and normalises
+        from ..distributed import parallel_state as ps
+        ps.all_reduce_norm_partials(X.parts, residual, weight.contiguous(), eps, Y)
+        return Y.view(X.shape), residual.view(X.shape)
     L.check(
         L.lib().ll_skip_rmsnorm_partials(Y.data_ptr(), X.parts.data_ptr(), s, residual.data_ptr(),
                                          weight.contiguous().data_ptr(), m, n, float(eps), L.dtype_code(X.dtype),

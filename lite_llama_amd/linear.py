@@ -4,6 +4,8 @@ is the block's single collective."""
 
 from __future__ import annotations
 
+import os
+
 import torch
 import torch.nn as nn
 
@@ -68,12 +70,34 @@ class RowParallelLinear(LinearBase):
     def forward(self, x: torch.Tensor, partials_ok: bool = False):
         """``partials_ok`` (extension): the caller feeds the result to ``skip_rmsnorm_partials`` and accepts a
         :class:`PartialSums` -- only taken without tensor parallelism (the all-reduce needs the finished sums)."""
-        if (partials_ok and get_tp_world_size() == 1 and not collective_forced()
-                and hasattr(self.quant_method, "apply_partials")):
-            out = self.quant_method.apply_partials(self, x)
-            if out is not None:
-                return out
+        if partials_ok and not collective_forced() and hasattr(self.quant_method, "apply_partials"):
+            if get_tp_world_size() == 1:
+                out = self.quant_method.apply_partials(self, x)
+                if out is not None:
+                    return out
+            else:
+                # tensor parallelism (round 3): the partials go to ONE launch that also carries the block's collective and
+                # the add-and-normalise -- available when the one-shot all-reduce is enabled and the payload fits it
+                # (decided from shapes only: every rank takes the same route)
+                from .distributed.parallel_state import fused_reduce_norm_available
+                rows = x.numel() // x.shape[-1] if x.shape[-1] else 0
+                if fused_reduce_norm_available(rows, self.output_size, x.dtype) and not os.environ.get("LL_TP_NO_FUSED_NORM"):
+                    if self._tp_partials_ok(rows):
+                        out = self.quant_method.apply_partials(self, x)
+                        if out is None:  # the peers took the fused launch: a different collective here would hang or race
+                            raise RuntimeError("row-parallel projection: this rank's shard cannot leave split-K partials "
+                                               "although its shape class can (set LL_TP_NO_FUSED_NORM=1 on every rank)")
+                        out.tp_reduce = True
+                        return out
         return all_reduce_tp(self.apply_linear(x))
+
+    def _tp_partials_ok(self, rows: int) -> bool:
+        """Whether EVERY rank's shard of this projection can leave split-K partials -- from properties all ranks share
+        (format, group size, decode-shaped batch, output width) plus this rank's contracted size, which is a multiple of
+        128 on every rank under both shard rules (equal cuts respect the scale group; extension plans cut whole groups)."""
+        q = self.quant
+        return (q is not None and getattr(q, "format", None) == "int4" and q.group_k % 128 == 0 and 1 <= rows <= 64
+                and self.output_size % 128 == 0 and self.input_size % 128 == 0 and self.bias is None)
 
 
 def _check_shard_alignment(quant, local_size: int, what: str) -> None:

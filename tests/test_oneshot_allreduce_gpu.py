@@ -94,10 +94,12 @@ def test_two_ranks_on_one_gpu_exchange_through_ipc():
         assert report["error_word"] == 0 and report["fits_big"] is False and report["fits_f32"] is False
 
 
-def _tp_decode_worker(rank, world, port, q, oneshot):
+def _tp_decode_worker(rank, world, port, q, oneshot, fused=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["LL_DIST_BACKEND"] = "gloo"
+    if not fused:
+        os.environ["LL_TP_NO_FUSED_NORM"] = "1"   # GEMM -> one-shot all-reduce -> norm as three launches
     from lite_llama_amd.distributed import parallel_state as ps
 
     try:
@@ -128,11 +130,11 @@ def test_tp2_decode_over_the_oneshot_kernel_matches_the_backend_collective():
     import numpy as np
 
     outs = {}
-    for oneshot in (False, True):
+    for oneshot in (False, True, "unfused"):
         ctx = mp.get_context("spawn")
         q = ctx.Queue()
         port = _free_port()
-        procs = [ctx.Process(target=_tp_decode_worker, args=(r, 2, port, q, oneshot)) for r in range(2)]
+        procs = [ctx.Process(target=_tp_decode_worker, args=(r, 2, port, q, bool(oneshot), oneshot is True)) for r in range(2)]
         for p in procs:
             p.start()
         results = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
@@ -145,3 +147,96 @@ def test_tp2_decode_over_the_oneshot_kernel_matches_the_backend_collective():
         outs[oneshot] = results[0][2]
     assert np.array_equal(outs[True][0], outs[False][0])
     np.testing.assert_allclose(outs[True][2], outs[False][2], rtol=1e-2, atol=1e-2)
+    # round 3: with the kernel enabled the decode step's row-parallel projections leave split-K partials and ONE launch
+    # does partial sums + all-reduce + add-and-normalise; same roundings in the same places as the three-launch form:
+    # tokens and logits are bit-identical
+    assert np.array_equal(outs[True][1], outs["unfused"][1]) and np.array_equal(outs[True][2], outs["unfused"][2])
+
+
+def _fused_worker(rank, world, port, q):
+    os.environ["MASTER_ADDR"] = "127.0.0.1"
+    os.environ["MASTER_PORT"] = str(port)
+    os.environ["LL_DIST_BACKEND"] = "gloo"
+    import torch.distributed as dist
+
+    from lite_llama_amd.distributed import parallel_state as ps
+    from lite_llama_amd.kernels import skip_rmsnorm
+    from lite_llama_amd.kernels.norm_act import PartialSums, skip_rmsnorm_partials
+
+    try:
+        torch.cuda.set_device(0)
+        ps.init_tensor_parallel(rank, world, master_port=port)
+        ps.enable_oneshot_all_reduce(64 * 3584)
+        dev = torch.device("cuda", 0)
+        report = {}
+        for case, (rows, n, s, dtype) in enumerate([(64, 3584, 5, torch.float16), (64, 3584, 9, torch.float16), (7, 512, 1, torch.float16),
+                                                     (33, 2048, 12, torch.bfloat16), (64, 3584, 6, torch.float16)]):
+            g = torch.Generator(device=dev).manual_seed(1000 * rank + case)
+            parts = torch.randn(s, rows, n, device=dev, generator=g) * 0.3
+            g2 = torch.Generator(device=dev).manual_seed(50 + case)          # residual / weight: the same on both ranks
+            resid = (torch.randn(rows, n, device=dev, generator=g2) * 0.5).to(dtype)
+            w = (1 + 0.1 * torch.randn(n, device=dev, generator=g2)).to(dtype)
+            # three-launch form: the projection's own rounding, the one-shot all-reduce, the add-and-normalise
+            o = parts.sum(0).to(dtype) if s > 1 else parts[0].to(dtype)
+            # (the kernel adds the planes in order s = 0, 1, ...: restate that order, torch.sum may pair differently)
+            acc = torch.zeros(rows, n, device=dev)
+            for i in range(s):
+                acc = acc + parts[i]
+            o = acc.to(dtype)
+            ps.all_reduce_tp(o)
+            r1 = resid.clone()
+            y1, r1 = skip_rmsnorm(o, r1, w, 1e-6)
+            # fused form
+            r2 = resid.clone()
+            y2, r2 = skip_rmsnorm_partials(PartialSums(parts, (rows, n), dtype, tp_reduce=True), r2, w, 1e-6)
+            torch.cuda.synchronize()
+            report[case] = bool(torch.equal(y1, y2) and torch.equal(r1, r2))
+            dist.barrier()
+        # captured: replays keep exchanging (epochs advance on the device)
+        parts = torch.full((2, 64, 3584), float(rank + 1), device=dev)
+        resid = torch.zeros(64, 3584, device=dev, dtype=torch.float16)
+        w = torch.ones(3584, device=dev, dtype=torch.float16)
+        keep = resid.clone()
+        skip_rmsnorm_partials(PartialSums(parts, (64, 3584), torch.float16, tp_reduce=True), keep.clone(), w, 1e-6)
+        torch.cuda.synchronize()
+        dist.barrier()
+        graph = torch.cuda.CUDAGraph()
+        rr = torch.zeros_like(resid)
+        with torch.cuda.graph(graph):
+            rr.zero_()
+            yy, _ = skip_rmsnorm_partials(PartialSums(parts, (64, 3584), torch.float16, tp_reduce=True), rr, w, 1e-6)
+        ok = True
+        total = 2.0 * sum(range(1, world + 1))
+        for _ in range(4):
+            graph.replay()
+            torch.cuda.synchronize()
+            ok = ok and bool((rr == total).all()) and bool(torch.allclose(yy.float(), torch.ones_like(yy).float(), atol=2e-3))
+        report["graph"] = ok
+        report["error_word"] = ps.oneshot_error()
+        q.put((rank, True, report))
+    except Exception as exc:  # pragma: no cover
+        import traceback
+
+        q.put((rank, False, repr(exc) + traceback.format_exc()[-2000:]))
+    finally:
+        ps.destroy_parallel()
+
+
+def test_fused_partials_allreduce_norm_equals_the_three_launch_form():
+    """csrc/tp_allreduce.hip::allreduce_norm_partials_kernel with two ranks on the one GPU: y and the updated residual are
+    BIT-IDENTICAL to fp16(sum of partials) -> one-shot all-reduce -> skip_rmsnorm, for the headline payload (64 x 3584, 5 / 9 / 6
+    planes), a single plane, bf16 with 12 planes over 33 rows; and inside a captured graph over several replays."""
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_fused_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = sorted((q.get(timeout=300) for _ in procs), key=lambda r: r[0])
+    for p in procs:
+        p.join(timeout=60)
+    for rank, ok, report in results:
+        assert ok is True, (rank, report)
+        bad = [k for k, v in report.items() if k != "error_word" and v is not True]
+        assert not bad, (rank, bad)
+        assert report["error_word"] == 0
