@@ -6,6 +6,8 @@ over the HIP C-ABI.  Same signatures, same ValueErrors, same on-device weight fo
 
 from __future__ import annotations
 
+import os
+
 import torch
 
 from .. import _lib as L
@@ -16,6 +18,31 @@ def _flatten(x: torch.Tensor, k: int):
     if a.stride(-1) != 1 or (a.stride(0) % 8) != 0 or (a.data_ptr() % 16) != 0:
         a = a.contiguous()
     return a
+
+
+def _auto_prepacked(m, n, k, group_size, qweight, scales, zeros):
+    """The drop-in route's access to the decode engine (round 3): a caller of the REFERENCE signature (the reference's
+    ``W4A16LinearMethod.apply`` after ``integration.install()``) passes the reference-format parameters on every call; for
+    decode shapes (<= 64 rows) their load-time layouts -- ``pack_w4a16_weights`` / ``pack_w4a16_scales``, bit-exact
+    permutations -- are built on first use and kept ON the weight tensor object (freed with it; rebuilt when any of the
+    three tensors was replaced or written in place).  Costs a second copy of the int4 weights (+0.5625 B per weight);
+    ``LL_W4_NO_AUTO_PREPACK=1`` keeps the reference-layout engine.  Never built inside a graph capture."""
+    if m < 1 or m > 64 or os.environ.get("LL_W4_NO_AUTO_PREPACK") or not qweight.is_contiguous():
+        return None
+    if not w4a16_prepacked_supported(m, n, k, group_size):
+        return None
+    key = (qweight.data_ptr(), qweight._version, scales.data_ptr(), scales._version, zeros.data_ptr(), zeros._version)
+    cached = getattr(qweight, "_ll_prepacked", None)
+    if cached is not None and cached[0] == key:
+        return cached[1]
+    if torch.cuda.is_current_stream_capturing():
+        return None
+    try:
+        pre = (pack_w4a16_weights(qweight), pack_w4a16_scales(scales, zeros))
+        qweight._ll_prepacked = (key, pre)
+    except (AttributeError, RuntimeError):
+        return None
+    return pre
 
 
 def w4a16_matmul(
@@ -60,6 +87,9 @@ def w4a16_matmul(
         if tuple(packed_scales.shape) != (k // group_size, n, 2) or packed_scales.dtype != torch.int32 \
                 or not packed_scales.is_contiguous():
             raise ValueError("packed_scales must be the int32 [K/g, N, 2] tensor made by pack_w4a16_scales")
+    pre = _auto_prepacked(m, n, k, group_size, qweight, scales, zeros)
+    if pre is not None:  # decode-shaped call of the reference signature: the load-time layouts, made once per weight
+        return w4a16_matmul_prepacked(x, pre[0], pre[1], group_size=group_size, bias=bias)
     out = torch.empty((m, n), dtype=x.dtype, device=x.device)
     ws, cnt = L.gemm_workspace(x.device, m, n, k)
     L.check(
