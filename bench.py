@@ -48,6 +48,11 @@ def parse():
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--ctx", type=int, default=512, help="context tokens per sequence when decoding starts")
     ap.add_argument("--quant", default="int4", choices=["int4", "int8", "smoothquant", "fp8", "none"])
+    ap.add_argument("--dtype", default="f16", choices=["f16", "bf16"],
+                    help="activation / unquantised-weight dtype; bf16 (BASELINE config 2) needs --quant none: the reference's "
+                         "quantised GEMMs are fp16-only (kernels/quantization/*.py raise on anything else)")
+    ap.add_argument("--steps-per-graph", type=int, default=1,
+                    help="decode steps captured in ONE hipGraph launch (the timed K steps are then K / this many replays)")
     ap.add_argument("--no-graph", action="store_true")
     ap.add_argument("--scattered", action="store_true", help="context rows in random pool order (gather cost)")
     ap.add_argument("--kv-block-size", type=int, default=0, help="block-granular KV paging on the device (0: the reference's bump allocator)")
@@ -98,7 +103,7 @@ def gemm_roofline(model, batch, quant, iters=6):
     fused_members = set()
     launches_list = []  # (callable, input_size, weights in the launch)
     for mc in merged:
-        if mc.layers[0].quant is not None and mc.refresh():
+        if (mc.layers[0].quant is not None or quant == "none") and mc.refresh():
             fused_members.update(id(l) for l in mc.layers)
             if mc.interleave:
                 fn = lambda x, mc=mc: mc.swiglu(x)
@@ -106,14 +111,15 @@ def gemm_roofline(model, batch, quant, iters=6):
                 fn = lambda x, mc=mc: (mc.partials(x) or mc(x))
             launches_list.append((fn, mc.layers[0].input_size, sum(l.input_size * l.output_size for l in mc.layers)))
     for m in model.modules():
-        if isinstance(m, LinearBase) and m.quant is not None and id(m) not in fused_members:
+        if isinstance(m, LinearBase) and (m.quant is not None or quant == "none") and id(m) not in fused_members:
             fn = (lambda x, m=m: m(x, partials_ok=True)) if (isinstance(m, RowParallelLinear) and solo) else m.apply_linear
             launches_list.append((fn, m.input_size, m.input_size * m.output_size))
     if not launches_list:
         return None
     dev = next(model.parameters()).device
-    xs = {k: torch.randn(batch, k, device=dev, dtype=torch.float16) * 0.5 for _, k, _ in launches_list}
-    per_w = {"int4": 0.5 + 8.0 / 128, "int8": 1.0, "smoothquant": 1.0, "fp8": 1.0}[quant]
+    adt = next(model.parameters()).dtype if quant == "none" else torch.float16
+    xs = {k: (torch.randn(batch, k, device=dev) * 0.5).to(adt) for _, k, _ in launches_list}
+    per_w = {"int4": 0.5 + 8.0 / 128, "int8": 1.0, "smoothquant": 1.0, "fp8": 1.0, "none": 2.0}[quant]
     nbytes = sum(w * per_w for _, _, w in launches_list)
     stream = torch.cuda.current_stream()
     for fn, k, _ in launches_list:  # warm
@@ -161,7 +167,9 @@ def gemm_roofline(model, batch, quant, iters=6):
         "int8": "dense8_kernel + dense8_finish (w8a16 int8, split-K weight streaming; gemm_w8_skinny.hip)",
         "fp8": "dense8_kernel + dense8_finish (w8a16 fp8-e4m3, split-K weight streaming; gemm_w8_skinny.hip)",
         "smoothquant": "quantize_activations_int8 + dense8_kernel (int8 x int8 MFMA) + dense8_finish (gemm_w8_skinny.hip)",
-    }[quant] if batch <= 64 else "wgemm_kernel (generic engine, M > 64; gemm_wq.hip)"
+        "none": "hipBLASLt 16-bit GEMM through torch F.linear (the reference's own unquantised path, methods/unquantized.py:21-22; "
+                "NOT a kernel of this repo -- see DESIGN.md on the dense 16-bit row)",
+    }[quant] if batch <= 64 or quant == "none" else "wgemm_kernel (generic engine, M > 64; gemm_wq.hip)"
     return {
         "bound": "hbm", "kernel": kernel,
         "covers": "the dense linear projections (attention q|k|v / o" + ("" if getattr(model.geo, "num_experts", 0) else ", gate|up, down")
@@ -579,12 +587,18 @@ def main():
     with torch.device(dev):
         model = CausalLM(geo, quant)
     model.init_synthetic(seed=0, quant=quant, device=dev)
+    act_dtype = torch.float16
+    if args.dtype == "bf16":
+        if quant is not None:
+            raise SystemExit("--dtype bf16 needs --quant none (the quantised GEMMs follow the reference: fp16 activations only)")
+        model = model.to(torch.bfloat16)
+        act_dtype = torch.bfloat16
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
 
     total = args.warmup + args.steps
     engine = DecodeEngine(model, max_batch=args.batch, max_seq_len=args.ctx + total + 8, device=dev,
-                              kv_block_size=args.kv_block_size or None)
+                              kv_block_size=args.kv_block_size or None, kv_dtype=act_dtype)
     first = engine.synthetic_context(args.batch, args.ctx, seed=1 + ps.get_dp_rank(), scattered=args.scattered)
 
     marks = {}
@@ -609,7 +623,9 @@ def main():
     graph_note = "hipGraph" if use_graph else "eager (--no-graph or uncapturable backend)"
     graph_error = None
     try:
-        out = engine.decode(first, total, use_graph=use_graph, on_step=on_step)
+        if args.steps_per_graph > 1 and (args.warmup % args.steps_per_graph or args.steps % args.steps_per_graph):
+            raise SystemExit("--steps-per-graph must divide --warmup and --steps (the timed region starts on a replay boundary)")
+        out = engine.decode(first, total, use_graph=use_graph, on_step=on_step, steps_per_graph=args.steps_per_graph)
     except Exception as exc:
         if not use_graph:
             raise
@@ -628,7 +644,7 @@ def main():
         graph_note = "eager (graph capture failed)"
         marks.clear()
         engine = DecodeEngine(model, max_batch=args.batch, max_seq_len=args.ctx + total + 8, device=dev,
-                              kv_block_size=args.kv_block_size or None)
+                              kv_block_size=args.kv_block_size or None, kv_dtype=act_dtype)
         first = engine.synthetic_context(args.batch, args.ctx, seed=1 + ps.get_dp_rank(), scattered=args.scattered)
         out = engine.decode(first, total, use_graph=False, on_step=on_step)
     barrier()
@@ -654,7 +670,7 @@ def main():
         "scaling": "strong" if dp == 1 else "weak", "vs_baseline": None,
         "dtype": {"int4": "f16 (int4 weights, fp32 accumulate)", "int8": "f16 (int8 weights, fp32 accumulate)",
                   "fp8": "f16 (fp8-e4m3 weights, fp32 accumulate)", "smoothquant": "int8 (int32 accumulate, f16 epilogue)",
-                  "none": "f16 (fp32 accumulate)"}[args.quant],
+                  "none": f"{args.dtype} (fp32 accumulate)"}[args.quant],
         "data": "synthetic", "graph": bool(use_graph), "graph_error": graph_error,
         "allreduce_error": ps.oneshot_error(),  # 0, or 1: a peer flag of the one-shot all-reduce timed out during the run
         "config": {"workload": f"{args.model} {args.quant} decode, batch {args.batch}/replica, ctx {args.ctx}->"
@@ -663,14 +679,14 @@ def main():
                    "global_batch": global_batch,
                    "parallelism": f"dp{dp}xtp{tp}", "allreduce": allreduce_how, "ranks": world,
                    "collective_backend": ("none" if world == 1 else ps._backend() + (" (= RCCL)" if ps._backend() == "nccl" else "")),
-                   "shard_plan": plan_note,
+                   "shard_plan": plan_note, "steps_per_graph_launch": args.steps_per_graph if use_graph else None,
                    "parallelism_note": os.environ.get("LL_BENCH_SHARED_DEVICE"), "build_seconds": round(t_build, 1)},
         "step_roofline": {"algorithmic_bytes_per_step_per_gpu": int(step_bytes),
                           "achieved_GBps_per_gpu": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
                           "frac_of_8TBps": round(step_bytes / (elapsed / args.steps) / PEAK_HBM, 4)},
     }
     if rank == 0:
-        rf = gemm_roofline(model, args.batch, args.quant) if quant is not None else None
+        rf = gemm_roofline(model, args.batch, args.quant)
         if geo.num_experts and quant is not None:
             try:  # the dominant kernel of a MoE model is the grouped expert GEMM; the dense projections stay as a second object
                 mrf = moe_roofline(model, args.batch)

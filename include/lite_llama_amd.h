@@ -259,6 +259,12 @@ int ll_moe_gemm(void* c, const void* a, const void* w, const float* w_scale, con
 int ll_silu_and_mul(void* out, const void* x, int64_t rows, int64_t n, int dtype, void* stream);
 int ll_moe_sum(void* out, const void* x, int64_t tokens, int top_k, int64_t n, int dtype,
                void* stream);
+/* Router tail (models/qwen3_moe.py:85-100 after the router GEMM): probabilities = softmax over ALL experts in fp32 of
+ * the 16-bit logits [tokens, experts] (row stride logits_stride), the top_k largest in descending order (equal values:
+ * lower expert first), optionally renormalised to sum 1, cast to the logits' dtype -> weights_out [tokens, top_k];
+ * ids_out int64 [tokens, top_k].  experts <= 1024, top_k <= 64. */
+int ll_moe_route_topk(void* weights_out, int64_t* ids_out, const void* logits, int64_t tokens, int experts,
+                      int64_t logits_stride, int top_k, int norm_topk_prob, int dtype, void* stream);
 
 /* Decode-step bookkeeping in one launch (executor extension; the reference issues these as
  * separate tensor ops, model_runner.py:200-218 + llm_engine.py:173-213): records the sampled

@@ -55,6 +55,7 @@ SIGNATURES = {
     "ll_moe_gemm": [P, P, P, P, P, P, P, P, L, L, I, L, L, I, I, I, I, L, L, L, L, L, L, L, I, P],
     "ll_silu_and_mul": [P, P, L, L, I, P],
     "ll_moe_sum": [P, P, L, I, L, I, P],
+    "ll_moe_route_topk": [P, P, P, L, I, L, I, I, I, P],
     "ll_argmax": [P, P, L, L, L, I, P],
     "ll_decode_advance": [P, L, P, P, P, P, P, P, P, P, L, L, I, P],
     "ll_slot_advance": [P, P, P, P, P, P, P, L, L, I, I, P],

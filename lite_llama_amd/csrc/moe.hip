@@ -436,3 +436,93 @@ extern "C" int ll_moe_gemm(void* c, const void* a, const void* w, const float* w
 #undef LL_MOE
   return LL_LAUNCH_CHECK();
 }
+
+
+// ---------------------------------------------------------------------------------- //
+// Router tail in one launch (round 3): lite_llama/models/qwen3_moe.py:85-100 runs, after the fp16 router GEMM,
+// softmax(dtype=fp32) over ALL experts -> top-k -> renormalise -> cast to the activation dtype as four tensor ops per
+// layer (x 48 layers in Qwen3-30B-A3B).  One wave per token: the row's logits live in registers (experts / 64 per lane),
+// max and sum are wave reductions, the k selections are k rounds of a wave arg-max over (probability bits, ~index) --
+// probabilities are positive floats, so their bit patterns order like the values, and equal values resolve to the LOWER
+// expert index (torch.topk leaves the order among equal values unspecified; this kernel is deterministic).
+// ---------------------------------------------------------------------------------- //
+template <int DT>
+__global__ __launch_bounds__(256) void moe_route_topk_kernel(uint16_t* __restrict__ w_out, int64_t* __restrict__ ids_out,
+                                                             const uint16_t* __restrict__ logits, int64_t tokens, int experts,
+                                                             int64_t l_stride, int top_k, int norm) {
+  constexpr int PER = 16;  // experts <= 1024
+  const int lane = threadIdx.x & 63;
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (tok >= tokens) return;
+  float v[PER];
+  float mx = -INFINITY;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int e = j * 64 + lane;
+    v[j] = e < experts ? to_f32<DT>(logits[tok * l_stride + e]) : -INFINITY;
+    mx = fmaxf(mx, v[j]);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    v[j] = j * 64 + lane < experts ? expf(v[j] - mx) : 0.f;
+    sum += v[j];
+  }
+  sum = wave_sum(sum);
+#pragma unroll
+  for (int j = 0; j < PER; ++j) v[j] = v[j] / sum;  // the probabilities torch.softmax(dtype=float32) hands to topk
+  float picked_w = 0.f;   // lane r keeps selection r
+  int picked_e = 0;
+  float top_sum = 0.f;
+  for (int r = 0; r < top_k; ++r) {
+    unsigned long long best = 0ull;
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int e = j * 64 + lane;
+      if (e < experts && v[j] >= 0.f) {
+        const unsigned long long key = ((unsigned long long)__float_as_uint(v[j]) << 32) | (unsigned)(0xffffffffu - (unsigned)e);
+        best = key > best ? key : best;
+      }
+    }
+#pragma unroll
+    for (int off = 32; off > 0; off >>= 1) {
+      const unsigned long long o = __shfl_xor(best, off, 64);
+      best = o > best ? o : best;
+    }
+    const int e = (int)(0xffffffffu - (unsigned)(best & 0xffffffffull));
+    const float pw = __uint_as_float((unsigned)(best >> 32));
+    top_sum += pw;
+    if (lane == r) {
+      picked_w = pw;
+      picked_e = e;
+    }
+    if ((e & 63) == lane) {
+#pragma unroll
+      for (int j = 0; j < PER; ++j)
+        if (j == (e >> 6)) v[j] = -1.f;  // taken
+    }
+  }
+  if (lane < top_k) {
+    const float wv = norm ? picked_w / top_sum : picked_w;
+    w_out[tok * top_k + lane] = from_f32<DT>(wv);
+    ids_out[tok * top_k + lane] = picked_e;
+  }
+}
+
+extern "C" int ll_moe_route_topk(void* weights_out, int64_t* ids_out, const void* logits, int64_t tokens, int experts,
+                                 int64_t logits_stride, int top_k, int norm_topk_prob, int dtype, void* stream) {
+  if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (tokens < 0 || experts < 1 || experts > 1024 || top_k < 1 || top_k > 64 || top_k > experts || logits_stride < experts)
+    return LL_ERR_SHAPE;
+  if (tokens == 0) return LL_OK;
+  if (!weights_out || !ids_out || !logits) return LL_ERR_ARG;
+  const dim3 grid((unsigned)((tokens + 3) / 4));
+  if (dtype == LL_F16)
+    moe_route_topk_kernel<LL_F16><<<grid, 256, 0, (hipStream_t)stream>>>((uint16_t*)weights_out, ids_out, (const uint16_t*)logits,
+                                                                          tokens, experts, logits_stride, top_k, norm_topk_prob);
+  else
+    moe_route_topk_kernel<LL_BF16><<<grid, 256, 0, (hipStream_t)stream>>>((uint16_t*)weights_out, ids_out, (const uint16_t*)logits,
+                                                                           tokens, experts, logits_stride, top_k, norm_topk_prob);
+  return LL_LAUNCH_CHECK();
+}

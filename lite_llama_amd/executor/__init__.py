@@ -269,12 +269,16 @@ class DecodeEngine:
 
     @torch.no_grad()
     def decode(self, first_tokens: torch.Tensor, max_new_tokens: int, use_graph: bool = True,
-               warmup_steps: int = 0, on_step=None, sampling=None) -> torch.Tensor:
+               warmup_steps: int = 0, on_step=None, sampling=None, steps_per_graph: int = 1) -> torch.Tensor:
         """Generate ``max_new_tokens`` greedy tokens per row; returns ``[B, max_new_tokens]``.
 
         With ``use_graph`` the step is captured once (``max_actual_seq_len`` baked as the final
         context length rounded up to the attention partition size) and replayed per token.
         ``warmup_steps`` of the total are run before ``on_step`` timing hooks fire (bench use).
+        ``steps_per_graph`` ("a whole multi-step decode is one graph launch", the counterpart of the loop in
+        engine/llm_engine.py:137-213): that many consecutive steps are captured in ONE hipGraph -- every step already
+        advances its own metadata on the device, so the steps chain without the host -- and a remainder shorter than the
+        group replays a one-step graph; ``on_step(i)`` then fires once per replay with the index of its first step.
         """
         self._sampling = sampling  # None = greedy; else an object with temperature / top_p / repetition_penalty
         self._begin_decode(first_tokens, max_new_tokens)
@@ -311,10 +315,25 @@ class DecodeEngine:
                 raise
             self._restore(snap)  # capture does not execute, but keep the state explicit
             self._graph = graph
-            for i in range(max_new_tokens):
+            group = max(1, min(int(steps_per_graph), max_new_tokens))
+            multi = None
+            if group > 1:
+                multi = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(multi):
+                    for _ in range(group):
+                        self._step_body()
+                self._restore(snap)
+                self._graph_multi = multi
+            i = 0
+            while i < max_new_tokens:
                 if on_step is not None:
                     on_step(i)
-                graph.replay()
+                if multi is not None and max_new_tokens - i >= group:
+                    multi.replay()
+                    i += group
+                else:
+                    graph.replay()
+                    i += 1
         else:
             for i in range(max_new_tokens):
                 if on_step is not None:

@@ -138,3 +138,22 @@ def fused_moe(
         "moe_sum",
     )
     return out
+
+
+@torch.no_grad()
+def moe_route_topk(router_logits: torch.Tensor, top_k: int, norm_topk_prob: bool = True):
+    """Extension (decode-step launch count): the router's tail -- fp32 softmax over all experts, top-k, optional
+    renormalisation, cast to the activation dtype (models/qwen3_moe.py:95-100) -- as ONE launch instead of four tensor
+    ops.  ``router_logits [tokens, experts]`` fp16 / bf16 -> ``(weights [tokens, top_k] in that dtype, ids int64)``."""
+    L.require_cuda(router_logits)
+    if router_logits.dim() != 2 or router_logits.dtype not in (torch.float16, torch.bfloat16):
+        raise ValueError("router logits must be a 16-bit [tokens, experts] tensor")
+    if router_logits.stride(1) != 1:
+        router_logits = router_logits.contiguous()
+    t, e = router_logits.shape
+    w = torch.empty((t, top_k), dtype=router_logits.dtype, device=router_logits.device)
+    ids = torch.empty((t, top_k), dtype=torch.int64, device=router_logits.device)
+    L.check(L.lib().ll_moe_route_topk(w.data_ptr(), ids.data_ptr(), router_logits.data_ptr(), t, e, router_logits.stride(0),
+                                      int(top_k), 1 if norm_topk_prob else 0, L.dtype_code(router_logits.dtype),
+                                      L.stream_ptr()), "moe_route_topk")
+    return w, ids

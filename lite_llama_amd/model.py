@@ -370,6 +370,9 @@ class SparseMoeBlock(nn.Module):
 
     def _route(self, x):
         logits = F.linear(x, self.gate_weight)
+        if logits.is_cuda and self.num_experts <= 1024 and self.top_k <= 64 and not os.environ.get("LL_MOE_TORCH_ROUTER"):
+            from .kernels.fused_moe import moe_route_topk
+            return moe_route_topk(logits, self.top_k, self.norm_topk_prob)  # softmax + top-k + renorm + cast: one launch
         probs = torch.softmax(logits, dim=-1, dtype=torch.float32)
         w, ids = torch.topk(probs, self.top_k, dim=-1)
         if self.norm_topk_prob:

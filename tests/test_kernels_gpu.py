@@ -872,3 +872,34 @@ def test_top_p_sampling_full_vocabulary_and_greedy_rows():
     got = Sampler().sample(logits.to(DEV).unsqueeze(1), params, gen).cpu()
     ref = torch.argmax(O.apply_repetition_penalty(logits, gen.token_ids.cpu(), gen.mask.cpu(), 1.2).float(), -1).view(-1, 1)
     assert torch.equal(got, ref)
+
+
+@pytest.mark.parametrize("T,E,k,norm,dt", [(64, 128, 8, True, torch.float16), (5, 128, 8, False, torch.float16),
+                                           (33, 60, 4, True, torch.bfloat16), (1, 1024, 64, True, torch.float16),
+                                           (7, 8, 2, True, torch.float16)])
+def test_moe_route_topk_matches_the_reference_router_tail(T, E, k, norm, dt):
+    """softmax(fp32) -> topk -> renormalise -> cast (models/qwen3_moe.py:95-100) in one launch: the same expert ids
+    wherever the selected probabilities are distinct, weights within one rounding of the 16-bit result; exact ties
+    resolve to the lower expert index (torch leaves them unspecified)."""
+    from lite_llama_amd.kernels.fused_moe import moe_route_topk
+
+    g = torch.Generator().manual_seed(T * 1000 + E)
+    logits = (torch.randn(T, E, generator=g) * 2).to(dt)
+    probs = torch.softmax(logits.float(), dim=-1)
+    w_ref, id_ref = torch.topk(probs, k, dim=-1)
+    if norm:
+        w_ref = w_ref / w_ref.sum(-1, keepdim=True)
+    w, ids = moe_route_topk(logits.to(DEV), k, norm)
+    assert w.dtype == dt and ids.dtype == torch.int64
+    srt = probs.sort(-1, descending=True).values
+    distinct = (srt[:, : min(k + 1, E) - 1] - srt[:, 1: min(k + 1, E)]).min(-1).values > 0 if E > 1 else torch.ones(T, dtype=torch.bool)
+    assert torch.equal(ids.cpu()[distinct], id_ref[distinct])
+    close(w.float()[distinct.to(DEV)], w_ref[distinct].to(dt).float(), 2e-3 if dt == torch.float16 else 1.6e-2)
+    # ties: torch.topk leaves the order among EQUAL values unspecified (its CPU and device kernels differ); this kernel is
+    # deterministic: the lower expert index first
+    tie = torch.zeros(2, E).to(dt)
+    tie[0, E // 2] = 1.0
+    w2, ids2 = moe_route_topk(tie.to(DEV), k, True)
+    assert ids2.cpu()[1].tolist() == list(range(k))
+    assert ids2.cpu()[0].tolist() == [E // 2] + [e for e in range(E) if e != E // 2][: k - 1]
+    close(w2.float().sum(-1), torch.ones(2), 2e-3 if dt == torch.float16 else 1.6e-2)

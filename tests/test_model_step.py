@@ -175,6 +175,11 @@ def test_engine_graph_equals_eager_and_oracle():
         assert torch.equal(first.cpu(), torch.from_numpy(d["first_tokens"]))
         outs.append(eng.decode(first, steps, use_graph=use_graph).cpu())
     assert torch.equal(outs[0], outs[1])
+    # several steps per graph launch: groups of 5 + a remainder of 2 one-step replays -- same tokens
+    eng = DecodeEngine(m, max_batch=2, max_seq_len=64)
+    fired = []
+    grouped = eng.decode(eng.prefill(ids, lens), steps, use_graph=True, steps_per_graph=5, on_step=fired.append).cpu()
+    assert torch.equal(grouped, outs[0]) and fired == [0, 5, 10, 11]
     # ---- oracle greedy path over the same prompt ----
     H, I, L, HQ, HKV, D, V = [int(x) for x in d["geometry"]]
     om = _oracle_model(params, None)
