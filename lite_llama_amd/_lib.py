@@ -187,6 +187,17 @@ def _grow_gemm_ws(key, device, floats: int, ints: int):
     return ws
 
 
+def gemm_scratch_error(device: torch.device) -> bool:
+    """True if any merge-counter buffer of ``device`` holds a non-zero word (synchronises): the buffers are all zero at
+    rest by construction, so a non-zero word is the sticky trace of a GEMM merge that gave up on a contributor (its tile was
+    written as NaN) -- csrc/gemm_w4_v3.hip."""
+    bad = False
+    for key, ws in _gemm_ws.items():
+        if key[0] == device.type and key[1] == device.index and ws[1].numel():
+            bad = bad or bool(ws[1].any().item())
+    return bad
+
+
 def gemm_workspace(device: torch.device, m: int, n: int, k: int):
     floats, ints = c_int64(0), c_int64(0)
     lib().ll_gemm_workspace(m, n, k, ctypes.byref(floats), ctypes.byref(ints))

@@ -81,6 +81,8 @@ struct V3Params {
   uint32_t w_bytes, s_bytes, x_bytes;
   int nblocks, chunks, total_units, upw, slots;
   int gt, gbase, grem, glead;  // tile-group split, see v3_plan
+  int err_idx;  // index of the launch's error word in `counters` (just past the merge counters)
+  uint32_t chunks_magic, gt_magic, upw_magic;  // ceil(2^32 / d): x / d = umulhi(x, magic) for the unit / workgroup indices of a launch (< 2^20)
   int gshift;                  // log2(group_size / 128)
   int epi;                     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu;  2: fp32 split-K partials [slot][m][n]
 #ifdef V3_TIMELINE
@@ -387,6 +389,22 @@ struct V3Ops {  // everything a consumer wave needs for one unit
   f16x8 a[4][MT];
 };
 
+#ifndef V3_WIDE_STORES
+#define V3_WIDE_STORES 1
+#endif
+#ifndef V3_MAGIC_DIV
+#define V3_MAGIC_DIV 1
+#endif
+__device__ __forceinline__ int v3_div(int x, uint32_t magic, int d) {
+#if V3_MAGIC_DIV
+  (void)d;
+  return magic ? (int)__umulhi((uint32_t)x, magic) : x;  // magic 0: d = 1
+#else
+  (void)magic;
+  return (int)((uint32_t)x / (uint32_t)d);
+#endif
+}
+
 template <int MT, int NF>
 __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgemm3_kernel(const V3Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
@@ -398,7 +416,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   V3_TLC(61)
   int ub, ue;
   if (p.gt) {
-    const int gtile = (int)blockIdx.x / p.gt, j = (int)blockIdx.x - gtile * p.gt;
+    const int gtile = v3_div((int)blockIdx.x, p.gt_magic, p.gt), j = (int)blockIdx.x - gtile * p.gt;
     const int lo = j * p.gbase + (j < p.grem ? j : p.grem);
     ub = gtile * chunks + lo;
     ue = j == p.gt - 1 ? (gtile + 1) * chunks : ub + p.gbase + (j < p.grem ? 1 : 0);
@@ -409,8 +427,8 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   }
   if (ub >= ue) return;
   const int cnt = ue - ub;
-  const int tA = (int)((uint32_t)ub / (uint32_t)chunks), cA = ub - tA * chunks;
-  const int tZ = (int)((uint32_t)(ue - 1) / (uint32_t)chunks), cZ = (ue - 1) - tZ * chunks;
+  const int tA = v3_div(ub, p.chunks_magic, chunks), cA = ub - tA * chunks;
+  const int tZ = v3_div(ue - 1, p.chunks_magic, chunks), cZ = (ue - 1) - tZ * chunks;
   int LT = 0, LH = cnt;  // a range inside one tile runs as a single "head" segment
   if (tA != tZ) {
     LT = (cZ != chunks - 1) ? cZ + 1 : 0;
@@ -475,7 +493,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   // [c_lo, c_hi] this workgroup has just summed into v0 (and v1) -- k-halves already added.
   auto flush = [&](f32x16& v0, f32x16& v1, auto nm_tag, int mt0, int t, int f, int c_lo, int c_hi) {
     constexpr int NM = decltype(nm_tag)::value;
-    const int w0 = p.gt ? t * p.gt : (int)((uint32_t)(t * chunks) / (uint32_t)p.upw);  // first contributor of the tile
+    const int w0 = p.gt ? t * p.gt : v3_div(t * chunks, p.upw_magic, p.upw);  // first contributor of the tile
     const int slot = (int)blockIdx.x - w0;
     const int blk = t * NF + f;  // 128-row block
     auto vsel = [&](int i) -> f32x16& { return i == 0 ? v0 : v1; };
@@ -495,6 +513,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       }
       return;
     }
+    bool poison = false;
     int32_t* ctr = &p.counters[(blk * 4 + ng) * 2 + mt0];
     auto slab = [&](int sq, int mt) { return p.workspace + ((((int64_t)blk * p.slots + sq) * 4 + ng) * 2 + mt) * V3_FRAG; };
     if (c_hi != chunks - 1) {
@@ -518,20 +537,31 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     }
     if (c_lo != 0) {
       // owner: chunks [0, c_lo) were summed by the `slot` lower-numbered contributors
+      bool arrived = false;
       for (int spin = 0; spin < V3_SPIN_LIMIT; ++spin) {
         int seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if constexpr (NM == 2) {
           const int s1 = __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           seen = seen < s1 ? seen : s1;
         }
-        if (__builtin_amdgcn_readfirstlane(seen) >= c_lo) break;
+        if (__builtin_amdgcn_readfirstlane(seen) >= c_lo) {
+          arrived = true;
+          break;
+        }
         __builtin_amdgcn_s_sleep(4);
-        // A contributor that has not delivered after ~10 s is not coming (its workgroup was never resident, or died):
-        // abort the launch -- the host sees a launch failure at its next synchronisation -- rather than sum what is
-        // there and leave the counters non-zero for the next launch.
-        if (spin == V3_SPIN_LIMIT - 1) __builtin_trap();
       }
-      if (lane < NM) __hip_atomic_store(ctr + lane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      if (arrived) {
+        if (lane < NM) __hip_atomic_store(ctr + lane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+      } else {
+        // A contributor that has not delivered after ~10 s of polling is not coming (its workgroup was never resident, or
+        // died).  Never a silent partial sum: the tile is written as NaN -- the poison reaches the logits --
+        // and the merge counters are LEFT non-zero, plus the launch's error word (counters[err_idx]): the counter buffer is
+        // all zero at rest by construction, so "any non-zero word after a synchronisation" is the sticky error the host
+        // checks (DecodeEngine._check_device_errors, _lib.gemm_scratch_error).  (A __builtin_trap() here cost the kernel two
+        // user SGPRs for the queue pointer and 15-25 % of its speed through spills in the unit loop: measured, removed.)
+        if (lane == 0) __hip_atomic_store(p.counters + p.err_idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+        poison = true;
+      }
       V3_TL(52)
       // slabs were written through (sc1) before their counter: coherent (sc1) loads, no acquire fence.
       // Sixteen loads in flight per round trip (4 slabs x 1 batch half or 2 x 2); the tail of the last round is
@@ -573,11 +603,23 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     }
     V3_TL(53)
     const bool has_bias = p.bias != nullptr;
+    // Output stores (round 3): a lane holds, for its batch row, the rows 8g + 4h .. + 3 of the wave's 32 (g = 0..3) -- four
+    // separate 8-byte pieces (4 bytes after swiglu).  Lanes nl and nl + 32 (h = 0 / 1) hold the interleaving pieces of the
+    // SAME batch row: one v_permlane32_swap per register hands lane h = 0 both halves of groups 0, 1 and lane h = 1 both
+    // halves of groups 2, 3, so every lane writes 16 contiguous bytes per store (4x fewer, 2-4x wider store instructions:
+    // the tail of the fused gate|up launch was store-issue bound).
+    auto swap32 = [](uint32_t& a, uint32_t& b) {  // lanes h = 1 of `a` <-> lanes h = 0 of `b`
+      const auto r = __builtin_amdgcn_permlane32_swap(a, b, false, false);
+      a = r[0];
+      b = r[1];
+    };
 #pragma unroll
     for (int i = 0; i < NM; ++i) {
       const f32x16& v = vsel(i);
       const int64_t mrow = nl + (mt0 + i) * 32;
-      if (mrow >= p.m) continue;
+      const bool row_ok = mrow < p.m;
+      uint32_t lo[4], hi[4];  // per g: fp16 pairs (o0, o1), (o2, o3)
+      uint32_t sw[4];         // per g: swiglu pair
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
         const int64_t nn = (int64_t)blk * V3_BN + ng * 32 + 8 * g + 4 * h;
@@ -586,8 +628,10 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         for (int e = 0; e < 4; ++e) {
           float fv = v[4 * g + e];
           if (has_bias) fv += f16_bits_to_f32(p.bias[nn + e]);
-          o[e] = f32_to_f16_bits(fv);
+          o[e] = poison ? (uint16_t)0x7e00 : f32_to_f16_bits(fv);
         }
+        lo[g] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
+        hi[g] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
         if (p.epi) {
           // weight rows 2j / 2j+1 are gate_j / up_j: both land in this lane.  Same arithmetic as the
           // stand-alone kernels: the two GEMM outputs rounded to fp16, then silu(g) * u in fp32.
@@ -595,12 +639,33 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
           const float g1 = f16_bits_to_f32(o[2]), u1 = f16_bits_to_f32(o[3]);
           const uint32_t s0 = f32_to_f16_bits(g0 * ll_sigmoidf(g0) * u0);
           const uint32_t s1 = f32_to_f16_bits(g1 * ll_sigmoidf(g1) * u1);
-          *reinterpret_cast<uint32_t*>(p.out + mrow * (p.n >> 1) + (nn >> 1)) = s0 | (s1 << 16);
-        } else {
-          uint2 pk;
-          pk.x = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
-          pk.y = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
-          *reinterpret_cast<uint2*>(p.out + mrow * p.n + nn) = pk;
+          sw[g] = s0 | (s1 << 16);
+        }
+      }
+      const int64_t n0 = (int64_t)blk * V3_BN + ng * 32 + 16 * h;  // first of the 16 rows this lane stores after the swap
+#if !V3_WIDE_STORES
+      if (row_ok) {
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          const int64_t nn = (int64_t)blk * V3_BN + ng * 32 + 8 * g + 4 * h;
+          if (p.epi) *reinterpret_cast<uint32_t*>(p.out + mrow * (p.n >> 1) + (nn >> 1)) = sw[g];
+          else *reinterpret_cast<uint2*>(p.out + mrow * p.n + nn) = uint2{lo[g], hi[g]};
+        }
+      }
+      continue;
+#endif
+      if (p.epi) {
+        swap32(sw[0], sw[2]);
+        swap32(sw[1], sw[3]);
+        if (row_ok) *reinterpret_cast<u32x4*>(p.out + mrow * (p.n >> 1) + (n0 >> 1)) = u32x4{sw[0], sw[2], sw[1], sw[3]};
+      } else {
+        swap32(lo[0], lo[2]);
+        swap32(hi[0], hi[2]);
+        swap32(lo[1], lo[3]);
+        swap32(hi[1], hi[3]);
+        if (row_ok) {
+          *reinterpret_cast<u32x4*>(p.out + mrow * p.n + n0) = u32x4{lo[0], hi[0], lo[2], hi[2]};
+          *reinterpret_cast<u32x4*>(p.out + mrow * p.n + n0 + 8) = u32x4{lo[1], hi[1], lo[3], hi[3]};
         }
       }
     }
@@ -940,7 +1005,7 @@ extern "C" int ll_w4a16_v3_workspace(int64_t m, int64_t n, int64_t k, int64_t* f
     const int64_t f = (int64_t)pl.nblocks * pl.nf * pl.slots * V3_SLAB;
     if (floats && f > *floats) *floats = f;
   }
-  if (ints) *ints = n / V3_BN * 8;
+  if (ints) *ints = n / V3_BN * 8 + 1;  // merge counters + the error word
   return LL_OK;
 }
 
@@ -973,6 +1038,13 @@ extern "C" int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* w
   p.nblocks = pl.nblocks; p.chunks = pl.chunks; p.total_units = pl.total_units; p.upw = pl.upw; p.slots = pl.slots;
   p.gt = pl.gt; p.gbase = pl.gbase; p.grem = pl.grem; p.glead = pl.glead;
   p.epi = epilogue;
+  auto magic = [](int d) { return d > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u; };
+  // umulhi(x, ceil(2^32 / d)) == x / d for x * d < 2^32 (x: unit / workgroup indices); d == 1 is handled by the guard below
+  if ((int64_t)pl.total_units * (pl.chunks > pl.upw ? pl.chunks : pl.upw) >= (1ll << 31)) return LL_ERR_SHAPE;
+  p.err_idx = (int)(n / V3_BN * 8);
+  p.chunks_magic = magic(pl.chunks);
+  p.gt_magic = magic(pl.gt);
+  p.upw_magic = magic(pl.upw);
 #ifdef V3_TIMELINE
   p.tlwave = getenv("LL_GEMM3_TL_WAVE") ? atoi(getenv("LL_GEMM3_TL_WAVE")) : 0;
   p.tl = getenv("LL_GEMM3_TIMELINE") ? (unsigned long long*)strtoull(getenv("LL_GEMM3_TIMELINE"), nullptr, 16) : nullptr;

@@ -16,6 +16,8 @@ from __future__ import annotations
 
 from dataclasses import dataclass, field
 
+import os
+
 import torch
 
 from .. import _lib as L
@@ -351,6 +353,9 @@ class DecodeEngine:
 
         if ps._ONESHOT is not None:
             ps.check_collective_errors()
+        if L.gemm_scratch_error(torch.device(self.device)):
+            raise RuntimeError("a split-K GEMM merge gave up waiting for a contributor workgroup: its output tile was poisoned "
+                               "with NaN and the merge counters are not zero at rest")
         if self.paged:
             err = self.pool.error
             if err:
