@@ -243,6 +243,16 @@ int ll_w8a8_matmul(void* out, const int8_t* qa, const float* a_scale, const int8
                    int64_t qw_stride_n, int32_t* acc_out /* nullable: raw int32 accumulators [M,N] */,
                    int32_t* workspace, int32_t* counters, void* stream);
 
+/* ---- unquantised 16-bit linears at decode shapes (models/quantization/methods/unquantized.py:21-22 and the lm_head of
+ * models/base.py:486-489: torch F.linear, i.e. a vendor GEMM, in the reference) -------------------------------------------
+ * out[m, n] = x[m, :] . w[n, :] (+ bias[n]); x [m, k] (row stride x_stride elements), w [n, k] (row stride w_stride), bias,
+ * out [m, n] all fp16 or all bf16; fp32 accumulation, one rounding.  Split-K weight streaming (gemm_w8_skinny.hip without
+ * the dequantisation): `partials` = ll_gemm_workspace(m, n, k) floats of scratch.  Serves m <= 64, k % 64 == 0, n % 4 == 0,
+ * 16-byte aligned rows; returns 1 when the launches were issued, 0 when the shape is not served (the caller keeps its
+ * library GEMM), < 0 on error. */
+int ll_dense16_matmul(void* out, const void* x, const void* w, const void* bias, int64_t m, int64_t n, int64_t k,
+                      int64_t x_stride, int64_t w_stride, int dtype, void* partials, void* stream);
+
 /* ---- a11: fused_moe pieces  (kernels/fused_moe.py:45-99, :236-292, :298-335) ---
  * moe_align_block_size: sorted_ids int32[num_slots + E*(block-1)] (sentinel =
  * num_slots), expert_ids int32[ceil(max_padded/block)], num_post int32[1]. */

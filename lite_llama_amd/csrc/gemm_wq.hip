@@ -654,6 +654,7 @@ extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweig
 
 // the decode-shaped 8-bit engine (gemm_w8_skinny.hip): served shapes leave S fp32 / int32 partial planes in the workspace
 extern "C" int64_t ll_dense8_partial_words(int64_t m, int64_t n, int64_t k);
+extern "C" int64_t ll_dense16_partial_words(int64_t m, int64_t n, int64_t k);
 extern "C" int ll_dense8_try(void* out, const void* x, const void* w, const float* scales, const float* a_scale,
                              const void* bias, int32_t* acc_out, int64_t m, int64_t n, int64_t k, int group_n,
                              int64_t group_k, int wfmt, int64_t x_stride, int64_t w_stride, int64_t s_stride_n,
@@ -670,6 +671,8 @@ extern "C" int ll_gemm_workspace(int64_t m, int64_t n, int64_t k, int64_t* works
   ll_w4a16_v3_workspace(m, n, k, &f2, &c2);
   const int64_t f3 = ll_dense8_partial_words(m, n, k);
   if (f3 > f) f = f3;
+  const int64_t f4 = ll_dense16_partial_words(m, n, k);
+  if (f4 > f) f = f4;
   if (workspace_floats) *workspace_floats = f > f2 ? f : f2;
   if (counter_ints) *counter_ints = c > c2 ? c : c2;
   return LL_OK;

@@ -345,3 +345,41 @@ def smoothquant_matmul(
     if _return_int32:
         return out, acc, qa, a_scale
     return out
+
+
+def dense16_wins(m: int, n: int, k: int) -> bool:
+    """Where the hand-written kernel measured FASTER than the library GEMM on MI355X (benchmarks/dense16_shapes.py, round 3,
+    same box, hipGraph replays over rotating weights): batches of <= 32 rows with a long contraction (Qwen2.5-1.5B down
+    8960 -> 1536: 20.4 vs 21.8 us) or a very wide output written straight from the single split (lm_head 151936 x 1536: 94.9
+    vs 104.1 us).  Elsewhere hipBLASLt is ahead (7 vs 9 us on the small projections, 211 vs 230 us on the 7B lm_head at
+    batch 64) and stays -- a plain library GEMM, the reference's own choice for these layers."""
+    return m <= 32 and (k >= 4096 or n >= 32768)
+
+
+def dense16_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None, policy: str = "always"):
+    """Extension: ``F.linear(x, weight, bias)`` for decode shapes (<= 64 rows) of an UNQUANTISED fp16 / bf16 weight
+    ``[N, K]`` on the split-K weight-streaming kernel (csrc/gemm_w8_skinny.hip, 16-bit form) -- the reference's
+    ``UnquantizedLinearMethod.apply`` / lm_head are torch's library GEMM.  Returns ``None`` when the call is not served
+    (other shapes, dtypes, CPU tensors, ``LL_DENSE16_OFF``) or -- ``policy="auto"`` -- where the library measured faster
+    (:func:`dense16_wins`): the caller keeps ``F.linear``."""
+    if policy == "auto" and x.shape[-1] and not dense16_wins(x.numel() // x.shape[-1], weight.shape[0], weight.shape[1]):
+        return None
+    if (not x.is_cuda or x.dtype not in (torch.float16, torch.bfloat16) or weight.dtype != x.dtype or weight.dim() != 2
+            or os.environ.get("LL_DENSE16_OFF")):
+        return None
+    n, k = weight.shape
+    if x.shape[-1] != k or (bias is not None and (bias.dtype != x.dtype or bias.numel() != n)):
+        return None
+    a = _flatten(x, k)
+    m = a.shape[0]
+    if m < 1 or m > 64 or k % 64 or n % 4 or weight.stride(1) != 1 or weight.stride(0) % 8 or weight.data_ptr() % 16:
+        return None
+    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
+    ws, _ = L.gemm_workspace(x.device, m, n, k)
+    rc = L.lib().ll_dense16_matmul(out.data_ptr(), a.data_ptr(), weight.data_ptr(), L.ptr(bias), m, n, k, a.stride(0),
+                                   weight.stride(0), L.dtype_code(x.dtype), ws.data_ptr(), L.stream_ptr())
+    if rc == 0:
+        return None
+    if rc < 0:
+        L.check(rc, "dense16_matmul")
+    return out.reshape(*x.shape[:-1], n)

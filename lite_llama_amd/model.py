@@ -455,6 +455,11 @@ class CausalLM(nn.Module):
         hidden_states, _ = add_norm(hidden_states, residual, self.norm_weight, self.eps)
         if logits_rows is not None:
             hidden_states = hidden_states.view(-1, hidden_states.shape[-1])[logits_rows]
+        if hidden_states.is_cuda and not os.environ.get("LL_LM_HEAD_LIBRARY"):
+            from .kernels.quantization import dense16_linear
+            logits = dense16_linear(hidden_states, self.lm_head_weight, policy="auto")
+            if logits is not None:
+                return logits
         return F.linear(hidden_states, self.lm_head_weight)
 
     @torch.no_grad()

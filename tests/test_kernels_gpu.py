@@ -903,3 +903,30 @@ def test_moe_route_topk_matches_the_reference_router_tail(T, E, k, norm, dt):
     assert ids2.cpu()[1].tolist() == list(range(k))
     assert ids2.cpu()[0].tolist() == [E // 2] + [e for e in range(E) if e != E // 2][: k - 1]
     close(w2.float().sum(-1), torch.ones(2), 2e-3 if dt == torch.float16 else 1.6e-2)
+
+
+@pytest.mark.parametrize("M,N,K_", [(1, 128, 64), (7, 516, 192), (32, 1536, 8960), (32, 4100, 1536), (64, 2048, 1536),
+                                    (33, 132, 4096), (64, 151936 // 8, 1536)])
+@pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("with_bias", [False, True])
+def test_dense16_linear_matches_fp32_reference(M, N, K_, dt, with_bias):
+    """The hand-written 16-bit weight-streaming GEMM (csrc/gemm_w8_skinny.hip, 16-bit form; the reference's counterpart is
+    torch's F.linear, methods/unquantized.py:21-22) against the plain fp32 product of the same 16-bit values, rounded
+    once: single-split direct epilogue and split-K + finish, ragged N tiles, both batch-half forms, fp16 and bf16."""
+    from lite_llama_amd.kernels.quantization import dense16_linear
+
+    g = torch.Generator().manual_seed(M * 7 + N + K_)
+    x = (torch.randn(M, K_, generator=g) * 0.5).to(dt)
+    w = (torch.randn(N, K_, generator=g) * 0.05).to(dt)
+    b = (torch.randn(N, generator=g) * 0.1).to(dt) if with_bias else None
+    ref = x.float() @ w.float().T
+    if b is not None:
+        ref = ref + b.float()
+    got = dense16_linear(x.to(DEV), w.to(DEV), None if b is None else b.to(DEV))
+    assert got is not None and got.dtype == dt and got.shape == (M, N)
+    tol = 2e-3 if dt == torch.float16 else 1.6e-2          # one rounding of the fp32 sum to the 16-bit type
+    close(got.float(), ref.to(dt).float(), tol)
+    # leading dimensions pass through; shapes outside the kernel are declined, not mis-served
+    assert dense16_linear(x.to(DEV).view(1, M, K_), w.to(DEV)).shape == (1, M, N)
+    assert dense16_linear(torch.zeros(65, K_, dtype=dt, device=DEV), w.to(DEV)) is None
+    assert dense16_linear(x.to(DEV), w.to(DEV).float()) is None
