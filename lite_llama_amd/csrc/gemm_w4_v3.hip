@@ -389,6 +389,9 @@ struct V3Ops {  // everything a consumer wave needs for one unit
   f16x8 a[4][MT];
 };
 
+#ifndef V3_PART_STORE
+#define V3_PART_STORE 0  // split-K partial planes: 0 plain stores, 1 write-through (sc1), 2 non-temporal -- A/B knob
+#endif
 #ifndef V3_WIDE_STORES
 #define V3_WIDE_STORES 1
 #endif
@@ -507,8 +510,16 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         if (mrow < p.m) {
           float* dst = reinterpret_cast<float*>(p.out) + ((int64_t)slot * p.m + mrow) * p.n + (int64_t)blk * V3_BN + ng * 32 + 4 * h;
 #pragma unroll
-          for (int g = 0; g < 4; ++g)
-            *reinterpret_cast<f32x4*>(dst + 8 * g) = f32x4{v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+          for (int g = 0; g < 4; ++g) {
+            const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
+#if V3_PART_STORE == 1
+            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + 8 * g), "v"(o) : "memory");
+#elif V3_PART_STORE == 2
+            asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst + 8 * g), "v"(o) : "memory");
+#else
+            *reinterpret_cast<f32x4*>(dst + 8 * g) = o;
+#endif
+          }
         }
       }
       return;
