@@ -21,12 +21,24 @@
 // 0 of the sticky error word (flags[2 * B * world]) and writes NaN over its slice of the tensor -- the poison reaches the
 // logits of this and every later step -- and the callers (DecodeEngine.decode, bench.py, parallel_state.oneshot_error)
 // read the word when they synchronise and raise.  (Round 2 summed what had arrived and went on.)
+#include <stdlib.h>
+
 #include "common.h"
 
 namespace {
 
 constexpr int kMaxWorld = 8;
-constexpr int kSpinLimit = 1 << 23;  // ~10 s of polling: ranks may reach their FIRST collective seconds apart (model build)
+constexpr int kSpinLimitDefault = 1 << 23;  // ~10 s of polling: ranks may reach their FIRST collective seconds apart (model build)
+// LL_TP_SPIN_LOG2 (read once): log2 of the polls a rank waits for a peer's flag.  Only oversubscribed debugging set-ups need
+// it (several ranks time-slicing ONE GPU: the spinning ranks burn their polls while the late rank gets 1/N of the device).
+static int tp_spin_limit() {
+  static const int v = [] {
+    const char* e = getenv("LL_TP_SPIN_LOG2");
+    const int l = e ? atoi(e) : 0;
+    return l >= 10 && l <= 30 ? 1 << l : kSpinLimitDefault;
+  }();
+  return v;
+}
 
 struct PeerTable {
   const uint16_t* stage[kMaxWorld];
@@ -36,7 +48,8 @@ struct PeerTable {
 template <int DT>
 __global__ __launch_bounds__(256) void allreduce_oneshot_kernel(uint16_t* __restrict__ inout, int64_t count, PeerTable peers,
                                                                 int rank, int world, int64_t stage_elems,
-                                                                int32_t* __restrict__ epoch, int32_t* __restrict__ done) {
+                                                                int32_t* __restrict__ epoch, int32_t* __restrict__ done,
+                                                                int kSpinLimit) {
   const int nb = gridDim.x, b = blockIdx.x, tid = threadIdx.x;
   const int e = __hip_atomic_load(epoch, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT) + 1;
   const int p = e & 1;
@@ -119,7 +132,7 @@ template <int DT>
 __global__ __launch_bounds__(256) void allreduce_norm_partials_kernel(
     uint16_t* __restrict__ y, const float* __restrict__ part, int s_count, uint16_t* __restrict__ resid,
     const uint16_t* __restrict__ w, int64_t rows, int n, float eps, PeerTable peers, int rank, int world,
-    int64_t stage_elems, int32_t* __restrict__ epoch, int32_t* __restrict__ done) {
+    int64_t stage_elems, int32_t* __restrict__ epoch, int32_t* __restrict__ done, int kSpinLimit) {
   constexpr int VMAX = 4;  // n <= 8192: up to 4 x 256 pieces of 8 values per row
   __shared__ float red[4];
   __shared__ int failed;
@@ -298,10 +311,10 @@ extern "C" int ll_tp_allreduce_oneshot(void* inout, int64_t count, int dtype, co
   hipStream_t st = (hipStream_t)stream;
   if (dtype == LL_F16)
     allreduce_oneshot_kernel<LL_F16><<<blocks, 256, 0, st>>>((uint16_t*)inout, count, t, rank, world, stage_elems,
-                                                              epoch_done, epoch_done + 1);
+                                                              epoch_done, epoch_done + 1, tp_spin_limit());
   else
     allreduce_oneshot_kernel<LL_BF16><<<blocks, 256, 0, st>>>((uint16_t*)inout, count, t, rank, world, stage_elems,
-                                                               epoch_done, epoch_done + 1);
+                                                               epoch_done, epoch_done + 1, tp_spin_limit());
   return LL_LAUNCH_CHECK();
 }
 
@@ -331,10 +344,10 @@ extern "C" int ll_tp_allreduce_norm_partials(void* y, const float* partials, int
   if (dtype == LL_F16)
     allreduce_norm_partials_kernel<LL_F16><<<blocks, 256, 0, st>>>((uint16_t*)y, partials, s_count, (uint16_t*)residual,
                                                                     (const uint16_t*)weight, rows, (int)n, eps, t, rank, world,
-                                                                    stage_elems, epoch_done, epoch_done + 1);
+                                                                    stage_elems, epoch_done, epoch_done + 1, tp_spin_limit());
   else
     allreduce_norm_partials_kernel<LL_BF16><<<blocks, 256, 0, st>>>((uint16_t*)y, partials, s_count, (uint16_t*)residual,
                                                                      (const uint16_t*)weight, rows, (int)n, eps, t, rank, world,
-                                                                     stage_elems, epoch_done, epoch_done + 1);
+                                                                     stage_elems, epoch_done, epoch_done + 1, tp_spin_limit());
   return LL_LAUNCH_CHECK();
 }

@@ -24,6 +24,9 @@ def _free_port():
 def _geometry(which="tp2"):
     from lite_llama_amd.model import tiny_geometry
 
+    if which == "tp4plan":  # 14 / 2 heads at TP = 4: each KV head on two ranks (4 + 3 query heads), six 128-groups -> 2, 2, 1, 1
+        return tiny_geometry(hidden_size=512, intermediate_size=768, num_layers=2, num_heads=14, num_kv_heads=2, head_dim=128,
+                             vocab_size=640, qkv_bias=True)
     if which == "tp8":  # Qwen2.5-7B's head layout (28 / 4 heads of 128) and an intermediate of twelve 128-groups: outside the
         # reference's rules at TP = 8 -> extension plan (4 + 3 query heads per rank, KV heads on two ranks, 2,2,2,2,1,1,1,1 groups)
         return tiny_geometry(hidden_size=512, intermediate_size=1536, num_layers=2, num_heads=28, num_kv_heads=4, head_dim=128,
@@ -43,6 +46,10 @@ def _run(which="tp2"):
     eng = DecodeEngine(model, max_batch=2, max_seq_len=32)
     g = torch.Generator().manual_seed(4)
     ids = torch.randint(0, 640, (2, 7), generator=g).cuda()
+    import torch.distributed as dist
+    if dist.is_available() and dist.is_initialized():
+        torch.cuda.synchronize()
+        dist.barrier()  # ranks sharing one GPU build their models seconds apart; the one-shot kernel's patience is ~10 s
     first = eng.prefill(ids, torch.tensor([7, 5], device="cuda"))
     grabbed = []
     orig = model.forward
@@ -58,17 +65,24 @@ def _run(which="tp2"):
     return first.cpu(), toks.cpu(), grabbed[0]
 
 
-def _worker(rank, world, port, q, which="tp2"):
+def _worker(rank, world, port, q, which="tp2", oneshot=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
     os.environ["LL_DIST_BACKEND"] = "gloo"
+    os.environ["LL_TP_SPIN_LOG2"] = "28"  # ranks time-slicing ONE GPU: the late rank gets 1 / N of the device while the others spin
     from lite_llama_amd.distributed import parallel_state as ps
 
     try:
         torch.cuda.set_device(0)
         ps.init_tensor_parallel(rank, world, master_port=port)
         assert ps.get_tp_world_size() == world
+        if oneshot:  # the collective of the real multi-GPU run: one-shot kernel over IPC mappings, fused with the norms
+            import torch.distributed as dist
+            ps.enable_oneshot_all_reduce(2 * 7 * 512)
+            dist.barrier()
         first, toks, logits = _run(which)
+        if oneshot:
+            assert ps.oneshot_error() == 0
         q.put((rank, True, first.numpy(), (toks.numpy(), logits.numpy())))  # by value: a shared-memory tensor handle dies with the worker
     except Exception as exc:  # pragma: no cover
         import traceback
@@ -108,19 +122,22 @@ def test_tp2_sharded_int4_decode_matches_tp1():
 
 
 @pytest.mark.gpu
-def test_tp8_extension_plan_int4_decode_matches_tp1():
+@pytest.mark.parametrize("world,which,oneshot", [(8, "tp8", False), (4, "tp4plan", True)])
+def test_tp8_extension_plan_int4_decode_matches_tp1(world, which, oneshot):
     """EIGHT ranks on the one GPU, a geometry the reference refuses at TP = 8 (28 / 4 heads, an intermediate that does not
     divide into eight group-aligned parts): the extension plan of distributed/partition.py -- 4 + 3 query heads per rank,
     every KV head replicated on two ranks (each rank's pool holds ONE KV head), whole 128-groups per rank -- decodes the
-    tokens of the unsharded model; the first decode step's logits agree at 1e-2 (sixteen fp16 partial sums per layer)."""
+    tokens of the unsharded model; the first decode step's logits agree at 1e-2 (sixteen fp16 partial sums per layer).
+    ``oneshot``: the all-reduces on the one-shot peer-to-peer kernel, the decode step's row-parallel projections through the
+    fused partials + all-reduce + add-and-normalise launch (what ``bench.py --gpus 8`` runs), on uneven shards -- with four
+    ranks (14 / 2 heads, six groups): eight spinning ranks time-slicing one GPU starve each other past any patience."""
     from lite_llama_amd.distributed.partition import make_plan
 
-    assert not make_plan(28, 4, 128, 1536, 8).uniform
-    world = 8
+    assert not make_plan(28, 4, 128, 1536, 8).uniform and not make_plan(14, 2, 128, 768, 4).uniform
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
-    procs = [ctx.Process(target=_worker, args=(r, world, port, q, "tp8")) for r in range(world)]
+    procs = [ctx.Process(target=_worker, args=(r, world, port, q, which, oneshot)) for r in range(world)]
     for p in procs:
         p.start()
     results = sorted((q.get(timeout=600) for _ in procs), key=lambda r: r[0])
@@ -129,7 +146,7 @@ def test_tp8_extension_plan_int4_decode_matches_tp1():
     for rank, ok, a, b in results:
         assert ok is True, (rank, a)
     t = torch.from_numpy
-    ref_first, ref_toks, ref_logits = _run("tp8")  # tp = 1 in this process
+    ref_first, ref_toks, ref_logits = _run(which)  # tp = 1 in this process
     for rank, _, first, (toks, logits) in results:
         assert torch.equal(t(first), t(results[0][2])) and torch.equal(t(toks), t(results[0][3][0]))
         assert torch.equal(t(logits), t(results[0][3][1]))
