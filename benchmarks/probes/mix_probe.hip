@@ -17,14 +17,29 @@ __global__ __launch_bounds__(768) void mix(const unsigned char* w, const unsigne
   if (wv >= 4) {
     typedef int i32x4 __attribute__((ext_vector_type(4)));
     i32x4 acc = {0, 0, 0, 0};
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    f16v c0 = {0}, c1 = {0};
     for (int u = 0; u < units; ++u) {
       if (CONS & 1) {
 #pragma unroll
         for (int j = 0; j < 9; ++j) acc ^= *(const i32x4*)(lds + ((u * 9 + j + wv) % 120) * 1024 + lane * 16);
       }
+      if (CONS & 4) {  // the consumers' arithmetic: 8 MFMA 32x32x16 + ~52 packed VALU per unit and wave, operands from acc
+#pragma unroll
+        for (int j = 0; j < 4; ++j) {
+          i32x4 w = acc;
+#pragma unroll
+          for (int r = 0; r < 13; ++r) w.x = (w.x * 3 + w.y) ^ (w.z >> 1);
+          w.y ^= w.x;
+          const h8 a = __builtin_bit_cast(h8, w), b = __builtin_bit_cast(h8, acc);
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+        }
+      }
       if (CONS & 2) asm volatile("s_barrier" ::: "memory");
     }
-    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678) out[0] = 1;
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678 || c0[0] + c1[3] == 1.2345f) out[0] = 1;
     return;
   }
   if (wv < 2) {
@@ -90,6 +105,10 @@ int main() {
   run("both d3 + LDS reads by 8 waves", mix<3, 3, 1, 1>, 64, 768);
   run("both d3 + barrier per unit (12 waves)", mix<3, 3, 1, 2>, 64, 768);
   run("both d3 + LDS reads + barrier", mix<3, 3, 1, 3>, 64, 768);
+  run("both d3 + LDS reads + barrier + MFMA/VALU", mix<3, 3, 1, 7>, 64, 768);
+  run("both d3 + MFMA/VALU + barrier (no LDS reads)", mix<3, 3, 1, 6>, 64, 768);
+  run("weights d3 + LDS + barrier + MFMA/VALU", mix<3, 1, 1, 7>, 64, 768);
+  run("no DMA: LDS + barrier + MFMA/VALU", mix<3, 0, 1, 7>, 64, 768);
   run("weights only d3 + LDS reads + barrier", mix<3, 1, 1, 3>, 64, 768);
   run("both d3 + LDS reads + barrier, 16 units", mix<3, 3, 1, 3>, 16, 768);
   run("both           depth 3, 16 units", mix<3, 3, 1>, 16);

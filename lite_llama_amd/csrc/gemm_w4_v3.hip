@@ -41,7 +41,10 @@
 // one activation tile feeds two weight blocks): weights 4 slots / 3 ahead, activations 3 slots / 2 ahead, the
 // consumers read a unit's operands at its start (a step is twice as long, the LDS latency is paid once).
 template <int NF> struct V3Ring;
-template <> struct V3Ring<1> { static constexpr int RW = 6, DW = 5, RX = 4, DX = 3, RA = 1; };
+#ifndef V3_RW1
+#define V3_RW1 6
+#endif
+template <> struct V3Ring<1> { static constexpr int RW = V3_RW1, DW = V3_RW1 - 1, RX = 4, DX = 3, RA = 1; };
 template <> struct V3Ring<2> { static constexpr int RW = 4, DW = 3, RX = 3, DX = 2, RA = 0; };
 #define V3_MAX_SLOTS 12
 #define V3_FRAG 1024                  // floats of one (row group, batch half) partial: 16 per lane
@@ -97,9 +100,12 @@ struct V3Params {
 #ifdef V3_TIMELINE
 #define V3_TL(IDX) if (p.tl && lane == 0 && wv == p.tlwave) p.tl[(size_t)blockIdx.x * 64 + (IDX)] = __builtin_amdgcn_s_memrealtime();
 #define V3_TLC(IDX) if (p.tl && lane == 0 && wv == p.tlwave) p.tl[(size_t)blockIdx.x * 64 + (IDX)] = __builtin_amdgcn_s_memtime();
+// (timeline builds) pin the step's MFMAs BEFORE the stamp that follows: the accumulators are made opaque to the scheduler
+#define V3_TL_FENCE(CUR) asm volatile("" : "+v"(acc0), "+v"(acc1));
 #else
 #define V3_TL(IDX)
 #define V3_TLC(IDX)
+#define V3_TL_FENCE(CUR)
 #endif
 
 __device__ __forceinline__ uint32_t v3_pk_add(uint32_t a, uint32_t b) {
@@ -236,8 +242,10 @@ __device__ __forceinline__ void v3_dma_w(uint32_t dw, uint32_t ds, const void* w
       "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %13" V3_W_POLICY "\n\t"
       "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %13" V3_W_POLICY "\n\t"
       "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %13" V3_W_POLICY "\n\t"
+#if !(defined(V3_ABLATE) && (V3_ABLATE & 512))  /* debug: no scale loads */
       "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %11, %14" V3_S_POLICY "\n\t"
       "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %12, %14" V3_S_POLICY "\n\t"
+#endif
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "s"(dw), "s"(dw + 1024), "s"(dw + 2048), "s"(dw + 3072), "s"(ds), "s"(ds + 256), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]),
@@ -290,11 +298,11 @@ template <int KIND, int NF>
 __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int cnt, int lane, int L) {
   using RG = V3Ring<NF>;
   using LD = V3Lds<NF>;
-  constexpr int OPS = KIND == 0 ? 6 * NF : 8;
+  constexpr int OPS = KIND == 0 ? (V3_ABL(512) ? 4 : 6) * NF : 8;
   constexpr int D = KIND == 0 ? RG::DW : RG::DX;
   constexpr int R = KIND == 0 ? RG::RW : RG::RX;
   constexpr int AHEAD = 1 + RG::RA;  // after barrier u the consumers may touch units <= u + AHEAD
-  static_assert(D - AHEAD <= 3 && D - AHEAD >= 1 && D <= R - 1 && 3 * OPS <= 63, "ring depth");
+  static_assert(D - AHEAD <= 4 && D - AHEAD >= 1 && D <= R - 1 && (D - AHEAD) * OPS <= 63, "ring depth");
   uint32_t voff[8];
   if constexpr (KIND == 0) {
 #pragma unroll
@@ -802,6 +810,34 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     }
   };
 
+  // Round 3 experiment (V3_INTERLEAVE = 1, 128-row tiles; OFF by default): ONE instruction stream per unit in which the next
+  // unit's operand reads and the step's scalar bookkeeping sit BETWEEN the current unit's MFMAs instead of in front of / behind
+  // them.  In-kernel cycle stamps of a consumer wave: issuing the ten reads up front 250 - 330 cycles (eight waves hit the LDS
+  // pipe at once), the MFMAs 510 (= the matrix pipe's bound), bookkeeping after the barrier 300 - 400, waiting at the barrier
+  // 250 - 520 -- the consumers WAIT for the loaders (issue 0.56 us + landing wait 0.24 us per unit), so shortening the consumer
+  // stream buys nothing: measured 17.9 vs 17.35 us on `down` (slightly worse), +-0 on q|k|v and o.
+#ifndef V3_INTERLEAVE
+#define V3_INTERLEAVE 0
+#endif
+  auto fused_step = [&](const V3Ops<MT, NF>& cur, V3Ops<MT, NF>& nxt, int wbase, int xbase, auto&& between) {
+    const unsigned char* wb = lds + wbase;
+    const unsigned char* xb = lds + xbase;
+    nxt.w[0] = *reinterpret_cast<const u32x4*>(wb + w_off);
+    nxt.s[0] = *reinterpret_cast<const u32x2*>(wb + s_off);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t word = j == 0 ? cur.w[0].x : j == 1 ? cur.w[0].y : j == 2 ? cur.w[0].z : cur.w[0].w;
+      const f16x8 wfrag = v3_dequant(word, cur.s[0].x, cur.s[0].y, magic);
+      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, cur.a[j][0], acc0, 0, 0, 0);
+      if constexpr (MT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, cur.a[j][1], acc1, 0, 0, 0);
+      __builtin_amdgcn_sched_barrier(0);
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) nxt.a[j][mt] = *reinterpret_cast<const f16x8*>(xb + x_off[j] + mt * 32 * 256);
+      if (j == 1) between();
+      __builtin_amdgcn_sched_barrier(0);
+    }
+  };
+
   V3Walk cc = v3_walk_begin(q);
   int seg_lo = cc.c;
   int wnext = LD::OFF_W + RG::RA * LD::W_SLOT, xnext = LD::OFF_X + RG::RA * V3_X_SLOT;  // ring slots of the next unit to READ
@@ -833,21 +869,59 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   // its start.
 #define V3_STEP(CUR, NXT)                                                                   \
   {                                                                                         \
+    if (done == 5) { V3_TLC(44) }                                                           \
     read_ops(RG::RA ? NXT : CUR, wnext, xnext);                                             \
     __builtin_amdgcn_sched_barrier(0); /* keep the reads up here (hipcc sinks them to their use otherwise) */ \
+    if (done == 5) { V3_TLC(45) }                                                           \
     wnext = wnext + LD::W_SLOT == LD::OFF_W + RG::RW * LD::W_SLOT ? LD::OFF_W : wnext + LD::W_SLOT; \
     xnext = xnext + V3_X_SLOT == LD::OFF_X + RG::RX * V3_X_SLOT ? LD::OFF_X : xnext + V3_X_SLOT; \
     compute(CUR);                                                                           \
     if constexpr (!RG::RA) asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory"); /* the slot is free once the barrier is passed */ \
+    V3_TL_FENCE(CUR)                                                                        \
+    if (done == 5) { V3_TLC(46) }                                                           \
     v3_barrier();                                                                           \
+    if (done == 5) { V3_TLC(47) }                                                           \
     if (done < 40) { V3_TL(4 + done) }                                                      \
     if (pending) post_pending(); /* the previous segment's slab stores are a unit old */    \
     const bool se_ = V3_ABL(128) ? (done + 1 == cnt) : v3_walk_ends(cc);                    \
     if (se_) segment_end(cc.t, seg_lo, cc.c);                                               \
     if (!V3_ABL(128)) v3_walk_next(cc, q);                                                  \
     if (se_) seg_lo = cc.c;                                                                 \
+    if (done == 5) { V3_TLC(48) }                                                           \
     ++done;                                                                                 \
   }
+#if V3_INTERLEAVE && !defined(V3_ABLATE) && !defined(V3_TIMELINE)
+#define V3_FSTEP(CUR, NXT)                                                                  \
+  {                                                                                         \
+    bool se_ = false;                                                                       \
+    int t_ = 0, c_ = 0;                                                                     \
+    const int wb_ = wnext, xb_ = xnext;                                                     \
+    fused_step(CUR, NXT, wb_, xb_, [&]() { /* scalar bookkeeping, under the MFMAs */        \
+      wnext = wnext + LD::W_SLOT == LD::OFF_W + RG::RW * LD::W_SLOT ? LD::OFF_W : wnext + LD::W_SLOT; \
+      xnext = xnext + V3_X_SLOT == LD::OFF_X + RG::RX * V3_X_SLOT ? LD::OFF_X : xnext + V3_X_SLOT; \
+      se_ = v3_walk_ends(cc);                                                               \
+      t_ = cc.t;                                                                            \
+      c_ = cc.c;                                                                            \
+      v3_walk_next(cc, q);                                                                  \
+    });                                                                                     \
+    v3_barrier();                                                                           \
+    if (pending) post_pending();                                                            \
+    if (se_) {                                                                              \
+      segment_end(t_, seg_lo, c_);                                                          \
+      seg_lo = cc.c;                                                                        \
+    }                                                                                       \
+    ++done;                                                                                 \
+  }
+  if constexpr (RG::RA && NF == 1) {
+    if (done < cnt) for (;;) {
+      V3_FSTEP(opA, opB)
+      if (done >= cnt) break;
+      V3_FSTEP(opB, opA)
+      if (done >= cnt) break;
+    }
+  } else
+#undef V3_FSTEP_GUARD
+#endif
   if (done < cnt) for (;;) {
     V3_STEP(opA, opB)
     if (done >= cnt) break;
