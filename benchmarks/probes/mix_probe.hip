@@ -20,7 +20,9 @@ __global__ __launch_bounds__(768) void mix(const unsigned char* w, const unsigne
     typedef _Float16 h8 __attribute__((ext_vector_type(8)));
     typedef float f16v __attribute__((ext_vector_type(16)));
     f16v c0 = {0}, c1 = {0};
+    i32x4 prev = {1, 2, 3, 4};
     for (int u = 0; u < units; ++u) {
+      if (CONS & 8) prev = acc;  // software-pipelined: this unit's arithmetic uses the PREVIOUS unit's reads (the kernel's read-ahead)
       if (CONS & 1) {
 #pragma unroll
         for (int j = 0; j < 9; ++j) acc ^= *(const i32x4*)(lds + ((u * 9 + j + wv) % 120) * 1024 + lane * 16);
@@ -28,7 +30,7 @@ __global__ __launch_bounds__(768) void mix(const unsigned char* w, const unsigne
       if (CONS & 4) {  // the consumers' arithmetic: 8 MFMA 32x32x16 + ~52 packed VALU per unit and wave, operands from acc
 #pragma unroll
         for (int j = 0; j < 4; ++j) {
-          i32x4 w = acc;
+          i32x4 w = (CONS & 8) ? prev : acc;
 #pragma unroll
           for (int r = 0; r < 13; ++r) w.x = (w.x * 3 + w.y) ^ (w.z >> 1);
           w.y ^= w.x;
@@ -109,6 +111,9 @@ int main() {
   run("both d3 + MFMA/VALU + barrier (no LDS reads)", mix<3, 3, 1, 6>, 64, 768);
   run("weights d3 + LDS + barrier + MFMA/VALU", mix<3, 1, 1, 7>, 64, 768);
   run("no DMA: LDS + barrier + MFMA/VALU", mix<3, 0, 1, 7>, 64, 768);
+  run("both d3 + LDS + barrier + MFMA/VALU, read-ahead", mix<3, 3, 1, 15>, 64, 768);
+  run("no DMA: LDS + barrier + MFMA/VALU, read-ahead", mix<3, 0, 1, 15>, 64, 768);
+  run("no DMA: barrier + MFMA/VALU only", mix<3, 0, 1, 6>, 64, 768);
   run("weights only d3 + LDS reads + barrier", mix<3, 1, 1, 3>, 64, 768);
   run("both d3 + LDS reads + barrier, 16 units", mix<3, 3, 1, 3>, 16, 768);
   run("both           depth 3, 16 units", mix<3, 3, 1>, 16);
