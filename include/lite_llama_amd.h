@@ -225,6 +225,19 @@ int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* wpacked, con
                               const void* bias, int64_t m, int64_t n, int64_t k, int group_size,
                               int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,
                               void* stream);
+/* ll_skip_rmsnorm_partials + ll_w4a16_matmul_prepacked in ONE launch (decode step, TP = 1; no reference counterpart: the
+ * reference launches skip_rmsnorm, lite_llama/kernels/skip_rms_norm.py, then the projection): `x` [m][k] is an OUTPUT -- the
+ * normalised rows, produced inside the launch (workgroup r < m: row r, bit-identical to ll_skip_rmsnorm_partials(x,
+ * norm_partials, s_count, residual, norm_weight, m, k, eps)) while the weight stream already runs, and consumed by the
+ * launch's activation loaders behind a launch-wide gate (agent-scope release / acquire).  `residual` [m][k] is updated in
+ * place.  fp16; k <= 4096, k % 8 == 0, 1 <= s_count <= 12, the launch must have >= m workgroups (LL_ERR_SHAPE otherwise:
+ * use the two launches).  A gate that never opens sets the launch's sticky error word (ll_w4a16_v3_workspace's `ints`
+ * words are all zero at rest) instead of hanging. */
+int ll_w4a16_prepacked_normed_supported(int64_t m, int64_t n, int64_t k, int group_size, int epilogue, int s_count); /* 1 / 0 */
+int ll_w4a16_matmul_prepacked_normed(void* out, void* x, const void* wpacked, const void* spacked, const void* bias,
+                                     int64_t m, int64_t n, int64_t k, int group_size, int64_t x_stride_m,
+                                     float* workspace, int32_t* counters, int epilogue, const float* norm_partials,
+                                     int s_count, void* residual, const void* norm_weight, float eps, void* stream);
 
 /* ---- a9: w8a16_matmul  (kernels/quantization/w8a16.py:155-216) ---------------
  * qweight [N,K] uint8 (fp8-e4m3 bits) or int8; scales fp32 [ceil(N/gn), ceil(K/gk)]. */

@@ -48,6 +48,8 @@ SIGNATURES = {
     "ll_w4a16_partials_count": [L, L, L, I],
     "ll_skip_rmsnorm_partials": [P, P, I, P, P, L, L, F, I, P],
     "ll_w4a16_matmul_prepacked": [P, P, P, P, P, L, L, L, I, L, P, P, I, P],
+    "ll_w4a16_prepacked_normed_supported": [L, L, L, I, I, I],
+    "ll_w4a16_matmul_prepacked_normed": [P, P, P, P, P, L, L, L, I, L, P, P, I, P, I, P, P, F, P],
     "ll_w8a16_matmul": [P, P, P, P, P, L, L, L, I, L, I, L, L, L, L, P, P, P],
     "ll_quantize_activations_int8": [P, P, P, L, L, L, P],
     "ll_dense16_matmul": [P, P, P, P, L, L, L, L, L, I, P, P],
@@ -102,6 +104,8 @@ def lib() -> ctypes.CDLL:
             )
         handle = ctypes.CDLL(LIB_PATH)
         for name, argtypes in SIGNATURES.items():
+            if os.environ.get("LL_LIB_OVERRIDE") and not hasattr(handle, name):
+                continue  # A/B builds of an older source (benchmarks only): a call to the missing entry still fails loudly
             fn = getattr(handle, name)  # AttributeError if the symbol is missing -> loud
             fn.argtypes = argtypes
             fn.restype = ctypes.c_int64 if name in _RETURNS_I64 else c_int

@@ -88,6 +88,16 @@ struct V3Params {
   uint32_t chunks_magic, gt_magic, upw_magic;  // ceil(2^32 / d): x / d = umulhi(x, magic) for the unit / workgroup indices of a launch (< 2^20)
   int gshift;                  // log2(group_size / 128)
   int epi;                     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu;  2: fp32 split-K partials [slot][m][n]
+  // In-launch add-and-normalise (ll_w4a16_matmul_prepacked_normed): the activation matrix x [m][k] does not exist yet when
+  // the launch starts -- workgroup r < m produces row r from the previous projection's split-K partials (the arithmetic of
+  // ll_skip_rmsnorm_partials, bit for bit) while the weight loaders already stream; the activation loaders of ALL workgroups
+  // wait on a launch-wide arrival counter (the rows are written through: they cross XCD L2s) before their first DMA.
+  const float* pre_part;       // [pre_s][m][k] fp32 partials; nullptr: x is an ordinary input
+  uint16_t* pre_res;           // residual [m][k], updated in place
+  const uint16_t* pre_w;       // norm weight [k]
+  float pre_eps;
+  int pre_s;
+  int pre_idx;                 // counters[pre_idx + 0..15]: arrivals (4 per row, spread), counters[pre_idx + 16]: workgroups past the gate
 #ifdef V3_TIMELINE
   unsigned long long* tl;  // debug: [workgroup][64] s_memrealtime stamps of wave LL_GEMM3_TL_WAVE (benchmarks/gemm3_timeline.py)
   int tlwave;
@@ -291,10 +301,121 @@ __device__ __forceinline__ void v3_barrier() { asm volatile("" ::: "memory"); } 
 __device__ __forceinline__ void v3_barrier() { asm volatile("s_barrier" ::: "memory"); }
 #endif
 
+#ifndef V3_PRE_SPIN_LIMIT
+#define V3_PRE_SPIN_LIMIT (1 << 21)  // x ~1.5 us per poll: seconds, then the sticky error word
+#endif
+// Row `row` of the launch's activation matrix from split-K partials: skip_rmsnorm_partials_kernel<LL_F16, VPT, SMAX>
+// (norm_act.hip) run by waves 0..3 of a 12-wave workgroup -- same per-thread columns, same summation order, the same
+// 256-thread reduction (wave sums meet in LDS; the workgroup barrier inside is the launch's "pre" barrier, which the
+// other eight waves execute on their own paths), so the row equals the separate launch's bit for bit.
+template <int VPT, int SMAX>
+__device__ __forceinline__ void v3_pre_norm(const V3Params& p, int row, int tr, float* lds4) {
+  const int n = (int)p.k;
+  const float nf = (float)n;
+  const int64_t plane = p.m * (int64_t)n;
+  const int lane = tr & 63, wv = tr >> 6;  // (timeline builds)
+  (void)lane; (void)wv;
+  V3_TL(54)
+  uint16_t* y = const_cast<uint16_t*>(p.x);
+  uint16_t* r = p.pre_res;
+  U16x8 rv[VPT], wv8[VPT];
+  float sv[VPT][8];
+  bool ok[VPT];
+  float ssq = 0.f;
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    const int col = (v * 256 + tr) * 8;
+    ok[v] = col < n;
+    const int64_t off = ok[v] ? (int64_t)row * n + col : 0;
+    rv[v] = *reinterpret_cast<const U16x8*>(r + off);
+    wv8[v] = *reinterpret_cast<const U16x8*>(p.pre_w + (ok[v] ? col : 0));
+    f32x4 pv[SMAX][2];
+#pragma unroll
+    for (int s = 0; s < SMAX; ++s) {
+      const float* src = p.pre_part + (s < p.pre_s ? s : 0) * plane + off;  // slots >= pre_s re-read slot 0 and are dropped below
+      pv[s][0] = *reinterpret_cast<const f32x4*>(src);
+      pv[s][1] = *reinterpret_cast<const f32x4*>(src + 4);
+    }
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a = 0.f;
+#pragma unroll
+      for (int s = 0; s < SMAX; ++s) a += s < p.pre_s ? pv[s][i >> 2][i & 3] : 0.f;
+      const float x = to_f32<LL_F16>(from_f32<LL_F16>(a)) + to_f32<LL_F16>(rv[v].v[i]);
+      rv[v].v[i] = from_f32<LL_F16>(x);
+      sv[v][i] = ok[v] ? x : 0.f;
+    }
+    if (ok[v]) *reinterpret_cast<U16x8*>(r + (int64_t)row * n + col) = rv[v];
+  }
+#pragma unroll
+  for (int v = 0; v < VPT; ++v)
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ssq += sv[v][i] * sv[v][i] / nf;
+  const float ws = wave_sum(ssq);
+  if ((tr & 63) == 0) lds4[tr >> 6] = ws;
+  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
+  V3_TL(55)
+  v3_barrier();  // the launch's "pre" barrier
+  V3_TL(56)
+  const float var = lds4[0] + lds4[1] + lds4[2] + lds4[3];
+  const float rrms = 1.0f / sqrtf(var + p.pre_eps);
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    if (ok[v]) {
+      U16x8 yv;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) yv.v[i] = mul_storage<LL_F16>(from_f32<LL_F16>(sv[v][i] * rrms), wv8[v].v[i]);
+      // written through (sc1): the row must have left this XCD's L2 before its arrival is counted.  (An agent-scope release /
+      // acquire fence pair is the textbook form; its buffer_wbl2 / buffer_inv walk the whole L2 once per wave -- 768 walks
+      // per launch measured +21 us.  No invalidate is needed on the reading side: every L2 was invalidated at the launch
+      // boundary and nobody reads these addresses before the gate opens.)
+      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(y + (int64_t)row * p.x_stride + (v * 256 + tr) * 8),
+                   "v"(__builtin_bit_cast(u32x4, yv)) : "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  V3_TL(57)
+  // arrivals are counted in 16 words (same-address device-scope read-modify-writes are served one after the other, ~50 ns
+  // each: 256 of them on one word took longer than the rows)
+  if ((tr & 63) == 0)
+    __hip_atomic_fetch_add(p.counters + p.pre_idx + ((row * 4 + (tr >> 6)) & 15), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+__device__ __forceinline__ void v3_pre_norm_dispatch(const V3Params& p, int row, int tr, float* lds4) {
+  const int nv = (int)(p.k / 8);
+  if (nv <= 256) { if (p.pre_s <= 6) v3_pre_norm<1, 6>(p, row, tr, lds4); else v3_pre_norm<1, 12>(p, row, tr, lds4); }
+  else { if (p.pre_s <= 6) v3_pre_norm<2, 6>(p, row, tr, lds4); else v3_pre_norm<2, 12>(p, row, tr, lds4); }
+}
+// The gate: every row has arrived (4 waves each, counted in words pre_idx + 0..15).
+__device__ __forceinline__ void v3_pre_gate(const V3Params& p, int lane) {
+  const int32_t* arr = p.counters + p.pre_idx;
+  const int want = lane < 16 ? (4 * (int)p.m - lane + 15) >> 4 : 0;  // arrivals i = 4 row + wave with i % 16 == lane
+  bool ok = false;
+  for (int spin = 0; spin < V3_PRE_SPIN_LIMIT; ++spin) {
+    const int seen = __hip_atomic_load(arr + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if (__builtin_amdgcn_ballot_w64(seen < want) == 0) {
+      ok = true;
+      break;
+    }
+    __builtin_amdgcn_s_sleep(8);
+  }
+  if (!ok && lane == 0) __hip_atomic_store(p.counters + p.err_idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sticky (see the merge wait)
+  asm volatile("" ::: "memory");  // (no acquire fence: see v3_pre_norm)
+}
+// Counted at the END of a workgroup's work (the read-modify-write's round trip would otherwise sit in front of the first
+// activation DMA -- and all workgroups pass the gate at the same moment): the last one through puts the words back to zero
+// (all arrivals precede any pass, all passes precede the reset; the next launch starts after this one has ended).
+__device__ __forceinline__ void v3_pre_pass(const V3Params& p, int lane, int wgs) {
+  int32_t* arr = p.counters + p.pre_idx;
+  int old = 0;
+  if (lane == 0) old = __hip_atomic_fetch_add(arr + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  if (__builtin_amdgcn_readfirstlane(old) == wgs - 1 && lane <= 16)
+    __hip_atomic_store(arr + lane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+}
+
 // One loader wave.  KIND 0: weight pieces 4L..4L+3 (1 KB each) + scale quarters 2L, 2L+1 (256 B each) of every
 // unit, V3_DW units ahead into a V3_RW-slot ring.  KIND 1: activation pieces 8L..8L+7 (4 rows x 256 B each),
 // V3_DX units ahead into a V3_RX-slot ring; LDS image row r, 16-B slot j <- source slot j ^ (r & 15).
-template <int KIND, int NF>
+template <int KIND, int NF, bool PRE>
 __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int cnt, int lane, int L) {
   using RG = V3Ring<NF>;
   using LD = V3Lds<NF>;
@@ -351,7 +472,25 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
   // unit ahead (RA) they multiply unit 0 while units 1, 2 land and meet the loaders again at B0.  (Round 2 requested two
   // units, waited for both, and refilled the ring two units per step: first unit finished 4.2-4.8 us after entry.)
   const int pre = cnt < 1 + AHEAD ? cnt : 1 + AHEAD;  // what the consumers' first two steps need; the rest of the ring after P0
+  // PRE (in-launch add-and-normalise): the "pre" barrier of a workgroup that produces a row (v3_pre_norm), then the gate --
+  // activation loader 0 polls the launch-wide arrival counter and the workgroup's twelve waves meet at the "gate" barrier
+  // (one polling wave per workgroup: 512 waves polling one word every 50 ns starved the producers' own atomics, +14 us).
+  // The weight loaders have their first units on the way before either barrier.
+  if constexpr (PRE && KIND == 1) {
+    const int wv = 10 + L;  // (timeline builds)
+    (void)wv;
+    if ((int)blockIdx.x < (int)p.m) v3_barrier();
+    V3_TL(54)
+    if (L == 0) v3_pre_gate(p, lane);
+    V3_TL(55)
+    v3_barrier();
+    V3_TL(56)
+  }
   for (int i = 0; i < pre; ++i) issue();
+  if constexpr (PRE && KIND == 0) {
+    if ((int)blockIdx.x < (int)p.m) v3_barrier();
+    v3_barrier();
+  }
   V3_TL(2)
   v3_wait_units<OPS>(issued - 1);  // unit 0 has landed
   v3_barrier();                    // P0
@@ -416,7 +555,7 @@ __device__ __forceinline__ int v3_div(int x, uint32_t magic, int d) {
 #endif
 }
 
-template <int MT, int NF>
+template <int MT, int NF, bool PRE = false>
 __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgemm3_kernel(const V3Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
@@ -436,7 +575,20 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     ue = ub + p.upw;
     if (ue > p.total_units) ue = p.total_units;
   }
-  if (ub >= ue) return;
+  const bool pre_wg = PRE && (int)blockIdx.x < (int)p.m;
+  if (ub >= ue) {
+    if constexpr (PRE) {  // a workgroup without units still owes its row and its pass of the gate
+      if (pre_wg) {
+        if (wv < 4) v3_pre_norm_dispatch(p, (int)blockIdx.x, tid, reinterpret_cast<float*>(lds + V3Lds<NF>::OFF_R));
+        else v3_barrier();
+      }
+      if (wv == 10) {  // (waits like everybody else: the last pass resets the words)
+        v3_pre_gate(p, lane);
+        v3_pre_pass(p, lane, (int)gridDim.x);
+      }
+    }
+    return;
+  }
   const int cnt = ue - ub;
   const int tA = v3_div(ub, p.chunks_magic, chunks), cA = ub - tA * chunks;
   const int tZ = v3_div(ue - 1, p.chunks_magic, chunks), cZ = (ue - 1) - tZ * chunks;
@@ -461,14 +613,24 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 #ifdef V3_LOADER_PRIO
     __builtin_amdgcn_s_setprio(V3_LOADER_PRIO);
 #endif
-    if (wv < 10) v3_loader<0, NF>(p, q, cnt, lane, wv - 8);
-    else v3_loader<1, NF>(p, q, cnt, lane, wv - 10);
+    if (wv < 10) v3_loader<0, NF, PRE>(p, q, cnt, lane, wv - 8);
+    else v3_loader<1, NF, PRE>(p, q, cnt, lane, wv - 10);
+    if constexpr (PRE) {
+      if (wv == 10) v3_pre_pass(p, lane, (int)gridDim.x);
+    }
     return;
   }
 
   // ======================================= consumers ======================================= //
   using RG = V3Ring<NF>;
   using LD = V3Lds<NF>;
+  if constexpr (PRE) {
+    if (pre_wg) {  // this workgroup's activation row (waves 0..3; the barrier inside is matched by everybody else's)
+      if (wv < 4) v3_pre_norm_dispatch(p, (int)blockIdx.x, tid, reinterpret_cast<float*>(lds + LD::OFF_R));
+      else v3_barrier();
+    }
+    v3_barrier();  // "gate": activation loader 0 has seen every row of the launch arrive
+  }
   const int ng = wv & 3, kh = wv >> 2;
   const int nl = lane & 31, h = lane >> 5;
   const int w_off = wv * 1024 + lane * 16;
@@ -1090,14 +1252,20 @@ extern "C" int ll_w4a16_v3_workspace(int64_t m, int64_t n, int64_t k, int64_t* f
     const int64_t f = (int64_t)pl.nblocks * pl.nf * pl.slots * V3_SLAB;
     if (floats && f > *floats) *floats = f;
   }
-  if (ints) *ints = n / V3_BN * 8 + 1;  // merge counters + the error word
+  if (ints) *ints = n / V3_BN * 8 + 1 + 17;  // merge counters + the error word + the in-launch norm's gate (16 arrival words, 1 pass word)
   return LL_OK;
 }
 
-extern "C" int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* wpacked, const void* spacked,
-                                         const void* bias, int64_t m, int64_t n, int64_t k, int group_size,
-                                         int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,
-                                         void* stream) {
+struct V3Pre {  // in-launch add-and-normalise (V3Params::pre_*)
+  const float* part = nullptr;
+  int s_count = 0;
+  void* residual = nullptr;
+  const void* weight = nullptr;
+  float eps = 0.f;
+};
+static int v3_launch(void* out, const void* x, const void* wpacked, const void* spacked, const void* bias, int64_t m, int64_t n,
+                     int64_t k, int group_size, int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,
+                     const V3Pre& pre, void* stream) {
   if (m < 0 || n <= 0 || k <= 0 || group_size <= 0) return LL_ERR_SHAPE;
   if (m == 0) return LL_OK;
   if (!ll_w4a16_prepacked_supported(m, n, k, group_size) || x_stride_m % 8 != 0 || ((epilogue & 1) && (n & 1))) return LL_ERR_SHAPE;
@@ -1146,9 +1314,31 @@ extern "C" int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* w
     (void)hipFuncSetAttribute((const void*)wgemm3_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<1>::BYTES);
     (void)hipFuncSetAttribute((const void*)wgemm3_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<2>::BYTES);
     (void)hipFuncSetAttribute((const void*)wgemm3_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<2>::BYTES);
+    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<1>::BYTES);
+    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<1>::BYTES);
+    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<2>::BYTES);
+    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<2>::BYTES);
     attr_set[dev] = true;
   }
+  if (pre.part) {
+    // one row per workgroup, 256 threads x (1 or 2) x 8 columns, up to 12 partials; the gate's two words follow the error word
+    if (pl.grid < m || k % 8 != 0 || k > 4096 || pre.s_count < 1 || pre.s_count > 12 || x_stride_m < k) return LL_ERR_SHAPE;
+    if (!pre.residual || !pre.weight || !ll_aligned16(pre.part) || !ll_aligned16(pre.residual) || !ll_aligned16(pre.weight))
+      return LL_ERR_ARG;
+    p.pre_part = pre.part; p.pre_s = pre.s_count; p.pre_res = (uint16_t*)pre.residual; p.pre_w = (const uint16_t*)pre.weight;
+    p.pre_eps = pre.eps; p.pre_idx = p.err_idx + 1;
+  }
   const dim3 grid((unsigned)pl.grid);
+  if (pre.part) {
+    if (pl.nf == 2) {
+      if (m <= 32) wgemm3_kernel<1, 2, true><<<grid, V3_THREADS, V3Lds<2>::BYTES, st>>>(p);
+      else wgemm3_kernel<2, 2, true><<<grid, V3_THREADS, V3Lds<2>::BYTES, st>>>(p);
+    } else {
+      if (m <= 32) wgemm3_kernel<1, 1, true><<<grid, V3_THREADS, V3Lds<1>::BYTES, st>>>(p);
+      else wgemm3_kernel<2, 1, true><<<grid, V3_THREADS, V3Lds<1>::BYTES, st>>>(p);
+    }
+    return LL_LAUNCH_CHECK();
+  }
   if (pl.nf == 2) {
     if (m <= 32) wgemm3_kernel<1, 2><<<grid, V3_THREADS, V3Lds<2>::BYTES, st>>>(p);
     else wgemm3_kernel<2, 2><<<grid, V3_THREADS, V3Lds<2>::BYTES, st>>>(p);
@@ -1157,4 +1347,37 @@ extern "C" int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* w
     else wgemm3_kernel<2, 1><<<grid, V3_THREADS, V3Lds<1>::BYTES, st>>>(p);
   }
   return LL_LAUNCH_CHECK();
+}
+
+extern "C" int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* wpacked, const void* spacked,
+                                         const void* bias, int64_t m, int64_t n, int64_t k, int group_size,
+                                         int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,
+                                         void* stream) {
+  return v3_launch(out, x, wpacked, spacked, bias, m, n, k, group_size, x_stride_m, workspace, counters, epilogue, V3Pre{}, stream);
+}
+
+// 1 / 0: ll_w4a16_matmul_prepacked_normed serves the shape (same epilogue word; s_count = number of norm partials)
+extern "C" int ll_w4a16_prepacked_normed_supported(int64_t m, int64_t n, int64_t k, int group_size, int epilogue, int s_count) {
+  if (m < 1 || !ll_w4a16_prepacked_supported(m, n, k, group_size)) return 0;
+  const bool partials = (epilogue & 3) == 2;
+  if (partials && !ll_w4a16_partials_count(m, n, k, group_size)) return 0;
+  const V3Plan pl = v3_plan(n, k, (epilogue >> 8) & 3, partials);
+  return pl.grid >= m && k % 8 == 0 && k <= 4096 && s_count >= 1 && s_count <= 12 ? 1 : 0;
+}
+
+// ll_skip_rmsnorm_partials + ll_w4a16_matmul_prepacked in ONE launch (decode step, TP = 1): ``x`` [m][k] is an OUTPUT here --
+// the normalised rows, written by the launch itself (workgroup r < m: row r, values bit-identical to
+// ll_skip_rmsnorm_partials(x, norm_partials, s_count, residual, norm_weight, m, k, eps)) while the weight stream is already
+// running, then consumed by every workgroup's activation loaders behind a launch-wide gate -- one kernel boundary and the
+// GEMM's cold start less per add-and-normalise.  ``residual`` [m][k] is updated in place.  fp16, k <= 4096, k % 8 == 0,
+// 1 <= s_count <= 12, and a launch of at least m workgroups (LL_ERR_SHAPE otherwise: run the two launches).  ``counters`` as
+// for ll_w4a16_matmul_prepacked (ll_w4a16_v3_workspace sizes it; all words zero at rest).
+extern "C" int ll_w4a16_matmul_prepacked_normed(void* out, void* x, const void* wpacked, const void* spacked, const void* bias,
+                                                int64_t m, int64_t n, int64_t k, int group_size, int64_t x_stride_m,
+                                                float* workspace, int32_t* counters, int epilogue, const float* norm_partials,
+                                                int s_count, void* residual, const void* norm_weight, float eps, void* stream) {
+  if (!norm_partials) return LL_ERR_ARG;
+  V3Pre pre;
+  pre.part = norm_partials; pre.s_count = s_count; pre.residual = residual; pre.weight = norm_weight; pre.eps = eps;
+  return v3_launch(out, x, wpacked, spacked, bias, m, n, k, group_size, x_stride_m, workspace, counters, epilogue, pre, stream);
 }

@@ -172,14 +172,45 @@ def w4a16_prepacked_supported(m: int, n: int, k: int, group_size: int) -> bool:
     return bool(L.lib().ll_w4a16_prepacked_supported(m, n, k, int(group_size)))
 
 
+def _launch_prepacked(out_ptr, a, m, n, k, packed_weight, packed_scales, bias, group_size, epilogue, pending, what):
+    """The decode-engine launch; with ``pending`` (kernels/norm_act.py::PendingNorm whose ``out`` IS ``a``'s storage) and a
+    served shape the launch produces its own activation rows (ll_w4a16_matmul_prepacked_normed), else the pending norm runs
+    as its own launch first."""
+    ws, cnt = L.gemm_workspace(a.device, m, n, k)
+    lib = L.lib()
+    if pending is not None and not pending.done:
+        if (pending.out.data_ptr() == a.data_ptr() and a.stride(0) == k and
+                lib.ll_w4a16_prepacked_normed_supported(m, n, k, int(group_size), epilogue, pending.X.parts.shape[0])):
+            parts, s_count, res, wgt, eps = pending.take()
+            L.check(
+                lib.ll_w4a16_matmul_prepacked_normed(
+                    out_ptr, a.data_ptr(), packed_weight.data_ptr(), packed_scales.data_ptr(), L.ptr(bias), m, n, k,
+                    int(group_size), a.stride(0), ws.data_ptr(), cnt.data_ptr(), epilogue, parts, s_count, res, wgt, eps,
+                    L.stream_ptr(),
+                ),
+                what + " (in-launch add-and-normalise)",
+            )
+            return
+        pending.materialise()
+    L.check(
+        lib.ll_w4a16_matmul_prepacked(
+            out_ptr, a.data_ptr(), packed_weight.data_ptr(), packed_scales.data_ptr(), L.ptr(bias), m, n, k,
+            int(group_size), a.stride(0), ws.data_ptr(), cnt.data_ptr(), epilogue, L.stream_ptr(),
+        ),
+        what,
+    )
+
+
 def w4a16_matmul_prepacked(x, packed_weight, packed_scales, *, group_size: int = 128, bias=None, gate_up_swiglu=False,
-                           _tile_blocks: int = 0):
+                           _tile_blocks: int = 0, pending=None):
     """Decode-engine form of :func:`w4a16_matmul` over the load-time layouts (``pack_w4a16_weights`` /
     ``pack_w4a16_scales``); at most 64 rows.  ``gate_up_swiglu`` applies the fused epilogue of
     :func:`w4a16_gate_up_swiglu` (rows interleaved gate/up).  Same arithmetic as ``w4a16_matmul``.
     ``_tile_blocks`` (tests / tuning): 0 = tile width chosen by the host plan, 1 / 2 = 128- / 256-row tiles."""
     if x.dtype != torch.float16:
         raise ValueError(f"w4a16 activations must be fp16, got {x.dtype}")
+    if pending is not None and not pending.done and (x.data_ptr() != pending.out.data_ptr() or not x.is_contiguous()):
+        pending.materialise()  # not the pending norm's own rows: they are read before the launch
     L.require_cuda(x, packed_weight, packed_scales, bias)
     if packed_weight.dtype != torch.int32 or packed_weight.dim() != 5 or not packed_weight.is_contiguous():
         raise ValueError("packed_weight must be the int32 [N/128, K/128, 8, 64, 4] tensor made by pack_w4a16_weights")
@@ -198,23 +229,18 @@ def w4a16_matmul_prepacked(x, packed_weight, packed_scales, *, group_size: int =
         bias = bias.half()
     n_out = n // 2 if gate_up_swiglu else n
     out = torch.empty((m, n_out), dtype=x.dtype, device=x.device)
-    ws, cnt = L.gemm_workspace(x.device, m, n, k)
-    L.check(
-        L.lib().ll_w4a16_matmul_prepacked(
-            out.data_ptr(), a.data_ptr(), packed_weight.data_ptr(), packed_scales.data_ptr(), L.ptr(bias), m, n, k,
-            int(group_size), a.stride(0), ws.data_ptr(), cnt.data_ptr(),
-            (1 if gate_up_swiglu else 0) | ((int(_tile_blocks) & 3) << 8), L.stream_ptr(),
-        ),
-        "w4a16_matmul_prepacked",
-    )
+    _launch_prepacked(out.data_ptr(), a, m, n, k, packed_weight, packed_scales, bias, group_size,
+                      (1 if gate_up_swiglu else 0) | ((int(_tile_blocks) & 3) << 8), pending, "w4a16_matmul_prepacked")
     return out.reshape(*leading, n_out)
 
 
-def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 128):
+def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 128, pending=None):
     """Decode-step extension: the projection as ``S`` fp32 split-K partial sums (:class:`PartialSums`) for
     :func:`skip_rmsnorm_partials` to add up -- the GEMM has no cross-workgroup merge then.  ``None`` when the shape
     is not served (the caller runs :func:`w4a16_matmul_prepacked`)."""
     from .norm_act import PartialSums
+    if pending is not None and not pending.done and (x.data_ptr() != pending.out.data_ptr() or not x.is_contiguous()):
+        pending.materialise()
     L.require_cuda(x, packed_weight, packed_scales)
     n, k = packed_weight.shape[0] * 128, packed_weight.shape[1] * 128
     if x.dtype != torch.float16 or x.shape[-1] != k or n % 8:
@@ -227,14 +253,8 @@ def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 
     if s < 1:
         return None
     parts = torch.empty((s, m, n), dtype=torch.float32, device=x.device)
-    ws, cnt = L.gemm_workspace(x.device, m, n, k)
-    L.check(
-        L.lib().ll_w4a16_matmul_prepacked(
-            parts.data_ptr(), a.data_ptr(), packed_weight.data_ptr(), packed_scales.data_ptr(), 0, m, n, k,
-            int(group_size), a.stride(0), ws.data_ptr(), cnt.data_ptr(), 2, L.stream_ptr(),
-        ),
-        "w4a16_matmul_partials",
-    )
+    _launch_prepacked(parts.data_ptr(), a, m, n, k, packed_weight, packed_scales, None, group_size, 2, pending,
+                      "w4a16_matmul_partials")
     return PartialSums(parts, (*x.shape[:-1], n), x.dtype)
 
 

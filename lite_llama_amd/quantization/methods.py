@@ -89,28 +89,38 @@ class W4A16LinearMethod(LinearQuantMethod):
                             group_size=layer.quant.group_k, bias=layer.bias,
                             packed_scales=self._packed(layer))
 
-    def apply_partials(self, layer, x, allow_bias: bool = False):
+    accepts_pending_norm = True  # apply_partials / apply_gate_up_swiglu take ``pending`` (kernels/norm_act.py::PendingNorm)
+
+    def apply_partials(self, layer, x, allow_bias: bool = False, pending=None):
         """Decode-shaped projection left as fp32 split-K partials for ``skip_rmsnorm_partials`` /
         ``decode_attention_partials`` (extension); ``None`` -> the caller runs :meth:`apply`.  The partials never
         include the bias: a consumer that adds it itself passes ``allow_bias``."""
         if (layer.bias is not None and not allow_bias) or os.environ.get("LL_W4_NO_PARTIALS"):
             return None
+        if pending is not None and getattr(layer, "act_perm", None) is not None:
+            pending.materialise()  # the gather below reads the rows
         x = _ordered_input(layer, x)
         pre = self._prepacked(layer, x)
         if pre is None:
             return None
-        return w4a16_matmul_partials(x, pre, self._packed(layer), group_size=layer.quant.group_k)
+        return w4a16_matmul_partials(x, pre, self._packed(layer), group_size=layer.quant.group_k, pending=pending)
 
-    def apply_gate_up_swiglu(self, layer, x):
+    def apply_gate_up_swiglu(self, layer, x, pending=None):
         """``layer`` holds gate/up row-interleaved (linear.py::MergedColumnLinear): one launch for
-        both projections and the activation; ``None`` -> the caller falls back to the two-step form."""
+        both projections and the activation; ``None`` -> the caller falls back to the two-step form.
+        ``pending``: ``x`` is the output of an add-and-normalise that has not run yet -- the decode engine's launch
+        does it (or it is run here before anything else reads ``x``)."""
         if layer.bias is not None:
             return None
+        if pending is not None and getattr(layer, "act_perm", None) is not None:
+            pending.materialise()
         x = _ordered_input(layer, x)
         pre = self._prepacked(layer, x)
         if pre is not None:
             return w4a16_matmul_prepacked(x, pre, self._packed(layer), group_size=layer.quant.group_k,
-                                          gate_up_swiglu=True)
+                                          gate_up_swiglu=True, pending=pending)
+        if pending is not None:
+            pending.materialise()
         return w4a16_gate_up_swiglu(x, layer.weight, layer.weight_scale, layer.weight_zeros,
                                     group_size=layer.quant.group_k, packed_scales=self._packed(layer))
 
