@@ -79,6 +79,75 @@ __global__ __launch_bounds__(768) void mix(const unsigned char* w, const unsigne
   if (lds[threadIdx.x] == 0x7f) out[0] = 1;
 }
 
+// Two 6-wave workgroups per CU instead of one 12-wave workgroup (round 3, last experiment): wave 0 streams the unit's weights
+// (8 x 1 KB + 4 x 256 B), wave 1 its activation tile (16 x 1 KB), waves 2..5 are the consumers of the whole unit (18 KB of
+// LDS fragment reads, 16 MFMA 32x32x16 + the packed VALU work each), one 6-wave barrier per unit; 64 KB of LDS per
+// workgroup.  Same work per CU and unit as mix<3, 3, 1, 15>; the two lock-step groups of a CU are independent.
+template <int DEPTH, int CONS>
+__global__ __launch_bounds__(384) void mix2(const unsigned char* w, const unsigned char* x, int units, int* out) {
+  extern __shared__ unsigned char lds[];
+  const int lane = threadIdx.x & 63, wv = threadIdx.x >> 6;
+  if (wv >= 2) {
+    typedef int i32x4 __attribute__((ext_vector_type(4)));
+    i32x4 acc = {0, 0, 0, 0};
+    typedef _Float16 h8 __attribute__((ext_vector_type(8)));
+    typedef float f16v __attribute__((ext_vector_type(16)));
+    f16v c0 = {0}, c1 = {0};
+    i32x4 prev = {1, 2, 3, 4};
+    for (int u = 0; u < units; ++u) {
+      if (CONS & 8) prev = acc;
+      if (CONS & 1) {
+#pragma unroll
+        for (int j = 0; j < 18; ++j) acc ^= *(const i32x4*)(lds + ((u * 18 + j + wv) % 56) * 1024 + lane * 16);
+      }
+      if (CONS & 4) {
+#pragma unroll
+        for (int j = 0; j < 8; ++j) {
+          i32x4 w = (CONS & 8) ? prev : acc;
+#pragma unroll
+          for (int r = 0; r < 13; ++r) w.x = (w.x * 3 + w.y) ^ (w.z >> 1);
+          w.y ^= w.x;
+          const h8 a = __builtin_bit_cast(h8, w), b = __builtin_bit_cast(h8, acc);
+          c0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c0, 0, 0, 0);
+          c1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(a, b, c1, 0, 0, 0);
+        }
+      }
+      if (CONS & 2) asm volatile("s_barrier" ::: "memory");
+    }
+    if ((acc.x ^ acc.y ^ acc.z ^ acc.w) == 0x12345678 || c0[0] + c1[3] == 1.2345f) out[0] = 1;
+    return;
+  }
+  if (wv == 0) {
+    const unsigned char* p = w + ((size_t)blockIdx.x * units) * 9216;
+    for (int u = 0; u < units; ++u) {
+      unsigned char* dst = lds + (u % DEPTH) * 9216;
+#pragma unroll
+      for (int j = 0; j < 8; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void*)(p + j * 1024 + lane * 16), (lds_void*)(dst + j * 1024), 16, 0, 2);
+#pragma unroll
+      for (int j = 0; j < 4; ++j)
+        __builtin_amdgcn_global_load_lds((glb_void*)(p + 8192 + j * 256 + lane * 4), (lds_void*)(dst + 8192 + j * 256), 4, 0, 2);
+      p += 9216;
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(12 * (DEPTH - 1)) : "memory");
+      if (CONS & 2) asm volatile("s_barrier" ::: "memory");
+    }
+  } else {
+    for (int u = 0; u < units; ++u) {
+      const int c = (u + blockIdx.x * 3) % 28;
+      unsigned char* dst = lds + 3 * 9216 + (u % (DEPTH < 3 ? DEPTH : 2)) * 16384;
+#pragma unroll
+      for (int j = 0; j < 16; ++j) {
+        const int r = j * 4 + (lane >> 4);
+        __builtin_amdgcn_global_load_lds((glb_void*)(x + (size_t)r * 7168 + c * 256 + (lane & 15) * 16), (lds_void*)(dst + j * 1024), 16, 0, 0);
+      }
+      asm volatile("s_waitcnt vmcnt(%0)" ::"n"(16 * ((DEPTH < 3 ? DEPTH : 2) - 1)) : "memory");
+      if (CONS & 2) asm volatile("s_barrier" ::: "memory");
+    }
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+  if (lds[threadIdx.x] == 0x7f) out[0] = 1;
+}
+
 int main() {
   const size_t big = (size_t)2 << 30;
   unsigned char *d, *x; int* out;
@@ -96,6 +165,19 @@ int main() {
     float ms; hipEventElapsedTime(&ms, e0, e1);
     const double us = ms * 1e3 / reps;
     printf("%-40s units %3d: %8.2f us  %6.3f us/unit  (HBM %5.2f TB/s)\n", name, units, us, us / units, 256.0 * units * 9216 / us / 1e6);
+  };
+  auto run2 = [&](const char* name, auto kern, int units_per_cu) {
+    const int units = units_per_cu / 2;  // 512 workgroups, two per CU
+    hipFuncSetAttribute((const void*)kern, hipFuncAttributeMaxDynamicSharedMemorySize, 64 * 1024);
+    kern<<<512, 384, 64 * 1024>>>(d, x, units, out);
+    hipDeviceSynchronize();
+    hipEventRecord(e0);
+    const int reps = 5;
+    for (int i = 0; i < reps; ++i) kern<<<512, 384, 64 * 1024>>>(d + (size_t)(i % 3) * 512 * units * 9216, x, units, out);
+    hipEventRecord(e1); hipEventSynchronize(e1);
+    float ms; hipEventElapsedTime(&ms, e0, e1);
+    const double us = ms * 1e3 / reps;
+    printf("%-40s units %3d: %8.2f us  %6.3f us/unit  (HBM %5.2f TB/s)\n", name, units_per_cu, us, us / units_per_cu, 512.0 * units * 9216 / us / 1e6);
   };
   run("weights only   depth 3", mix<3, 1, 1>, 64);
   run("activ.  only   depth 3", mix<3, 2, 1>, 64);
@@ -118,5 +200,11 @@ int main() {
   run("both d3 + LDS reads + barrier, 16 units", mix<3, 3, 1, 3>, 16, 768);
   run("both           depth 3, 16 units", mix<3, 3, 1>, 16);
   run("weights only   depth 3, 16 units", mix<3, 1, 1>, 16);
+  run2("2 x 6 waves: DMA + LDS + barrier + MFMA/VALU, read-ahead", mix2<3, 15>, 64);
+  run2("2 x 6 waves: the same, no read-ahead", mix2<3, 7>, 64);
+  run2("2 x 6 waves: DMA + barrier + MFMA/VALU (no LDS reads)", mix2<3, 6>, 64);
+  run2("2 x 6 waves: DMA + LDS reads + barrier (no arithmetic)", mix2<3, 3>, 64);
+  run2("2 x 6 waves: read-ahead, 16 units per CU", mix2<3, 15>, 16);
+  run("both d3 + LDS + barrier + MFMA/VALU, read-ahead, 16 units", mix<3, 3, 1, 15>, 16, 768);
   return 0;
 }
