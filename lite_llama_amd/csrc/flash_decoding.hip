@@ -115,27 +115,60 @@ struct FdKv<true> {
   }
 };
 
-// K/V gathers: FD_NT = 1 asks for the non-temporal policy (A/B knob).  Measured SLOWER here (round 3, same box: 20.5 vs
-// 18.7 us at batch 64 x ctx 512): a row's 128-byte lines are fetched as two 64-byte halves by consecutive instructions, and
-// an nt load bypasses the L1 that serves the second half
+// K/V gathers.  FD_NT: non-temporal policy for the WHOLE-LINE gathers (FD_FULL_LINE below) -- same box, batch 64, us per
+// launch at a context of 512 / 640 / 1024: 17.1 / 21.6 / 30.5 against 18.8 / 23.5 / 33.3 with the default policy (3.93 / 4.4
+// TB/s instead of 3.57 / 4.05).  The half-line gathers (64 bytes of 16 rows per instruction: the fp8 pool, head size 64)
+// keep the default policy: nt measured SLOWER there (20.5 vs 18.7 us) -- a line's second half is served by the L1 that nt
+// bypasses.
 #ifndef FD_NT
-#define FD_NT 0
+#define FD_NT 1
 #endif
 typedef unsigned fd_u32x2 __attribute__((ext_vector_type(2)));
 typedef unsigned fd_u32x4 __attribute__((ext_vector_type(4)));
+template <bool NT = false>
 __device__ __forceinline__ Q4 fd_gather(const Q4* p) {
-#if FD_NT
-  return __builtin_bit_cast(Q4, __builtin_nontemporal_load(reinterpret_cast<const fd_u32x4*>(p)));
-#else
-  return *p;
-#endif
+  if constexpr (NT) return __builtin_bit_cast(Q4, __builtin_nontemporal_load(reinterpret_cast<const fd_u32x4*>(p)));
+  else return *p;
 }
+template <bool NT = false>
 __device__ __forceinline__ Q2 fd_gather(const Q2* p) {
-#if FD_NT
-  return __builtin_bit_cast(Q2, __builtin_nontemporal_load(reinterpret_cast<const fd_u32x2*>(p)));
-#else
-  return *p;
+  if constexpr (NT) return __builtin_bit_cast(Q2, __builtin_nontemporal_load(reinterpret_cast<const fd_u32x2*>(p)));
+  else return *p;
+}
+
+// FD_FULL_LINE (head size 128, 16-bit pool): every gather instruction covers WHOLE 128-byte lines -- lane (t, c) fetches row
+// t & 7 of an 8-row group, 16-byte piece c + 4 (t >> 3) of one line -- instead of 64-byte halves of 16 rows; lanes t and t ^ 8
+// then trade the piece the other one's MFMA fragment needs (one row_ror:8 DPP move per register).  V rows go to LDS
+// anyway: only their store addresses change.
+#ifndef FD_FULL_LINE
+#define FD_FULL_LINE 1
 #endif
+__device__ __forceinline__ Q4 fd_ror8(const Q4& v) {
+  Q4 o;
+  o.x = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.x, 0x128, 0xf, 0xf, true);
+  o.y = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.y, 0x128, 0xf, 0xf, true);
+  o.z = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.z, 0x128, 0xf, 0xf, true);
+  o.w = (uint32_t)__builtin_amdgcn_mov_dpp((int)v.w, 0x128, 0xf, 0xf, true);
+  return o;
+}
+__device__ __forceinline__ Q4 fd_sel(bool p, const Q4& a, const Q4& b) {
+  return Q4{p ? a.x : b.x, p ? a.y : b.y, p ? a.z : b.z, p ? a.w : b.w};
+}
+// raw[g * 2 + l] = (row g * 8 + (t & 7), line l, piece c + 4 hi)  ->  frag[s] = (row t, bytes s * 64 + c * 16)
+__device__ __forceinline__ void fd_fix_fragments(Q4 (&r)[4], bool hi) {
+#pragma unroll
+  for (int l = 0; l < 2; ++l) {
+    const Q4 keep = fd_sel(hi, r[2 + l], r[l]);
+    const Q4 recv = fd_ror8(fd_sel(hi, r[l], r[2 + l]));
+    r[l] = keep;      // parked; re-ordered below
+    r[2 + l] = recv;
+  }
+  // keep[l] = piece (hi ? 4 + c : c) of line l, recv[l] = the other one: s = 2 l + (piece >= 4)
+  const Q4 k0 = r[0], k1 = r[1], v0 = r[2], v1 = r[3];
+  r[0] = fd_sel(hi, v0, k0);
+  r[1] = fd_sel(hi, k0, v0);
+  r[2] = fd_sel(hi, v1, k1);
+  r[3] = fd_sel(hi, k1, v1);
 }
 
 template <int DT, int D, bool FUSE, bool ROPE, int GS, bool GROUPED, bool KV8 = false>
@@ -146,6 +179,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     int hq, int hkv, int nparts, float scale, int64_t q_sb, int64_t q_sh, int64_t k_st, int64_t k_sh,
     int64_t v_st, int64_t v_sh, int64_t t_sb, int req_w, int seq_w, uint16_t* __restrict__ out, int64_t o_sb,
     int64_t o_sh, int32_t* __restrict__ counters, FdRope rp) {
+  constexpr bool FDFL = FD_FULL_LINE && !KV8 && D == 128;  // whole-line gathers (see fd_fix_fragments)
   constexpr int NS = D / 32;      // MFMA k-steps over the head dim
   constexpr int NT = D / 16;      // output d-tiles
   constexpr int VSTR = D + 8;     // padded LDS row stride (elements)
@@ -230,6 +264,8 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     }
   };
 
+  // (requested together: the table row address needs req, the partition bounds need seq_len -- one round trip, not two)
+  const int64_t req = fd_load_idx(b_req_idx, b, req_w);
   const int64_t seq_len = fd_load_idx(b_seq_len, b, seq_w);
   const int64_t start = (int64_t)part * FD_PART;
   if (start >= seq_len) {  // empty partition stores nothing (flashdecoding.py:141-161)
@@ -246,7 +282,6 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     return;
   }
   const int64_t end = seq_len < start + FD_PART ? seq_len : start + FD_PART;
-  const int64_t req = fd_load_idx(b_req_idx, b, req_w);
   const int32_t* trow = table + req * t_sb;
   // Pool rows of the whole partition, requested now (the K/V gathers depend on them; everything up to the first
   // gather overlaps this round trip)
@@ -337,6 +372,25 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
 #define FD_LOAD(S, TI)                                                                         \
   {                                                                                            \
     const int rsrc_ = (TI) < 2 ? r0 : r1;                                                      \
+    if constexpr (FDFL) {                                                                      \
+      const int tl_ = t & 7, pc_ = (c + 4 * (t >> 3)) * 8;                                     \
+      _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                          \
+        const int64_t rowA_ = __shfl(rsrc_, ((TI) & 1) * 32 + g * 8 + tl_, 64);                \
+        const int64_t rowB_ = __shfl(rsrc_, ((TI) & 1) * 32 + 16 + g * 8 + tl_, 64);           \
+        _Pragma("unroll") for (int l = 0; l < 2; ++l) {                                        \
+          ka##S[g * 2 + l] = fd_gather<FD_NT != 0>(reinterpret_cast<const KVR*>(kcE + rowA_ * k_st + (int64_t)kvh * k_sh + l * 64 + pc_)); \
+          kb##S[g * 2 + l] = fd_gather<FD_NT != 0>(reinterpret_cast<const KVR*>(kcE + rowB_ * k_st + (int64_t)kvh * k_sh + l * 64 + pc_)); \
+        }                                                                                      \
+      }                                                                                        \
+      _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                          \
+        const int64_t rowA_ = __shfl(rsrc_, ((TI) & 1) * 32 + g * 8 + tl_, 64);                \
+        const int64_t rowB_ = __shfl(rsrc_, ((TI) & 1) * 32 + 16 + g * 8 + tl_, 64);           \
+        _Pragma("unroll") for (int l = 0; l < 2; ++l) {                                        \
+          va##S[g * 2 + l] = fd_gather<FD_NT != 0>(reinterpret_cast<const KVR*>(vcE + rowA_ * v_st + (int64_t)kvh * v_sh + l * 64 + pc_)); \
+          vb##S[g * 2 + l] = fd_gather<FD_NT != 0>(reinterpret_cast<const KVR*>(vcE + rowB_ * v_st + (int64_t)kvh * v_sh + l * 64 + pc_)); \
+        }                                                                                      \
+      }                                                                                        \
+    } else {                                                                                   \
     const int64_t rowA_ = __shfl(rsrc_, ((TI) & 1) * 32 + t, 64);                              \
     const int64_t rowB_ = __shfl(rsrc_, ((TI) & 1) * 32 + 16 + t, 64);                         \
     const KVE* kA_ = kcE + rowA_ * k_st + (int64_t)kvh * k_sh + c * 8;                        \
@@ -347,6 +401,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     _Pragma("unroll") for (int s = 0; s < NS; ++s) kb##S[s] = fd_gather(reinterpret_cast<const KVR*>(kB_ + s * 32)); \
     _Pragma("unroll") for (int s = 0; s < NS; ++s) va##S[s] = fd_gather(reinterpret_cast<const KVR*>(vA_ + s * 32)); \
     _Pragma("unroll") for (int s = 0; s < NS; ++s) vb##S[s] = fd_gather(reinterpret_cast<const KVR*>(vB_ + s * 32)); \
+    }                                                                                          \
   }
 
   // The V tile belongs to ONE wave: its LDS operations execute in order, so within a multi-wave (GROUPED) workgroup a
@@ -361,6 +416,10 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
   {                                                                                            \
     const int64_t pos0 = start + (TI) * 32;                                                    \
     const bool okA = pos0 + t < end, okB = pos0 + 16 + t < end;                                \
+    if constexpr (FDFL) {                                                                      \
+      fd_fix_fragments(ka##S, t >= 8);                                                         \
+      fd_fix_fragments(kb##S, t >= 8);                                                         \
+    }                                                                                          \
     /* S^T tiles: rows = tokens (4c+r), cols = heads (t) */                                    \
     f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};                                \
     _Pragma("unroll") for (int s = 0; s < NS; ++s) sa = mfma16<DT>(FdKv<KV8>::frag(ka##S[s]), qf[s], sa); \
@@ -394,6 +453,17 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     pf.w = pack2<DT>(p[6], p[7]);                                                              \
     /* stage V rows through LDS (zero rows past the end: garbage could be NaN) */              \
     FD_WAVE_SYNC(); /* previous tile's reads done */                                           \
+    if constexpr (FDFL) { /* raw registers: (row g * 8 + (t & 7), line l, piece c + 4 (t >> 3)) */ \
+      const int tl_ = t & 7, pc_ = (c + 4 * (t >> 3)) * 8;                                     \
+      const bool full_ = pos0 + 32 <= end;                                                     \
+      _Pragma("unroll") for (int g = 0; g < 2; ++g) {                                          \
+        const bool okA_ = full_ || pos0 + g * 8 + tl_ < end, okB_ = full_ || pos0 + 16 + g * 8 + tl_ < end; \
+        _Pragma("unroll") for (int l = 0; l < 2; ++l) {                                        \
+          *reinterpret_cast<Q4*>(&lds_v[(g * 8 + tl_) * VSTR + l * 64 + pc_]) = okA_ ? va##S[g * 2 + l] : Q4{0, 0, 0, 0};      \
+          *reinterpret_cast<Q4*>(&lds_v[(16 + g * 8 + tl_) * VSTR + l * 64 + pc_]) = okB_ ? vb##S[g * 2 + l] : Q4{0, 0, 0, 0}; \
+        }                                                                                      \
+      }                                                                                        \
+    } else                                                                                     \
     if (pos0 + 32 <= end) { /* whole tile inside the context (wave-uniform): no masking */     \
       _Pragma("unroll") for (int s = 0; s < NS; ++s) {                                         \
         *reinterpret_cast<Q4*>(&lds_v[t * VSTR + s * 32 + c * 8]) = FdKv<KV8>::frag(va##S[s]); \
