@@ -59,7 +59,15 @@ struct D8Params {
   // one split only (16-bit form): the kernel applies the epilogue itself -- out 16-bit [M][N], bias or nullptr
   uint16_t* direct_out;
   const uint16_t* direct_bias;
+  int nt_w;               // weight stream read with the non-temporal policy (d8_nt: big, bandwidth-bound streams only)
 };
+// Non-temporal weight loads pay where the launch is bandwidth-bound -- lm_head 151936 x 1536 fp16: 97.3 -> 88.7 us, 152064 x
+// 3584: 230 -> 220, Llama-3-8B W8A8 step 4.92 -> 4.76 ms with nt everywhere -- and COST 4 - 6 % on mid-size streams that run at
+// ~2.4 TB/s (17920 x 1536 fp16: 22.5 -> 24.1 us; same box, round 3): by size, LL_D8_NT_MIN_MB (default 96) megabytes.
+static int d8_nt(int64_t weight_bytes) {
+  static const int64_t min_mb = getenv("LL_D8_NT_MIN_MB") ? atoll(getenv("LL_D8_NT_MIN_MB")) : 96;
+  return weight_bytes >= min_mb * (1ll << 20) ? 1 : 0;
+}
 
 typedef __bf16 d8_bf16x8 __attribute__((ext_vector_type(8)));
 
@@ -119,8 +127,13 @@ __global__ __launch_bounds__(256) void dense8_kernel(const D8Params p) {
 
   i32x4 wreg[4], areg[APASS];
   auto fetch = [&](int c) {
+    if (p.nt_w) {  // (wave-uniform) the weight stream: whole 128-byte lines, read once
 #pragma unroll
-    for (int ps = 0; ps < 4; ++ps) wreg[ps] = *reinterpret_cast<const i32x4*>(wsrc[ps] + (int64_t)c * 128);
+      for (int ps = 0; ps < 4; ++ps) wreg[ps] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wsrc[ps] + (int64_t)c * 128));
+    } else {
+#pragma unroll
+      for (int ps = 0; ps < 4; ++ps) wreg[ps] = *reinterpret_cast<const i32x4*>(wsrc[ps] + (int64_t)c * 128);
+    }
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps)  // rows without a token all re-read ONE piece: their LDS rows are zeroed
       areg[ps] = *reinterpret_cast<const i32x4*>(aok[ps] ? asrc[ps] + (int64_t)c * (KCH * AB) : (const unsigned char*)p.x);
@@ -306,6 +319,7 @@ extern "C" int ll_dense8_try(void* out, const void* x, const void* w, const floa
   p.s_stride_n = s_stride_n; p.s_stride_k = s_stride_k; p.group_n = group_n > 0 ? group_n : 1;
   p.group_k = group_k > 0 ? group_k : k;
   p.chunks = (int)(k / 128);
+  p.nt_w = d8_nt(n * k);
   const int splits = d8_splits(n, k);
   p.cps = (p.chunks + splits - 1) / splits;
   const int used = (p.chunks + p.cps - 1) / p.cps;  // every launched split has at least one chunk
@@ -357,6 +371,7 @@ extern "C" int ll_dense16_matmul(void* out, const void* x, const void* w, const 
   p.m = m; p.n = n; p.k = k; p.x_stride = x_stride; p.w_stride = w_stride * 2;  // bytes
   p.group_n = 1; p.group_k = k;
   p.chunks = (int)(k / 64);
+  p.nt_w = d8_nt(n * k * 2);
   const int splits = d8_splits(n, k, 64);
   p.cps = (p.chunks + splits - 1) / splits;
   const int used = (p.chunks + p.cps - 1) / p.cps;
