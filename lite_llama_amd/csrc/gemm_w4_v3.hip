@@ -85,6 +85,9 @@ struct V3Params {
   int nblocks, chunks, total_units, upw, slots;
   int gt, gbase, grem, glead;  // tile-group split, see v3_plan
   int err_idx;  // index of the launch's error word in `counters` (just past the merge counters)
+  int xcd_shift;  // >= 0 (split-K partial mode, gt = 1 << xcd_shift <= 8, grid % 8 == 0): workgroup b = 8 q + x -- on XCD x under
+                  // the round-robin dispatch -- takes k-slice x % gt of tile q * (8 / gt) + x / gt, so one XCD's L2 only ever sees
+                  // ONE k-slice of the activation matrix (1 / gt of it) instead of all of it; -1: b = tile * gt + slice
   uint32_t chunks_magic, gt_magic, upw_magic;  // ceil(2^32 / d): x / d = umulhi(x, magic) for the unit / workgroup indices of a launch (< 2^20)
   int gshift;                  // log2(group_size / 128)
   int epi;                     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu;  2: fp32 split-K partials [slot][m][n]
@@ -565,8 +568,18 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   V3_TL(0)
   V3_TLC(61)
   int ub, ue;
+  int my_slice = -1;
   if (p.gt) {
-    const int gtile = v3_div((int)blockIdx.x, p.gt_magic, p.gt), j = (int)blockIdx.x - gtile * p.gt;
+    int gtile, j;
+    if (p.xcd_shift >= 0) {
+      const int x = (int)blockIdx.x & 7, q = (int)blockIdx.x >> 3;
+      j = x & (p.gt - 1);
+      gtile = q * (8 >> p.xcd_shift) + (x >> p.xcd_shift);
+      my_slice = j;
+    } else {
+      gtile = v3_div((int)blockIdx.x, p.gt_magic, p.gt);
+      j = (int)blockIdx.x - gtile * p.gt;
+    }
     const int lo = j * p.gbase + (j < p.grem ? j : p.grem);
     ub = gtile * chunks + lo;
     ue = j == p.gt - 1 ? (gtile + 1) * chunks : ub + p.gbase + (j < p.grem ? 1 : 0);
@@ -667,7 +680,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   auto flush = [&](f32x16& v0, f32x16& v1, auto nm_tag, int mt0, int t, int f, int c_lo, int c_hi) {
     constexpr int NM = decltype(nm_tag)::value;
     const int w0 = p.gt ? t * p.gt : v3_div(t * chunks, p.upw_magic, p.upw);  // first contributor of the tile
-    const int slot = (int)blockIdx.x - w0;
+    const int slot = my_slice >= 0 ? my_slice : (int)blockIdx.x - w0;
     const int blk = t * NF + f;  // 128-row block
     auto vsel = [&](int i) -> f32x16& { return i == 0 ? v0 : v1; };
     if (p.epi == 2) {
@@ -1150,11 +1163,14 @@ struct V3Plan {
   int nf;  // 128-row blocks per tile
   int nblocks, chunks, total_units, upw, grid, slots;
   int gt, gbase, grem, glead;
+  int xcd_shift = -1;  // V3Params::xcd_shift
 };
 
 struct V3Knobs {
   int wgs = 0, lead = 4, gt_cap_div = 5, gt_cap = -1, nf = 0;
+  int xcd = 8;  // split-K partial launches take a power-of-two split <= this and the XCD-aware map (LL_GEMM3_XCD=0: off)
   V3Knobs() {
+    if (const char* e = getenv("LL_GEMM3_XCD")) xcd = atoi(e);
     if (const char* e = getenv("LL_GEMM3_WGS")) wgs = atoi(e);
     if (const char* e = getenv("LL_GEMM3_LEAD")) lead = atoi(e);
     if (const char* e = getenv("LL_GEMM3_GT")) gt_cap = atoi(e);
@@ -1200,6 +1216,22 @@ static V3Plan v3_plan(int64_t n, int64_t k, int nf_force = 0, bool partials = fa
   const int gt_cap = kn.gt_cap >= 0 ? kn.gt_cap : pl.chunks / kn.gt_cap_div;
   if (gt > gt_cap) gt = gt_cap;
   if (partials && gt < 1) gt = 1;
+  if (partials && kn.xcd > 0 && pl.nblocks > 0) {
+    int want = target / pl.nblocks;  // (not capped by gt_cap: the XCD-aware split trades chunks per workgroup for L2 locality)
+    if (want > kn.xcd) want = kn.xcd;
+    if (want > 8) want = 8;
+    if (want > pl.chunks) want = pl.chunks;
+    int g2 = 1, sh = 0;
+    while (g2 * 2 <= want) { g2 *= 2; ++sh; }
+    // Same box, us per launch (round 3): o 3584 x 3584 8.75 -> 8.11 (8 slices instead of 5), down 3584 x 18944 18.5 -> 18.2 (8
+    // instead of 9), FETCH_SIZE of the 128-row launches 13.4 -> 9.6 MB on average (down 28.2 -> 19.9: the activation matrix
+    // crosses the fabric once instead of once per XCD); q|k|v 4608 x 3584 would drop to 4 slices = 144 workgroups and is
+    // SLOWER (9.19 -> 9.45): taken only when the launch still fills >= 85 % of the CUs.
+    if ((pl.nblocks * g2) % 8 == 0 && pl.nblocks * g2 * 100 >= target * 85) {
+      gt = g2;
+      pl.xcd_shift = sh;
+    }
+  }
   if ((lead > 0 || partials) && gt >= (partials ? 1 : 2) && pl.chunks - lead >= gt) {
     pl.gt = gt;
     pl.glead = lead;
@@ -1295,6 +1327,7 @@ static int v3_launch(void* out, const void* x, const void* wpacked, const void* 
   // umulhi(x, ceil(2^32 / d)) == x / d for x * d < 2^32 (x: unit / workgroup indices); d == 1 is handled by the guard below
   if ((int64_t)pl.total_units * (pl.chunks > pl.upw ? pl.chunks : pl.upw) >= (1ll << 31)) return LL_ERR_SHAPE;
   p.err_idx = (int)(n / V3_BN * 8);
+  p.xcd_shift = (partials && pl.gt >= 1 && pl.grid == pl.nblocks * pl.gt) ? pl.xcd_shift : -1;
   p.chunks_magic = magic(pl.chunks);
   p.gt_magic = magic(pl.gt);
   p.upw_magic = magic(pl.upw);
