@@ -563,13 +563,23 @@ def main():
     # the reference rule.  Remaining GPUs are data-parallel replicas (no collective between them).
     from lite_llama_amd.distributed.partition import admissible_tp, make_plan
     if geo.num_experts:
-        tp = 1
+        # MoE: the attention heads on a plan (KV heads replicated for tp > Hkv), the experts on the reference's equal cut of their
+        # intermediate dimension -- admitted when the cut keeps whole scale blocks of the run's quantisation (per-channel
+        # formats: any cut; 128 x 128 blocks: multiples of 128)
+        q_run = None if args.quant == "none" else QuantConfig.for_runtime_scheme(args.quant)
+        tp, plan_note = 1, None
         for cand in (8, 4, 2, 1):
-            if world % cand == 0 and geo.num_heads % cand == 0 and geo.num_kv_heads % cand == 0 and \
-                    (geo.moe_intermediate_size // cand) % 128 == 0:
-                tp = cand
-                break
-        plan_note = None
+            if world % cand or geo.moe_intermediate_size % cand:
+                continue
+            if q_run is not None and not q_run.shard_is_aligned(geo.moe_intermediate_size // cand):
+                continue
+            try:
+                plan_note = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, cand * 128, cand).describe() + \
+                    f"; experts: {geo.moe_intermediate_size // cand} intermediate channels per rank"
+            except ValueError:
+                continue
+            tp = cand
+            break
     else:
         tp = admissible_tp(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, world)
         plan_note = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, tp).describe()

@@ -220,6 +220,9 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(const MoeParams p) {
     __syncthreads();
     const int kbase = c * 128 + h * 64;
     uint32_t sp = 0;
+    // scale blocks along k: one per 64-k half when group_k is a multiple of 64 (or covers K); finer grids -- a
+    // tensor-parallel shard that cuts the checkpoint's 128-blocks and re-expresses them at gcd(128, shard) -- per 8-k step
+    const bool fine_k = p.group_k % 64 != 0 && p.group_k < K;
     if constexpr (WFMT != LL_W_F16) {
       const int kq = kbase < K ? kbase : K - 1;
       const float sv = srow[(int64_t)(kq / p.group_k) * p.s_stride_k];
@@ -229,6 +232,13 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(const MoeParams p) {
     for (int s = 0; s < 8; ++s) {
       const int kk = kbase + s * 8;
       Q4 wf = Q4{0, 0, 0, 0};
+      if constexpr (WFMT != LL_W_F16) {
+        if (fine_k) {
+          const int kq = kk < K ? kk : K - 1;
+          const float sv = srow[(int64_t)(kq / p.group_k) * p.s_stride_k];
+          sp = mpk_bcast(WFMT == LL_W_FP8E4M3 ? sv * 256.0f : sv);
+        }
+      }
       if (kk < K) {
         if constexpr (WFMT == LL_W_F16) {
           wf = *reinterpret_cast<const Q4*>(wrow + (int64_t)kk * 2);
@@ -409,6 +419,7 @@ extern "C" int ll_moe_gemm(void* c, const void* a, const void* w, const float* w
   if (block_m != 16 && block_m != 32 && block_m != 64) return LL_ERR_SHAPE;
   if (n <= 0 || k <= 0 || top_k <= 0 || k % 8 != 0 || a_stride_m % 8 != 0) return LL_ERR_SHAPE;
   if (wfmt != LL_W_F16 && (!w_scale || group_n <= 0 || group_k <= 0)) return LL_ERR_ARG;
+  if (wfmt != LL_W_F16 && group_k < k && group_k % 8 != 0) return LL_ERR_SHAPE;  // a scale block spans whole 8-k MFMA steps
   if (wfmt == LL_W_F16 ? (w_stride_n % 8 != 0) : (w_stride_n % 8 != 0)) return LL_ERR_SHAPE;
   if (num_slots == 0) return LL_OK;
   MoeParams p{};

@@ -87,8 +87,14 @@ def fused_moe(
     w2_scale: torch.Tensor | None = None,
     group_n: int = 0,
     group_k: int = 0,
+    w1_group: tuple | None = None,
+    w2_group: tuple | None = None,
 ) -> torch.Tensor:
     """``sum_k w_k * (silu(x W1g^T) * (x W1u^T)) W2^T`` over each token's top-k experts.
+
+    ``w1_group`` / ``w2_group`` (extension, ``(group_n, group_k)`` per matrix): a tensor-parallel shard whose cut does
+    not end on the checkpoint's scale blocks carries its scales re-expressed on a finer grid -- gate|up along N, down
+    along K (model.py::SparseMoeBlock); multiples of 8 along K.
 
     Pipeline and intermediate dtypes as the reference: align -> GEMM1 (``[T*k, 2I]`` in x's
     dtype) -> silu*up -> GEMM2 with the router weight folded in fp32 -> fp32 sum over top_k."""
@@ -102,8 +108,12 @@ def fused_moe(
     wfmt = _wfmt(w1, w1_scale)
     if wfmt != _wfmt(w2, w2_scale):
         raise ValueError("w1 and w2 must use the same quantisation format")
-    if wfmt and group_k % 128 != 0 and group_k < min(hidden, intermediate):
+    if wfmt and group_k % 128 != 0 and group_k < min(hidden, intermediate) and w1_group is None and w2_group is None:
         raise ValueError(f"group_k ({group_k}) must be a multiple of 128 unless it covers K")
+    g1 = w1_group if w1_group is not None else (group_n, group_k)
+    g2 = w2_group if w2_group is not None else (group_n, group_k)
+    if wfmt and any(gk < kdim and gk % 8 for gk, kdim in ((g1[1], hidden), (g2[1], intermediate))):
+        raise ValueError("scale blocks along K must be multiples of 8")
     L.require_cuda(hidden_states, w1, w2, topk_weights, topk_ids, w1_scale, w2_scale)
     if hidden_states.stride(-1) != 1:
         hidden_states = hidden_states.contiguous()
@@ -116,7 +126,7 @@ def fused_moe(
 
     gate_up = torch.empty((num_tokens * top_k, two_inter), device=device, dtype=dtype)
     _moe_gemm(hidden_states, w1, gate_up, w1_scale, flat_weights, sorted_ids, expert_ids, num_post,
-              top_k, False, wfmt, group_n, group_k, block_m)
+              top_k, False, wfmt, g1[0], g1[1], block_m)
 
     act = torch.empty((num_tokens * top_k, intermediate), device=device, dtype=dtype)
     L.check(
@@ -129,7 +139,7 @@ def fused_moe(
     # fused_moe.py:420-430) and folds the router weight in fp32.
     expanded = torch.empty((num_tokens * top_k, hidden), device=device, dtype=dtype)
     _moe_gemm(act, w2, expanded, w2_scale, flat_weights, sorted_ids, expert_ids, num_post,
-              1, True, wfmt, group_n, group_k, block_m)
+              1, True, wfmt, g2[0], g2[1], block_m)
 
     out = torch.empty((num_tokens, hidden), device=device, dtype=dtype)
     L.check(

@@ -92,10 +92,18 @@ GEOMETRY = {
 def shard_plan(geo: ModelGeometry, quant: QuantConfig | None, tp: int | None = None) -> ShardPlan | None:
     """The tensor-parallel cut of this geometry: ``None`` when the reference's equal division applies (its code path and
     error messages stay in charge), else the extension plan of distributed/partition.py (KV-head replication, whole scale
-    groups per rank).  MoE geometries keep the reference rule."""
+    groups per rank).  MoE geometries: the plan only lays out the attention heads (KV heads replicated for tp > Hkv --
+    Qwen3-30B-A3B's 32 / 4 heads at TP = 8); the experts keep the reference's equal cut of their intermediate dimension
+    (SparseMoeBlock checks it against the scale granularity)."""
     tp = get_tp_world_size() if tp is None else tp
-    if tp == 1 or geo.num_experts:
+    if tp == 1:
         return None
+    if geo.num_experts:
+        try:
+            plan = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, tp * 128, tp)  # (dense intermediate unused)
+        except ValueError:
+            return None
+        return None if plan.uniform else plan
     try:
         plan = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, tp,
                          unit=max(quant.group_k, 1) if quant is not None and quant.group_k < geo.intermediate_size else 128)
@@ -372,12 +380,21 @@ class SparseMoeBlock(nn.Module):
         self.top_k = geo.num_experts_per_tok
         self.norm_topk_prob = geo.norm_topk_prob
         self.moe_intermediate_size = divide(geo.moe_intermediate_size, tp, "MoE intermediate")
+        # Extension: a shard that cuts the checkpoint's scale blocks -- Qwen3-30B-A3B's 768 channels over 4 / 8
+        # ranks = 192 / 96 -- keeps the block's scale value on a finer grid of cut = gcd(block, shard) channels: gate|up's
+        # grid is refined along N, down's along K (the loader / quantise-then-cut path repeats every scale block / cut
+        # times, weights.py::expand_scale_grid).  Same dequantised weights, so the ranks still partition the unsharded model.
+        self.scale_cut = 0
         if quant is not None and not quant.shard_is_aligned(self.moe_intermediate_size):
-            raise ValueError(
-                f"tensor-parallel shard of MoE intermediate is {self.moe_intermediate_size} channels, which is not "
-                f"a multiple of the {quant.format} scale block ({quant.group_n}x{quant.group_k}); "
-                "use a smaller tensor_parallel_size"
-            )
+            block = max(quant.group_n, quant.group_k)
+            cut = math.gcd(block, self.moe_intermediate_size)
+            if quant.is_int4 or quant.group_n != quant.group_k or cut % 8 != 0:
+                raise ValueError(
+                    f"tensor-parallel shard of MoE intermediate is {self.moe_intermediate_size} channels, which is not "
+                    f"a multiple of the {quant.format} scale block ({quant.group_n}x{quant.group_k}); "
+                    "use a smaller tensor_parallel_size"
+                )
+            self.scale_cut = cut
         self.quant = quant
         self.quant_method = get_moe_method(quant)
         self.gate_weight = nn.Parameter(torch.empty(self.num_experts, self.hidden_size, dtype=torch.float16),

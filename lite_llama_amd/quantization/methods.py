@@ -228,20 +228,39 @@ class UnquantizedMoeMethod(MoeQuantMethod):
 class W8A16MoeMethod(MoeQuantMethod):
     """methods/w8a16.py:66-112."""
 
+    @staticmethod
+    def groups(block):
+        """``((gn, gk) of gate|up, (gn, gk) of down)``: the config's blocks, or -- ``block.scale_cut`` (a TP shard that cuts
+        them, model.py::SparseMoeBlock) -- the finer grid along the cut dimension (N of gate|up, K of down)."""
+        q = block.quant
+        cut = getattr(block, "scale_cut", 0)
+        if cut:
+            return (cut, q.group_k), (q.group_n, cut)
+        return (q.group_n, q.group_k), (q.group_n, q.group_k)
+
     def create_weights(self, block):
         q = block.quant
         gu_n, gu_k = 2 * block.moe_intermediate_size, block.hidden_size
         d_n, d_k = block.hidden_size, block.moe_intermediate_size
         e = block.num_experts
+        (g1n, g1k), (g2n, g2k) = self.groups(block)
+        cdiv = lambda a, b: (a + b - 1) // b
         return {
             "gate_up_proj": RawParameter(torch.empty(e, gu_n, gu_k, dtype=q.storage_dtype)),
-            "gate_up_proj_scale_inv": RawParameter(torch.empty(e, *q.scale_shape(gu_n, gu_k), dtype=torch.float32)),
+            "gate_up_proj_scale_inv": RawParameter(torch.empty(e, cdiv(gu_n, g1n), cdiv(gu_k, g1k), dtype=torch.float32)),
             "down_proj": RawParameter(torch.empty(e, d_n, d_k, dtype=q.storage_dtype)),
-            "down_proj_scale_inv": RawParameter(torch.empty(e, *q.scale_shape(d_n, d_k), dtype=torch.float32)),
+            "down_proj_scale_inv": RawParameter(torch.empty(e, cdiv(d_n, g2n), cdiv(d_k, g2k), dtype=torch.float32)),
         }
 
     def apply(self, block, x, topk_weights, topk_ids):
         q = block.quant
+        if getattr(block, "scale_cut", 0):
+            g1, g2 = self.groups(block)
+            return fused_moe(
+                x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids,
+                w1_scale=block.experts["gate_up_proj_scale_inv"], w2_scale=block.experts["down_proj_scale_inv"],
+                group_n=q.group_n, group_k=q.group_k, w1_group=(g1[0], min(g1[1], block.hidden_size)), w2_group=g2,
+            )
         return fused_moe(
             x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids,
             w1_scale=block.experts["gate_up_proj_scale_inv"], w2_scale=block.experts["down_proj_scale_inv"],

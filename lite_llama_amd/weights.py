@@ -14,6 +14,7 @@ that slice (gate / up inside an expert).
 
 from __future__ import annotations
 
+import math
 import re
 from collections.abc import Callable, Iterable, Iterator, Mapping
 from dataclasses import dataclass
@@ -137,12 +138,32 @@ def shard_dim(param_name: str) -> int | None:
     return None
 
 
+def expand_scale_grid(grid: torch.Tensor, dim: int, block: int, cut: int) -> torch.Tensor:
+    """A block-scale grid re-expressed on blocks of ``cut`` (a divisor of ``block``) channels along ``dim``: every entry
+    repeated ``block / cut`` times -- the same scale for the same weight, on the grid a tensor-parallel shard that cuts
+    the checkpoint's blocks is stored on (model.py::SparseMoeBlock.scale_cut)."""
+    if cut <= 0 or block % cut != 0:
+        raise ValueError(f"cannot re-express {block}-channel scale blocks on {cut}-channel blocks")
+    return grid if cut == block else grid.repeat_interleave(block // cut, dim=dim)
+
+
+def _is_expert_scale(name: str) -> bool:
+    return ".mlp.experts." in name and name.endswith("_scale_inv")
+
+
 def _narrow_for_rank(name: str, tensor: torch.Tensor, dim: int) -> torch.Tensor:
     world = get_tp_world_size()
     size = tensor.shape[dim]
     ext = plan_range(_module_of(name), size, get_tp_rank())  # extension plan in force (distributed/partition.py)?
     if ext is not None:
         return tensor.narrow(dim, ext[0], ext[1])
+    if size % world != 0 and _is_expert_scale(name) and (size * FP8_BLOCK) % world == 0:
+        # extension: the experts' intermediate dimension cut inside a scale block (768 channels over 4 / 8 ranks): the grid
+        # is refined to gcd(block, shard) channels first, then cut evenly
+        shard = size * FP8_BLOCK // world
+        cut = math.gcd(FP8_BLOCK, shard)
+        fine = expand_scale_grid(tensor, dim, FP8_BLOCK, cut)
+        return fine.narrow(dim, get_tp_rank() * (shard // cut), shard // cut)
     if size % world != 0:
         raise ValueError(f"{name}: dimension {dim} of size {size} does not divide across {world} tensor-parallel ranks")
     return tensor.narrow(dim, get_tp_rank() * (size // world), size // world)

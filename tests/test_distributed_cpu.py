@@ -4,6 +4,7 @@ Covers the rank grid arithmetic (reference tests/distributed/test_parallel_state
 SUM all-reduce of RowParallelLinear, shard-alignment errors, and that column->row sharded
 projections reproduce the unsharded result (which the reference never unit-tests for tp > 1)."""
 
+import math
 import os
 import socket
 
@@ -205,3 +206,61 @@ def test_tp8_extension_plan_sharded_equals_unsharded_gloo():
     want = _block_math(*_plan_case())  # tp = 1 in this process: the same seeded full matrices, uncut
     for rank, _, out in results:
         torch.testing.assert_close(torch.from_numpy(out), want, rtol=1e-4, atol=1e-4)
+
+
+def test_moe_expert_scale_grid_is_refined_before_an_inside_block_cut(monkeypatch):
+    """Extension (SURVEY 8e, config 5 at TP 4 / 8): Qwen3-30B-A3B's 768 expert channels over 4 / 8 ranks = 192 / 96 per
+    rank cut the checkpoint's 128 x 128 fp8 scale blocks.  The loader refines the grid to gcd(128, shard) = 64 / 32 channels
+    (every scale repeated) and cuts evenly; the dequantised shard is exactly the rank's slice of the dequantised tensor --
+    for gate / up (cut along N, dim 0 of the grid) and for down (cut along K, dim 1)."""
+    import lite_llama_amd.weights as W
+
+    g = torch.Generator().manual_seed(3)
+    I, H = 768, 512
+    for world in (4, 8):
+        sh = I // world
+        cut = math.gcd(128, sh)
+        for which, (n, k, dim) in {"gate": (I, H, 0), "down": (H, I, 1)}.items():
+            w = torch.randn(n, k, generator=g)
+            s = torch.rand(n // 128, k // 128, generator=g) + 0.5
+            full = w * s.repeat_interleave(128, 0).repeat_interleave(128, 1)
+            name = "layers.0.mlp.experts.gate_up_proj_scale_inv" if which == "gate" else "layers.0.mlp.experts.down_proj_scale_inv"
+            for rank in range(world):
+                monkeypatch.setattr(W, "get_tp_world_size", lambda world=world: world)
+                monkeypatch.setattr(W, "get_tp_rank", lambda rank=rank: rank)
+                s_r = W._narrow_for_rank(name, s, dim)
+                w_r = w.narrow(dim, rank * sh, sh)
+                gn, gk = (cut, 128) if dim == 0 else (128, cut)
+                assert tuple(s_r.shape) == (w_r.shape[0] // gn, w_r.shape[1] // gk)
+                deq = w_r * s_r.repeat_interleave(gn, 0).repeat_interleave(gk, 1)
+                assert torch.equal(deq, full.narrow(dim, rank * sh, sh)), (world, which, rank)
+    # aligned cuts are untouched (TP = 2: three whole blocks per rank)
+    monkeypatch.setattr(W, "get_tp_world_size", lambda: 2)
+    monkeypatch.setattr(W, "get_tp_rank", lambda: 1)
+    s = torch.rand(6, 4, generator=g)
+    assert torch.equal(W._narrow_for_rank("layers.0.mlp.experts.gate_up_proj_scale_inv", s, 0), s[3:6])
+
+
+def test_moe_block_shapes_under_an_inside_block_cut(monkeypatch):
+    """SparseMoeBlock at TP = 4 / 8 with 128 x 128 fp8 blocks: scale_cut 64 / 32, gate|up's scale grid refined along N, down's
+    along K; int4 experts and one-sided groups still refuse the cut with the reference's message."""
+    import lite_llama_amd.model as M
+    from lite_llama_amd.quantization import QuantConfig
+
+    geo = M.tiny_geometry(hidden_size=512, intermediate_size=1024, num_layers=1, num_heads=8, num_kv_heads=4, head_dim=64,
+                          vocab_size=256, num_experts=4, num_experts_per_tok=2, moe_intermediate_size=768)
+    for world, cut in ((2, 0), (4, 64), (8, 32)):
+        monkeypatch.setattr(M, "get_tp_world_size", lambda world=world: world)
+        blk = M.SparseMoeBlock(geo, QuantConfig.fp8_block(128, 128))
+        sh = 768 // world
+        assert blk.scale_cut == cut and blk.moe_intermediate_size == sh
+        g = cut or 128
+        assert tuple(blk.experts["gate_up_proj_scale_inv"].shape) == (4, 2 * sh // g, 512 // 128)
+        assert tuple(blk.experts["down_proj_scale_inv"].shape) == (4, 512 // 128, sh // g)
+    monkeypatch.setattr(M, "get_tp_world_size", lambda: 4)
+    with pytest.raises(ValueError, match="not a multiple of the"):
+        M.SparseMoeBlock(geo, QuantConfig.int8_groupwise(128))
+    # MoE geometries now get an attention-head plan: Qwen3-30B-A3B's 32 / 4 heads at TP = 8 replicate every KV head on two ranks
+    plan = M.shard_plan(M.GEOMETRY["qwen3-30b-a3b"], QuantConfig.fp8_per_channel(), tp=8)
+    assert plan is not None and [n for _, n in plan.q_heads] == [4] * 8 and [s for s, _ in plan.kv_heads] == [0, 0, 1, 1, 2, 2, 3, 3]
+    assert M.shard_plan(M.GEOMETRY["qwen3-30b-a3b"], QuantConfig.fp8_per_channel(), tp=4) is None  # the reference's equal cuts

@@ -31,6 +31,11 @@ def _geometry(which="tp2"):
         # reference's rules at TP = 8 -> extension plan (4 + 3 query heads per rank, KV heads on two ranks, 2,2,2,2,1,1,1,1 groups)
         return tiny_geometry(hidden_size=512, intermediate_size=1536, num_layers=2, num_heads=28, num_kv_heads=4, head_dim=128,
                              vocab_size=640, qkv_bias=True)
+    if which == "moe8":  # Qwen3-MoE-shaped: 16 / 4 heads with q/k norms (KV heads on two ranks each at TP = 8), 8 experts top-2
+        # whose 256 intermediate channels are cut into 32 per rank
+        return tiny_geometry(hidden_size=512, intermediate_size=1024, num_layers=2, num_heads=16, num_kv_heads=4, head_dim=64,
+                             vocab_size=640, qkv_bias=False, use_qk_norm=True, num_experts=8, num_experts_per_tok=2,
+                             moe_intermediate_size=256, norm_topk_prob=True)
     return tiny_geometry(hidden_size=512, intermediate_size=1024, num_layers=2, num_heads=8, num_kv_heads=2, head_dim=64,
                          vocab_size=640, qkv_bias=True)
 
@@ -41,7 +46,7 @@ def _run(which="tp2"):
     from lite_llama_amd.model import CausalLM
     from lite_llama_amd.quantization import QuantConfig
 
-    quant = QuantConfig.int4_groupwise(128)
+    quant = None if which == "moe8" else QuantConfig.int4_groupwise(128)  # (fp16 experts: every rank's shard is an exact cut)
     model = CausalLM(_geometry(which), quant).init_synthetic(seed=9, quant=quant, device="cuda")
     eng = DecodeEngine(model, max_batch=2, max_seq_len=32)
     g = torch.Generator().manual_seed(4)
@@ -122,7 +127,7 @@ def test_tp2_sharded_int4_decode_matches_tp1():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("world,which,oneshot", [(8, "tp8", False), (4, "tp4plan", True)])
+@pytest.mark.parametrize("world,which,oneshot", [(8, "tp8", False), (4, "tp4plan", True), (8, "moe8", False)])
 def test_tp8_extension_plan_int4_decode_matches_tp1(world, which, oneshot):
     """EIGHT ranks on the one GPU, a geometry the reference refuses at TP = 8 (28 / 4 heads, an intermediate that does not
     divide into eight group-aligned parts): the extension plan of distributed/partition.py -- 4 + 3 query heads per rank,
@@ -134,6 +139,8 @@ def test_tp8_extension_plan_int4_decode_matches_tp1(world, which, oneshot):
     from lite_llama_amd.distributed.partition import make_plan
 
     assert not make_plan(28, 4, 128, 1536, 8).uniform and not make_plan(14, 2, 128, 768, 4).uniform
+    # "moe8": a sparse-MoE geometry at TP = 8 -- the attention heads on the plan (the reference refuses tp > Hkv), the
+    # experts' intermediate dimension on the equal cut
     ctx = mp.get_context("spawn")
     q = ctx.Queue()
     port = _free_port()
