@@ -226,14 +226,13 @@ class SlotBatch:
     ``b_seq_len`` are rebuilt from the host only when the running set changes."""
 
     def __init__(self, runner) -> None:
-        self._runner = runner
-        self._atten = runner.atten_info
-        self.device = runner.device
-        self.max_seq_len = runner.max_seq_len
         table = runner.b_req_tokens_table
-        total_slots, row_len = table.shape
-        self._filler_slot: int | None = total_slots - 1 if total_slots > 1 else None
-        self.num_slots = total_slots - 1 if total_slots > 1 else 1
+        total_slots, row_len = (int(v) for v in table.shape)
+        has_filler = total_slots > 1  # the table's last row backs the filler entries of a padded decode batch
+        self._runner, self._atten = runner, runner.atten_info
+        self.device, self.max_seq_len = runner.device, runner.max_seq_len
+        self.num_slots = total_slots - 1 if has_filler else 1
+        self._filler_slot: int | None = total_slots - 1 if has_filler else None
         table.copy_(torch.arange(total_slots * row_len, dtype=table.dtype, device=self.device).view(total_slots, row_len))
         if self._filler_slot is not None:
             start = self._filler_slot * row_len
@@ -263,18 +262,16 @@ class SlotBatch:
     def begin_prefill(self, slots: Sequence[int], prompt_lens: Sequence[int]) -> None:
         """Sequence ``i``'s token ``j`` of the row-major ``[n, max_prompt_len]`` grid lands in slot
         ``slots[i]``'s row ``j`` (pad positions write junk the sequence's own decode overwrites)."""
-        max_prompt_len = max(prompt_lens)
-        if max_prompt_len > self.max_seq_len:
-            raise ValueError(f"prompt length {max_prompt_len} exceeds max_seq_len {self.max_seq_len}")
-        n = len(slots)
-        b_req_idx = self._to_device(slots)
-        table = self._atten.b_req_tokens_table
-        self._atten.b_req_idx = b_req_idx
-        self._atten.b_seq_len = self._to_device(prompt_lens)
-        self._atten.max_actual_seq_len = max_prompt_len
-        self._atten.cur_select_index = table[b_req_idx, :max_prompt_len].reshape(-1)
-        self._atten.b_start_loc = self._row_offsets[:n] * max_prompt_len
-        self._host_slots, self._host_lens = [], []
+        longest = max(prompt_lens)
+        if longest > self.max_seq_len:
+            raise ValueError(f"prompt length {longest} exceeds max_seq_len {self.max_seq_len}")
+        info = self._atten
+        rows = self._to_device(slots)
+        info.b_req_idx, info.b_seq_len = rows, self._to_device(prompt_lens)
+        info.b_start_loc = self._row_offsets[: len(slots)] * longest           # packed grid: sequence i starts at i * longest
+        info.cur_select_index = info.b_req_tokens_table[rows, :longest].reshape(-1)  # its scatter targets: the row's first columns
+        info.max_actual_seq_len = longest
+        self.reset()  # the next decode step rebuilds its vectors from the host
 
     def begin_decode(self, slots: Sequence[int], seq_lens: Sequence[int]) -> int:
         """``seq_lens``: length each sequence has AFTER this step's token (its K/V goes to row
