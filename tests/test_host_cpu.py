@@ -172,3 +172,22 @@ def test_oneshot_all_reduce_needs_a_tensor_parallel_group():
     assert ps.oneshot_error() == 0
     x = torch.ones(8)
     assert ps.all_reduce_tp(x) is x
+
+
+def test_xcd_aware_slice_map_is_a_bijection():
+    """Restatement of gemm_w4_v3.hip's XCD-aware map of the split-K partial launches (V3Params::xcd_shift): workgroup
+    b = 8 q + x takes k-slice x % gt of tile q * (8 / gt) + x / gt.  For every power-of-two split up to 8 and every tile count
+    with tiles * gt % 8 == 0 the map is one-to-one onto (tile, slice), and a workgroup's slice depends on b % 8 only -- the
+    XCD it runs on under the round-robin dispatch -- so one XCD's L2 only ever sees one slice of the activation matrix."""
+    for sh in range(4):
+        gt = 1 << sh
+        for tiles in range(1, 80):
+            if (tiles * gt) % 8:
+                continue
+            seen = set()
+            for b in range(tiles * gt):
+                x, q = b & 7, b >> 3
+                j, tile = x & (gt - 1), q * (8 >> sh) + (x >> sh)
+                assert 0 <= tile < tiles and j == (b % 8) % gt
+                seen.add((tile, j))
+            assert len(seen) == tiles * gt
