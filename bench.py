@@ -561,7 +561,7 @@ def main():
     # hold (tp | Hq, tp | Hkv, shards multiples of the scale group), else the extension plan of distributed/partition.py
     # (KV heads replicated for tp > Hkv, whole scale groups per rank): Qwen2.5-7B runs TP = 8 on it.  MoE geometries keep
     # the reference rule.  Remaining GPUs are data-parallel replicas (no collective between them).
-    from lite_llama_amd.distributed.partition import admissible_tp, make_plan
+    from lite_llama_amd.distributed.partition import admissible_tp, make_plan, scale_unit
     if geo.num_experts:
         # MoE: the attention heads on a plan (KV heads replicated for tp > Hkv), the experts on the reference's equal cut of their
         # intermediate dimension -- admitted when the cut keeps whole scale blocks of the run's quantisation (per-channel
@@ -581,8 +581,9 @@ def main():
             tp = cand
             break
     else:
-        tp = admissible_tp(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, world)
-        plan_note = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, tp).describe()
+        unit = scale_unit(None if args.quant == "none" else QuantConfig.for_runtime_scheme(args.quant), geo.intermediate_size)
+        tp = admissible_tp(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, world, unit)  # the model's own rule
+        plan_note = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, tp, unit).describe()
     dp = world // tp
     ps.init_parallel(rank, tp_size=tp, dp_size=dp, master_port=int(os.environ.get("MASTER_PORT", 29500)))
     allreduce_how = "none (tp1)" if tp == 1 else "rccl"

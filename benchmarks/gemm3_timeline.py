@@ -106,6 +106,14 @@ for name, n, k, epi in shapes:
             last = torch.gather(t[:, 4:44], 1, (nun.clamp(min=1) - 1).long().unsqueeze(1)).squeeze(1)
             period = ((last - t[:, 4]) / (nun - 1).clamp(min=1) / 100.0)[rows]
             print(f"  units/workgroup {int(nun.min())}..{int(nun.max())}; unit period median {period.median():.3f} us (min {period.min():.3f}, max {period.max():.3f})")
+        if os.environ.get("TL_DUMP"):  # per-workgroup table: index, entry, units, first / last unit barrier, done (us after the first entry)
+            idx_all = torch.nonzero(live).squeeze(1)
+            with open(os.environ["TL_DUMP"] + f".{name.replace('|', '')}.w{wave}.txt", "w") as fdump:
+                fdump.write("# wg entry units first_unit last_unit seg_begin done\n")
+                lastu = torch.gather(t[:, 4:44], 1, (nun.clamp(min=1) - 1).long().unsqueeze(1)).squeeze(1)
+                for r in range(t.shape[0]):
+                    g = lambda v: (v - t0) / 100.0 if v > 0 else -1.0
+                    fdump.write("%d %.2f %d %.2f %.2f %.2f %.2f\n" % (int(idx_all[r]), g(t[r, 0]), int(nun[r]), g(t[r, 4]), g(lastu[r]), g(t[r, 50]), g(t[r, 60])))
         cyc = (t[:, 62] - t[:, 61]); rt = (t[:, 60] - t[:, 0]) / 100.0
         ok = (t[:, 62] > 0) & (rt > 0)
         if ok.any():
@@ -119,3 +127,18 @@ for name, n, k, epi in shapes:
         if NORMED and wave == 0:
             print(f"  in-launch norm (row workgroups, after own entry): start {stat(54, True)} | sums done {stat(55, True)} | pre barrier {stat(56, True)} | row written through {stat(57, True)}")
         print(f"  last segment end: begin {stat(50)} exchanged {stat(51)} counter seen {stat(52)} merged {stat(53)} | wave done {stat(60)}")
+        ocn = int(os.environ.get("OCN", 0))  # owner / contributor split: workgroups < OCN are contributors
+        if ocn and epi:
+            idx = torch.nonzero(live).squeeze(1)
+            for label, rows_ in (("contributors", idx < ocn), ("owners", idx >= ocn)):
+                tt = t[rows_]
+
+                def st2(col):
+                    v = tt[:, col]
+                    m = v > 0
+                    if m.sum() == 0:
+                        return "      -      "
+                    d = (v[m] - t0) / 100.0
+                    return f"{d.min():6.2f}/{d.median():6.2f}/{d.max():6.2f}"
+
+                print(f"  {label:12s} (min/median/max us after the first entry): last segment begin {st2(50)} exchanged {st2(51)} counter seen {st2(52)} merged {st2(53)} epilogue math / slab stores issued {st2(58)} output stores issued {st2(59)} | wave done {st2(60)}")

@@ -225,6 +225,11 @@ int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* wpacked, con
                               const void* bias, int64_t m, int64_t n, int64_t k, int group_size,
                               int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,
                               void* stream);
+/* Host-side introspection (tests; no device work): the launch plan ll_w4a16_matmul_prepacked uses for (n, k,
+ * epilogue) as 16 ints -- grid, 128-row blocks per tile, tiles, chunks, slab slots, tile-group split (gt, gbase, grem, lead,
+ * xcd_shift), stream-K units per workgroup, owner / contributor split (contributors, chunks per tile left to them, their
+ * range base / remainder), compute units assumed.  tests/test_host_cpu.py restates the kernel's per-workgroup decode on it. */
+int ll_w4a16_v3_plan(int64_t m, int64_t n, int64_t k, int group_size, int epilogue, int32_t* out16);
 /* ll_skip_rmsnorm_partials + ll_w4a16_matmul_prepacked in ONE launch (decode step, TP = 1; no reference counterpart: the
  * reference launches skip_rmsnorm, lite_llama/kernels/skip_rms_norm.py, then the projection): `x` [m][k] is an OUTPUT -- the
  * normalised rows, produced inside the launch (workgroup r < m: row r, bit-identical to ll_skip_rmsnorm_partials(x,

@@ -48,6 +48,7 @@ SIGNATURES = {
     "ll_w4a16_partials_count": [L, L, L, I],
     "ll_skip_rmsnorm_partials": [P, P, I, P, P, L, L, F, I, P],
     "ll_w4a16_matmul_prepacked": [P, P, P, P, P, L, L, L, I, L, P, P, I, P],
+    "ll_w4a16_v3_plan": [L, L, L, I, I, P],
     "ll_w4a16_prepacked_normed_supported": [L, L, L, I, I, I],
     "ll_w4a16_matmul_prepacked_normed": [P, P, P, P, P, L, L, L, I, L, P, P, I, P, I, P, P, F, P],
     "ll_w8a16_matmul": [P, P, P, P, P, L, L, L, I, L, I, L, L, L, L, P, P, P],
@@ -166,12 +167,20 @@ _gemm_ws: dict = {}
 _scratch_keepalive: list = []  # captured hipGraphs may still point at outgrown buffers
 
 
+def _device_index(device) -> int:
+    """``torch.device("cuda")`` carries no index; tensors' devices always do -- keys use the resolved one."""
+    device = torch.device(device)
+    return device.index if device.index is not None else torch.cuda.current_device()
+
+
 def scratch_keys(device: torch.device):
     """(key to use now, key of the capture set)."""
-    cap = (device.type, device.index, "capture")
+    device = torch.device(device)
+    idx = _device_index(device)
+    cap = (device.type, idx, "capture")
     if torch.cuda.is_current_stream_capturing():
         return cap, cap
-    return (device.type, device.index, torch.cuda.current_stream(device).cuda_stream), cap
+    return (device.type, idx, torch.cuda.current_stream(idx).cuda_stream), cap
 
 
 def _grow_gemm_ws(key, device, floats: int, ints: int):
@@ -193,12 +202,17 @@ def _grow_gemm_ws(key, device, floats: int, ints: int):
 
 
 def gemm_scratch_error(device: torch.device) -> bool:
-    """True if any merge-counter buffer of ``device`` holds a non-zero word (synchronises): the buffers are all zero at
-    rest by construction, so a non-zero word is the sticky trace of a GEMM merge that gave up on a contributor (its tile was
-    written as NaN) -- csrc/gemm_w4_v3.hip."""
+    """True if a merge-counter buffer of ``device`` that the CURRENT stream's work uses -- this stream's eager set and the
+    device's capture set (graphs are replayed on one stream at a time) -- holds a non-zero word after the stream has been
+    synchronised: the buffers are all zero at rest by construction, so a non-zero word is the sticky trace of a GEMM merge
+    that gave up on a contributor (its tile was written as NaN) -- csrc/gemm_w4_v3.hip.  Other eager streams' sets are not
+    looked at: their counters are legitimately non-zero in the middle of a GEMM."""
+    key, cap = scratch_keys(device)
+    torch.cuda.current_stream(key[1]).synchronize()
     bad = False
-    for key, ws in _gemm_ws.items():
-        if key[0] == device.type and key[1] == device.index and ws[1].numel():
+    for k in {key, cap}:
+        ws = _gemm_ws.get(k)
+        if ws is not None and ws[1].numel():
             bad = bad or bool(ws[1].any().item())
     return bad
 

@@ -90,6 +90,14 @@ struct V3Params {
                   // ONE k-slice of the activation matrix (1 / gt of it) instead of all of it; -1: b = tile * gt + slice
   uint32_t chunks_magic, gt_magic, upw_magic;  // ceil(2^32 / d): x / d = umulhi(x, magic) for the unit / workgroup indices of a launch (< 2^20)
   int gshift;                  // log2(group_size / 128)
+  // Owner / contributor split (round 4; tiles <= workgroups < 2 tiles, non-partial epilogues): workgroups [0, oc_nc) are
+  // CONTRIBUTORS -- they share the chunks [0, oc_cown) of every tile (a stream of tiles * oc_cown units cut into oc_nc equal
+  // ranges of >= oc_cown units, so a tile's region is cut at most once: the piece that starts at chunk 0 is slab 0, the other
+  // slab 1); workgroup oc_nc + t is the OWNER of tile t and sums chunks [oc_cown, chunks).  The owners run `lead` units longer
+  // than the contributors, so every slab and counter has landed long before an owner looks (the stream-K split of round 2 / 3
+  // had a contributor finishing WITH its owner on ~95 of 148 tiles: store ack, counter, poll, slab read = ~7 us of tail).
+  int oc_nc, oc_cown, oc_cbase, oc_crem;
+  uint32_t oc_cown_magic;
   int epi;                     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu;  2: fp32 split-K partials [slot][m][n]
   // In-launch add-and-normalise (ll_w4a16_matmul_prepacked_normed): the activation matrix x [m][k] does not exist yet when
   // the launch starts -- workgroup r < m produces row r from the previous projection's split-K partials (the arithmetic of
@@ -163,7 +171,7 @@ __device__ __forceinline__ f16x8 v3_dequant(uint32_t w, uint32_t s, uint32_t nzs
 // and two countdowns; the per-unit path is three scalar adds and two compares, the fix-up at the end of a tile
 // or segment is a (rare) branch.
 struct V3Seq {
-  int chunks;
+  int chunks;  // the numbering's wrap length: chunks of a tile (contributors of the owner / contributor split: of a tile's region)
   int t0, c0, n0, t1, c1, n1, t2, c2, n2;
 };
 struct V3Walk {
@@ -452,7 +460,7 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
 #pragma unroll
       for (int f = 0; f < NF; ++f) {  // the tile's 128-row blocks lc.t * NF + f
         const int blk = lc.t * NF + f;
-        const char* wb = (const char*)p.wp + (size_t)(uint32_t)((blk * q.chunks + lc.c) * (V3_BN * V3_CK / 2));
+        const char* wb = (const char*)p.wp + (size_t)(uint32_t)((blk * p.chunks + lc.c) * (V3_BN * V3_CK / 2));
         const char* sb = (const char*)p.sp + (size_t)(uint32_t)(((lc.c >> p.gshift) * (int)p.n + blk * V3_BN) * 8);
         v3_dma_w(dst + f * V3_W_BLOCK + 4 * L * 1024, dst + f * V3_W_BLOCK + 8192 + 2 * L * 256, wb, sb, voff);
       }
@@ -569,6 +577,8 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   V3_TLC(61)
   int ub, ue;
   int my_slice = -1;
+  int wrap = chunks;  // chunks of a tile this workgroup's unit numbering runs over before it moves to the next tile
+  uint32_t wrap_magic = p.chunks_magic;
   if (p.gt) {
     int gtile, j;
     if (p.xcd_shift >= 0) {
@@ -583,6 +593,17 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     const int lo = j * p.gbase + (j < p.grem ? j : p.grem);
     ub = gtile * chunks + lo;
     ue = j == p.gt - 1 ? (gtile + 1) * chunks : ub + p.gbase + (j < p.grem ? 1 : 0);
+  } else if (p.oc_nc) {
+    const int b = (int)blockIdx.x;
+    if (b < p.oc_nc) {  // contributor: a range of the [tile][chunk < oc_cown] stream (numbered with wrap = oc_cown)
+      ub = b * p.oc_cbase + (b < p.oc_crem ? b : p.oc_crem);
+      ue = ub + p.oc_cbase + (b < p.oc_crem ? 1 : 0);
+      wrap = p.oc_cown;
+      wrap_magic = p.oc_cown_magic;
+    } else {  // owner of tile b - oc_nc: chunks [oc_cown, chunks)
+      ub = (b - p.oc_nc) * chunks + p.oc_cown;
+      ue = (b - p.oc_nc + 1) * chunks;
+    }
   } else {
     ub = blockIdx.x * p.upw;
     ue = ub + p.upw;
@@ -603,19 +624,19 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     return;
   }
   const int cnt = ue - ub;
-  const int tA = v3_div(ub, p.chunks_magic, chunks), cA = ub - tA * chunks;
-  const int tZ = v3_div(ue - 1, p.chunks_magic, chunks), cZ = (ue - 1) - tZ * chunks;
+  const int tA = v3_div(ub, wrap_magic, wrap), cA = ub - tA * wrap;
+  const int tZ = v3_div(ue - 1, wrap_magic, wrap), cZ = (ue - 1) - tZ * wrap;
   int LT = 0, LH = cnt;  // a range inside one tile runs as a single "head" segment
   if (tA != tZ) {
-    LT = (cZ != chunks - 1) ? cZ + 1 : 0;
-    LH = (cA != 0) ? chunks - cA : 0;
+    LT = (cZ != wrap - 1) ? cZ + 1 : 0;
+    LH = (cA != 0) ? wrap - cA : 0;
   }
   const int NFU = cnt - LT - LH;  // units of whole tiles
   const int tF = tA + ((LH > 0 && tA != tZ) ? 1 : 0);
   // segments in execution order, empty ones squeezed out (selects only: a runtime-indexed array would live in scratch)
   const bool hasT = LT > 0, hasF = NFU > 0;
   V3Seq q;
-  q.chunks = chunks;
+  q.chunks = wrap;
   q.t0 = hasT ? tZ : (hasF ? tF : tA); q.c0 = hasT ? 0 : (hasF ? 0 : cA); q.n0 = hasT ? LT : (hasF ? NFU : LH);
   q.t1 = (hasT && hasF) ? tF : tA; q.c1 = (hasT && hasF) ? 0 : cA; q.n1 = hasT ? (hasF ? NFU : LH) : (hasF ? LH : 0);
   q.t2 = tA; q.c2 = cA; q.n2 = (hasT && hasF) ? LH : 0;
@@ -679,8 +700,15 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   // [c_lo, c_hi] this workgroup has just summed into v0 (and v1) -- k-halves already added.
   auto flush = [&](f32x16& v0, f32x16& v1, auto nm_tag, int mt0, int t, int f, int c_lo, int c_hi) {
     constexpr int NM = decltype(nm_tag)::value;
-    const int w0 = p.gt ? t * p.gt : v3_div(t * chunks, p.upw_magic, p.upw);  // first contributor of the tile
-    const int slot = my_slice >= 0 ? my_slice : (int)blockIdx.x - w0;
+    // slab / plane index of this piece (an owner: the number of slabs to add).  Owner / contributor split: a tile's region is
+    // cut at most once -- the piece that starts at chunk 0 is slab 0, the other one slab 1 -- and an owner reads the number of
+    // pieces from the counter word (every piece adds 0x10000 + its chunk count).
+    int slot;
+    if (p.oc_nc) slot = c_lo == 0 ? 0 : 1;
+    else {
+      const int w0 = p.gt ? t * p.gt : v3_div(t * chunks, p.upw_magic, p.upw);  // first contributor of the tile
+      slot = my_slice >= 0 ? my_slice : (int)blockIdx.x - w0;
+    }
     const int blk = t * NF + f;  // 128-row block
     auto vsel = [&](int i) -> f32x16& { return i == 0 ? v0 : v1; };
     if (p.epi == 2) {
@@ -723,8 +751,9 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
           asm volatile("global_store_dwordx4 %0, %1, off sc1\n\ts_nop 1" ::"v"(dst), "v"(o) : "memory");
         }
       }
+      V3_TL(58)
       pend_ctr = ctr;
-      pend_val = c_hi - c_lo + 1;
+      pend_val = c_hi - c_lo + 1 + (p.oc_nc ? 0x10000 : 0);
       pend_n = NM;
       pending = 1;
       return;
@@ -738,8 +767,10 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
           const int s1 = __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           seen = seen < s1 ? seen : s1;
         }
-        if (__builtin_amdgcn_readfirstlane(seen) >= c_lo) {
+        seen = __builtin_amdgcn_readfirstlane(seen);
+        if ((seen & 0xffff) >= c_lo) {
           arrived = true;
+          if (p.oc_nc) slot = seen >> 16;
           break;
         }
         __builtin_amdgcn_s_sleep(4);
@@ -814,16 +845,31 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       const bool row_ok = mrow < p.m;
       uint32_t lo[4], hi[4];  // per g: fp16 pairs (o0, o1), (o2, o3)
       uint32_t sw[4];         // per g: swiglu pair
+      // (round 4: straight-line code -- the four bias halves of a group as one 8-byte load behind ONE branch, the NaN poison as
+      // a select; the per-element branches and the libm sigmoid of round 3 made this epilogue 2.6 us of dependent VALU chains)
+      float fv[4][4];
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) fv[g][e] = v[4 * g + e];
+      if (has_bias) {
+        uint2 bb[4];
+#pragma unroll
+        for (int g = 0; g < 4; ++g)
+          bb[g] = *reinterpret_cast<const uint2*>(p.bias + (int64_t)blk * V3_BN + ng * 32 + 8 * g + 4 * h);
+#pragma unroll
+        for (int g = 0; g < 4; ++g) {
+          fv[g][0] += f16_bits_to_f32((uint16_t)(bb[g].x & 0xffffu));
+          fv[g][1] += f16_bits_to_f32((uint16_t)(bb[g].x >> 16));
+          fv[g][2] += f16_bits_to_f32((uint16_t)(bb[g].y & 0xffffu));
+          fv[g][3] += f16_bits_to_f32((uint16_t)(bb[g].y >> 16));
+        }
+      }
 #pragma unroll
       for (int g = 0; g < 4; ++g) {
-        const int64_t nn = (int64_t)blk * V3_BN + ng * 32 + 8 * g + 4 * h;
         uint16_t o[4];
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          float fv = v[4 * g + e];
-          if (has_bias) fv += f16_bits_to_f32(p.bias[nn + e]);
-          o[e] = poison ? (uint16_t)0x7e00 : f32_to_f16_bits(fv);
-        }
+        for (int e = 0; e < 4; ++e) o[e] = poison ? (uint16_t)0x7e00 : f32_to_f16_bits(fv[g][e]);
         lo[g] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
         hi[g] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
         if (p.epi) {
@@ -836,6 +882,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
           sw[g] = s0 | (s1 << 16);
         }
       }
+      V3_TL(58)
       const int64_t n0 = (int64_t)blk * V3_BN + ng * 32 + 16 * h;  // first of the 16 rows this lane stores after the swap
 #if !V3_WIDE_STORES
       if (row_ok) {
@@ -862,6 +909,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
           *reinterpret_cast<u32x4*>(p.out + mrow * p.n + n0 + 8) = u32x4{lo[1], hi[1], lo[3], hi[3]};
         }
       }
+      V3_TL(59)
     }
   };
 
@@ -1164,12 +1212,15 @@ struct V3Plan {
   int nblocks, chunks, total_units, upw, grid, slots;
   int gt, gbase, grem, glead;
   int xcd_shift = -1;  // V3Params::xcd_shift
+  int oc_nc = 0, oc_cown = 0, oc_cbase = 0, oc_crem = 0;  // V3Params::oc_*
 };
 
 struct V3Knobs {
   int wgs = 0, lead = 4, gt_cap_div = 5, gt_cap = -1, nf = 0;
   int xcd = 8;  // split-K partial launches take a power-of-two split <= this and the XCD-aware map (LL_GEMM3_XCD=0: off)
+  int oc_lead = 4;  // owner / contributor split: units an owner runs longer than a contributor (LL_GEMM3_OC=-1: stream-K as before)
   V3Knobs() {
+    if (const char* e = getenv("LL_GEMM3_OC")) oc_lead = atoi(e);
     if (const char* e = getenv("LL_GEMM3_XCD")) xcd = atoi(e);
     if (const char* e = getenv("LL_GEMM3_WGS")) wgs = atoi(e);
     if (const char* e = getenv("LL_GEMM3_LEAD")) lead = atoi(e);
@@ -1242,6 +1293,28 @@ static V3Plan v3_plan(int64_t n, int64_t k, int nf_force = 0, bool partials = fa
     pl.slots = gt;
     return pl;
   }
+  // Owner / contributor split (V3Params::oc_*): between one and two workgroups per tile.  Owners (one per tile) sum the last
+  // a = chunks - cown chunks, the target - tiles contributors share the first cown chunks of every tile in equal ranges of
+  // b = tiles * cown / contributors units; cown is chosen so that a - b ~ lead.  (Qwen2.5-7B gate|up, 148 tiles x 28 chunks on
+  // 256 CUs: lead 4 -> cown 10, a = 18, b = 13.7; lead 2 -> cown 11, a = 17, b = 15.1.)
+  if (!partials && kn.oc_lead >= 0 && pl.nblocks < target && 2 * pl.nblocks >= target && pl.chunks >= 4) {
+    const int nc = target - pl.nblocks;
+    int cown = (int)((((int64_t)pl.chunks - kn.oc_lead) * nc + target / 2) / target);
+    if (cown > pl.chunks - 1) cown = pl.chunks - 1;
+    if (cown < 1) cown = 1;
+    const int64_t total_c = (int64_t)pl.nblocks * cown;
+    // a contributor's range is at least one region long (every region is cut at most once) and never longer than an owner's
+    if (total_c / nc >= cown && (total_c + nc - 1) / nc <= pl.chunks - cown) {
+      pl.oc_nc = nc;
+      pl.oc_cown = cown;
+      pl.oc_cbase = (int)(total_c / nc);
+      pl.oc_crem = (int)(total_c % nc);
+      pl.upw = pl.chunks - cown;
+      pl.grid = target;
+      pl.slots = 2;
+      return pl;
+    }
+  }
   int upw = (pl.total_units + target - 1) / target;
   // a tile has at most (chunks - 2) / upw + 2 contributors
   const int min_upw = (pl.chunks + (V3_MAX_SLOTS - 2) - 1) / (V3_MAX_SLOTS - 2);
@@ -1272,6 +1345,22 @@ extern "C" int ll_w4a16_partials_count(int64_t m, int64_t n, int64_t k, int grou
   if (!ll_w4a16_prepacked_supported(m, n, k, group_size)) return 0;
   const V3Plan pl = v3_plan(n, k, 1, true);
   return pl.gt >= 1 && pl.grid == pl.nblocks * pl.gt ? pl.gt : 0;
+}
+
+// The launch plan of ll_w4a16_matmul_prepacked for (n, k, epilogue) as 16 ints -- host-side introspection for tests and
+// DESIGN.md (no device work): [0] grid, [1] 128-row blocks per tile, [2] tiles, [3] chunks, [4] slab slots, [5] gt, [6] gbase,
+// [7] grem, [8] glead, [9] xcd_shift, [10] upw, [11] oc_nc, [12] oc_cown, [13] oc_cbase, [14] oc_crem, [15] compute units assumed.
+extern "C" int ll_w4a16_v3_plan(int64_t m, int64_t n, int64_t k, int group_size, int epilogue, int32_t* out16) {
+  if (!out16) return LL_ERR_ARG;
+  if (!ll_w4a16_prepacked_supported(m, n, k, group_size)) return LL_ERR_SHAPE;
+  const bool partials = (epilogue & 3) == 2;
+  if (partials && !ll_w4a16_partials_count(m, n, k, group_size)) return LL_ERR_SHAPE;
+  const V3Plan pl = v3_plan(n, k, (epilogue >> 8) & 3, partials);
+  const int v[16] = {pl.grid, pl.nf, pl.nblocks, pl.chunks, pl.slots, pl.gt, pl.gbase, pl.grem, pl.glead,
+                     (partials && pl.gt >= 1 && pl.grid == pl.nblocks * pl.gt) ? pl.xcd_shift : -1, pl.upw, pl.oc_nc, pl.oc_cown,
+                     pl.oc_cbase, pl.oc_crem, v3_knobs().wgs > 0 ? v3_knobs().wgs : v3_num_cus()};
+  for (int i = 0; i < 16; ++i) out16[i] = v[i];
+  return LL_OK;
 }
 
 extern "C" int ll_w4a16_v3_workspace(int64_t m, int64_t n, int64_t k, int64_t* floats, int64_t* ints) {
@@ -1322,6 +1411,7 @@ static int v3_launch(void* out, const void* x, const void* wpacked, const void* 
   p.x_bytes = (uint32_t)((m - 1) * x_stride_m * 2 + k * 2);
   p.nblocks = pl.nblocks; p.chunks = pl.chunks; p.total_units = pl.total_units; p.upw = pl.upw; p.slots = pl.slots;
   p.gt = pl.gt; p.gbase = pl.gbase; p.grem = pl.grem; p.glead = pl.glead;
+  p.oc_nc = pl.oc_nc; p.oc_cown = pl.oc_cown; p.oc_cbase = pl.oc_cbase; p.oc_crem = pl.oc_crem;
   p.epi = epilogue;
   auto magic = [](int d) { return d > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u; };
   // umulhi(x, ceil(2^32 / d)) == x / d for x * d < 2^32 (x: unit / workgroup indices); d == 1 is handled by the guard below
@@ -1331,6 +1421,7 @@ static int v3_launch(void* out, const void* x, const void* wpacked, const void* 
   p.chunks_magic = magic(pl.chunks);
   p.gt_magic = magic(pl.gt);
   p.upw_magic = magic(pl.upw);
+  p.oc_cown_magic = magic(pl.oc_cown);
 #ifdef V3_TIMELINE
   p.tlwave = getenv("LL_GEMM3_TL_WAVE") ? atoi(getenv("LL_GEMM3_TL_WAVE")) : 0;
   p.tl = getenv("LL_GEMM3_TIMELINE") ? (unsigned long long*)strtoull(getenv("LL_GEMM3_TIMELINE"), nullptr, 16) : nullptr;

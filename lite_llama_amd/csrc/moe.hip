@@ -25,6 +25,11 @@ __device__ __forceinline__ int64_t moe_load_idx(const void* p, int64_t i, int w)
 // moe_align_block_size: one workgroup, no host sync.  Thread e owns expert e (loops when
 // E > 1024): count, padded prefix, then a stable in-order placement scan.
 // ---------------------------------------------------------------------------------- //
+// An id outside [0, experts) -- never produced by a router over finite logits; the reference indexes out of bounds with it
+// (fused_moe.py:214-233) -- is folded onto the nearest valid expert instead of indexing LDS / sorted_ids out of bounds
+// (a NaN-poisoned activation reaches the router before the host raises).
+__device__ __forceinline__ int moe_clamp_id(int e, int experts) { return e < 0 ? 0 : (e >= experts ? experts - 1 : e); }
+
 __global__ __launch_bounds__(1024) void moe_align_kernel(const void* __restrict__ topk_ids, int ids_w,
                                                          int num_slots, int num_experts, int block_size,
                                                          int32_t* __restrict__ sorted_ids,
@@ -41,7 +46,7 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const void* __restrict_
   for (int e = tid; e < num_experts; e += 1024) counts[e] = 0;
   __syncthreads();
   for (int i = tid; i < num_slots; i += 1024) {
-    const int e = (int)moe_load_idx(topk_ids, i, ids_w);
+    const int e = moe_clamp_id((int)moe_load_idx(topk_ids, i, ids_w), num_experts);
     if (ids_lds) ids_lds[i] = e;
     atomicAdd(&counts[e], 1);
   }
@@ -102,7 +107,7 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const void* __restrict_
       if (counts[e] == 0) continue;
       int dst = starts[e];
       for (int i = 0; i < num_slots; ++i)
-        if ((int)moe_load_idx(topk_ids, i, ids_w) == e) sorted_ids[dst++] = i;
+        if (moe_clamp_id((int)moe_load_idx(topk_ids, i, ids_w), num_experts) == e) sorted_ids[dst++] = i;
     }
   }
   // expert_ids[b] = searchsorted(block_ends, b, right=True) clamped to E-1
@@ -486,12 +491,15 @@ __global__ __launch_bounds__(256) void moe_route_topk_kernel(uint16_t* __restric
   float picked_w = 0.f;   // lane r keeps selection r
   int picked_e = 0;
   float top_sum = 0.f;
+  unsigned taken = 0u;    // bit j: this lane's expert j * 64 + lane is already selected
   for (int r = 0; r < top_k; ++r) {
     unsigned long long best = 0ull;
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int e = j * 64 + lane;
-      if (e < experts && v[j] >= 0.f) {
+      // (no test of the VALUE: a NaN probability -- NaN logits, e.g. a poisoned activation -- orders above every finite one by
+      // its bit pattern, as torch.topk orders it, and still yields a valid expert index)
+      if (e < experts && !((taken >> j) & 1u)) {
         const unsigned long long key = ((unsigned long long)__float_as_uint(v[j]) << 32) | (unsigned)(0xffffffffu - (unsigned)e);
         best = key > best ? key : best;
       }
@@ -508,11 +516,7 @@ __global__ __launch_bounds__(256) void moe_route_topk_kernel(uint16_t* __restric
       picked_w = pw;
       picked_e = e;
     }
-    if ((e & 63) == lane) {
-#pragma unroll
-      for (int j = 0; j < PER; ++j)
-        if (j == (e >> 6)) v[j] = -1.f;  // taken
-    }
+    if ((e & 63) == lane) taken |= 1u << (e >> 6);
   }
   if (lane < top_k) {
     const float wv = norm ? picked_w / top_sum : picked_w;

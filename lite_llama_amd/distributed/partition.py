@@ -67,6 +67,17 @@ class ShardPlan:
                 f"MLP intermediate {'/'.join(map(str, its))} channels per rank (whole scale groups)")
 
 
+def scale_unit(quant, intermediate: int) -> int:
+    """Width the MLP-intermediate cut must respect for a run's quantisation: the scale-group width of a group format
+    (int4 / int8 groups, fp8 blocks), 1 for unquantised and per-channel weights -- there the reference's equal cut
+    ``intermediate / tp`` applies whenever it divides (models/weights.py:125-134), whatever 128 says (ADVICE round 3:
+    11008 channels at TP = 8 are 1376 per rank, not an 11 / 10-group extension plan)."""
+    if quant is None:
+        return 1
+    gk = int(getattr(quant, "group_k", 0) or 0)
+    return gk if 1 < gk < intermediate else 1
+
+
 def make_plan(num_heads: int, num_kv_heads: int, head_dim: int, intermediate: int, tp: int, unit: int = 128) -> ShardPlan:
     """``unit``: the scale-group width the intermediate cut must respect (int4 group / fp8 block: 128; 1 for unquantised
     or per-channel formats -- the decode engines still prefer 128)."""

@@ -23,7 +23,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from .distributed.parallel_state import all_reduce_tp, divide, get_tp_rank, get_tp_world_size
-from .distributed.partition import ShardPlan, make_plan, set_active_plan
+from .distributed.partition import ShardPlan, make_plan, scale_unit, set_active_plan
 from .kernels.attention import decode_attention, decode_attention_partials, decode_attention_partials_supported
 from .kernels.norm_act import PartialSums, PendingNorm, rope_and_cache, skip_rmsnorm_partials
 from .kernels import (
@@ -106,7 +106,7 @@ def shard_plan(geo: ModelGeometry, quant: QuantConfig | None, tp: int | None = N
         return None if plan.uniform else plan
     try:
         plan = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, tp,
-                         unit=max(quant.group_k, 1) if quant is not None and quant.group_k < geo.intermediate_size else 128)
+                         unit=scale_unit(quant, geo.intermediate_size))
     except ValueError:
         return None  # no plan: the reference's divide() raises its own error below
     return None if plan.uniform else plan

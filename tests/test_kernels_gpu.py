@@ -903,6 +903,24 @@ def test_moe_route_topk_matches_the_reference_router_tail(T, E, k, norm, dt):
     assert ids2.cpu()[1].tolist() == list(range(k))
     assert ids2.cpu()[0].tolist() == [E // 2] + [e for e in range(E) if e != E // 2][: k - 1]
     close(w2.float().sum(-1), torch.ones(2), 2e-3 if dt == torch.float16 else 1.6e-2)
+    # NaN logits (a poisoned activation after an all-reduce / merge time-out) still select k DISTINCT, VALID experts -- as
+    # torch.topk does -- and moe_align_block_size places every slot inside its buffers (ids of -1 indexed
+    # LDS and sorted_ids out of bounds)
+    from lite_llama_amd.kernels.fused_moe import moe_align_block_size
+
+    bad = logits.clone()
+    bad[0] = float("nan")
+    _, ids3 = moe_route_topk(bad.to(DEV), k, norm)
+    ids3 = ids3.cpu()
+    assert int(ids3.min()) >= 0 and int(ids3.max()) < E and all(len(set(r.tolist())) == k for r in ids3)
+    assert torch.equal(ids3[1:][distinct[1:]], id_ref[1:][distinct[1:]])
+    sorted_ids, expert_ids, n_post = moe_align_block_size(ids3.to(DEV), 16, E)
+    placed = sorted_ids.cpu()[: int(n_post)]
+    assert sorted(placed[placed < T * k].tolist()) == list(range(T * k))
+    wild = torch.tensor([[-1, E + 5][:k] + list(range(max(0, k - 2)))], dtype=torch.int64)[:, :k]
+    sorted_ids, expert_ids, n_post = moe_align_block_size(wild.to(DEV), 16, E)   # out-of-range ids are folded onto valid experts
+    placed = sorted_ids.cpu()[: int(n_post)]
+    assert sorted(placed[placed < k].tolist()) == list(range(k)) and int(expert_ids.max()) < E
 
 
 @pytest.mark.parametrize("M,N,K_", [(1, 128, 64), (7, 516, 192), (32, 1536, 8960), (32, 4100, 1536), (64, 2048, 1536),

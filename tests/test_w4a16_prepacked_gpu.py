@@ -327,3 +327,35 @@ def test_prepacked_with_in_launch_norm_equals_two_launches(m, n, k, s, form, ser
                 assert torch.equal(pend.out, y_ref) and torch.equal(r_buf, r_ref) and torch.equal(out_g, out_ref)
         torch.cuda.synchronize()
         assert L.gemm_scratch_error(torch.device(DEV)) == 0
+
+
+def test_sticky_merge_error_word_is_seen_from_an_indexless_device_and_only_on_this_streams_sets():
+    """``gemm_scratch_error(torch.device("cuda"))`` -- what ``DecodeEngine`` passes by default -- matched no
+    scratch set (its index is None, the sets are keyed by the tensors' device index), so a poisoned merge could never raise.
+    A planted non-zero counter word is now reported through both spellings of the device; a word planted in ANOTHER eager
+    stream's set (legitimately non-zero in the middle of that stream's GEMM) is not."""
+    from lite_llama_amd import _lib as L
+
+    n, k = 256, 512
+    qw = torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64, device=DEV).to(torch.int32)
+    pw = Q().pack_w4a16_weights(qw)
+    ps = Q().pack_w4a16_scales(torch.rand(n, k // 128, device=DEV) * 0.01 + 0.005, torch.randint(0, 16, (n, k // 128), device=DEV).float())
+    x = torch.randn(8, k, device=DEV, dtype=torch.float16)
+    Q().w4a16_matmul_prepacked(x, pw, ps, group_size=128)
+    for d in (torch.device("cuda"), torch.device("cuda", torch.cuda.current_device())):
+        assert L.gemm_scratch_error(d) is False
+    key, _ = L.scratch_keys(torch.device("cuda"))
+    assert key[1] == torch.cuda.current_device() and key in L._gemm_ws
+    word = L._gemm_ws[key][1][7:8]
+    word.fill_(1)
+    try:
+        for d in (torch.device("cuda"), torch.device("cuda", torch.cuda.current_device())):
+            assert L.gemm_scratch_error(d) is True
+        side = torch.cuda.Stream()
+        with torch.cuda.stream(side):
+            Q().w4a16_matmul_prepacked(x, pw, ps, group_size=128)  # creates the side stream's own set
+            assert L.gemm_scratch_error(torch.device("cuda")) is False  # this stream's sets are clean
+    finally:
+        word.zero_()
+    torch.cuda.synchronize()
+    assert L.gemm_scratch_error(torch.device("cuda")) is False
