@@ -1218,10 +1218,12 @@ struct V3Plan {
 struct V3Knobs {
   int wgs = 0, lead = 4, gt_cap_div = 5, gt_cap = -1, nf = 0;
   int xcd = 8;  // split-K partial launches take a power-of-two split <= this and the XCD-aware map (LL_GEMM3_XCD=0: off)
+  int fill = 85;  // ... when the launch still fills this percentage of the CUs (LL_GEMM3_FILL)
   int oc_lead = 4;  // owner / contributor split: units an owner runs longer than a contributor (LL_GEMM3_OC=-1: stream-K as before)
   V3Knobs() {
     if (const char* e = getenv("LL_GEMM3_OC")) oc_lead = atoi(e);
     if (const char* e = getenv("LL_GEMM3_XCD")) xcd = atoi(e);
+    if (const char* e = getenv("LL_GEMM3_FILL")) fill = atoi(e);
     if (const char* e = getenv("LL_GEMM3_WGS")) wgs = atoi(e);
     if (const char* e = getenv("LL_GEMM3_LEAD")) lead = atoi(e);
     if (const char* e = getenv("LL_GEMM3_GT")) gt_cap = atoi(e);
@@ -1278,7 +1280,7 @@ static V3Plan v3_plan(int64_t n, int64_t k, int nf_force = 0, bool partials = fa
     // instead of 9), FETCH_SIZE of the 128-row launches 13.4 -> 9.6 MB on average (down 28.2 -> 19.9: the activation matrix
     // crosses the fabric once instead of once per XCD); q|k|v 4608 x 3584 would drop to 4 slices = 144 workgroups and is
     // SLOWER (9.19 -> 9.45): taken only when the launch still fills >= 85 % of the CUs.
-    if ((pl.nblocks * g2) % 8 == 0 && pl.nblocks * g2 * 100 >= target * 85) {
+    if ((pl.nblocks * g2) % 8 == 0 && pl.nblocks * g2 * 100 >= target * kn.fill) {
       gt = g2;
       pl.xcd_shift = sh;
     }

@@ -240,12 +240,16 @@ extern "C" int ll_skip_rmsnorm_partials(void* y, const float* partials, int s_co
 #define LL_PART_CASE(DT, VPT, SMAX)                                                                             \
   skip_rmsnorm_partials_kernel<DT, VPT, SMAX><<<dim3((unsigned)rows), 256, 0, st>>>(                            \
       (uint16_t*)y, partials, s_count, (uint16_t*)residual, (const uint16_t*)weight, rows, (int)n, eps)
+// (SMAX = the number of plane loads issued per column group: slots >= s_count re-read plane 0 -- an exact-fit instance for the
+// 8-plane split of the XCD-aware slice map saves a third of the launch's load requests)
+#define LL_PART_S(DT, VPT)                                                   \
+  if (s_count <= 4) LL_PART_CASE(DT, VPT, 4); else if (s_count <= 6) LL_PART_CASE(DT, VPT, 6); \
+  else if (s_count <= 8) LL_PART_CASE(DT, VPT, 8); else LL_PART_CASE(DT, VPT, 12)
 #define LL_PART_DT(DT)                                                       \
-  if (nv <= 256) { if (s_count <= 6) LL_PART_CASE(DT, 1, 6); else LL_PART_CASE(DT, 1, 12); } \
-  else if (nv <= 512) { if (s_count <= 6) LL_PART_CASE(DT, 2, 6); else LL_PART_CASE(DT, 2, 12); } \
-  else { if (s_count <= 6) LL_PART_CASE(DT, 4, 6); else LL_PART_CASE(DT, 4, 12); }
+  if (nv <= 256) { LL_PART_S(DT, 1); } else if (nv <= 512) { LL_PART_S(DT, 2); } else { LL_PART_S(DT, 4); }
   if (dtype == LL_F16) { LL_PART_DT(LL_F16) } else { LL_PART_DT(LL_BF16) }
 #undef LL_PART_DT
+#undef LL_PART_S
 #undef LL_PART_CASE
   return LL_LAUNCH_CHECK();
 }
