@@ -11,24 +11,7 @@ if os.environ.get("SHAPES"):
 PARTIALS = bool(os.environ.get("PARTIALS"))  # the step's own form of the row-parallel / q|k|v launches
 
 
-NORMED = bool(os.environ.get("NORMED"))
-if NORMED:
-    os.environ["LL_NORM_IN_GEMM"] = "1"  # the add-and-normalise inside the launch (ll_w4a16_matmul_prepacked_normed)
-_norm_in = {}
-
-
 def gemm(x, w, s, epi):
-    if NORMED:
-        from lite_llama_amd.kernels.norm_act import PartialSums, skip_rmsnorm_partials
-        k = x.shape[-1]
-        if k not in _norm_in:
-            _norm_in[k] = (torch.randn(int(os.environ.get("NORM_S", 9)), 64, k, device=dev) * 0.3, torch.randn(64, k, device=dev).half(),
-                           torch.ones(k, device=dev).half())
-        parts, res, nw = _norm_in[k]
-        pend, _ = skip_rmsnorm_partials(PartialSums(parts, (64, k), torch.float16), res, nw, 1e-6, defer=True)
-        if PARTIALS and not epi:
-            return Q.w4a16_matmul_partials(pend.out, w, s, group_size=128, pending=pend)
-        return Q.w4a16_matmul_prepacked(pend.out, w, s, group_size=128, gate_up_swiglu=bool(epi), pending=pend)
     if PARTIALS and not epi:
         return Q.w4a16_matmul_partials(x, w, s, group_size=128)
     return Q.w4a16_matmul_prepacked(x, w, s, group_size=128, gate_up_swiglu=bool(epi))
@@ -64,9 +47,6 @@ for name, n, k, epi in shapes:
             if m.any():
                 line.append("u%d %.2f/%.2f/%.2f" % (u, ((a - prev)[m] / 100).median(), ((b - a)[m] / 100).median(), ((c0 - b)[m] / 100).median()))
         print(f"== {name} loader wave {wave}: prologue issued {rel(2).median():.2f} us, first barrier {rel(3).median():.2f}; per unit issue/wait/barrier us: " + " ".join(line))
-        if NORMED:
-            f = lambda c: (f"{rel(c).median():.2f}/{rel(c).max():.2f}" if (t[:, c] > 0).any() else "-")
-            print(f"   in-launch norm, us after own entry (median/max): pre barrier {f(54)} | gate seen {f(55)} | gate barrier {f(56)}")
     for wave in (0, 4):
         os.environ["LL_GEMM3_TL_WAVE"] = str(wave)
         os.environ.pop("LL_GEMM3_TIMELINE", None)
@@ -124,8 +104,6 @@ for name, n, k, epi in shapes:
             d = (c[m, 1:] - c[m, :-1])
             print("  unit 3, shader cycles (median): reads issued %d | compute issued %d | barrier %d | bookkeeping %d | step total %d" % (
                 d[:, 0].median(), d[:, 1].median(), d[:, 2].median(), d[:, 3].median(), (c[m, 4] - c[m, 0]).median()))
-        if NORMED and wave == 0:
-            print(f"  in-launch norm (row workgroups, after own entry): start {stat(54, True)} | sums done {stat(55, True)} | pre barrier {stat(56, True)} | row written through {stat(57, True)}")
         print(f"  last segment end: begin {stat(50)} exchanged {stat(51)} counter seen {stat(52)} merged {stat(53)} | wave done {stat(60)}")
         ocn = int(os.environ.get("OCN", 0))  # owner / contributor split: workgroups < OCN are contributors
         if ocn and epi:

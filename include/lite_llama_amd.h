@@ -180,37 +180,19 @@ int ll_w4a16_matmul(void* out, const void* x, const int32_t* qweight, const floa
                     int group_size, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
                     float* workspace, int32_t* counters, void* stream);
 /* Load-time companion (no reference counterpart; the reference keeps the fp32 grids only):
- * packed[g][n] = 8 bytes {fp16 s, fp16 s, fp16 -z*s, fp16 -z*s} -- exactly the pair the GEMM
- * otherwise derives on the fly, transposed so that one 128-row tile of one group is contiguous.
- * ll_w4a16_matmul_packed takes it as an optional extra operand (NULL = identical to
- * ll_w4a16_matmul); results are bit-identical either way. */
+ * packed[g][n] = 8 bytes {fp16 s, fp16 s, fp16 -z*s, fp16 -z*s} -- the pair the decode engine (ll_w4a16_matmul_prepacked)
+ * streams, transposed so that one 128-row tile of one group is contiguous. */
 int ll_w4a16_pack_scales(void* packed, const float* scales, const float* zeros, int64_t n,
                          int64_t groups, int64_t s_stride_n, void* stream);
-int ll_w4a16_matmul_packed(void* out, const void* x, const int32_t* qweight, const float* scales,
-                           const float* zeros, const void* packed_sz, const void* bias, int64_t m,
-                           int64_t n, int64_t k, int group_size, int64_t x_stride_m,
-                           int64_t qw_stride_n, int64_t s_stride_n, float* workspace,
-                           int32_t* counters, void* stream);
-
-/* Decode-step fusion (no reference counterpart: the reference runs gate_proj, up_proj and
- * swiglu.py:45-65 as three launches): qweight / scales / zeros hold the two projections
- * row-interleaved (row 2j = gate_j, row 2j+1 = up_j; n = 2 * intermediate), out [M, n/2] fp16 =
- * silu(gate) * up with the stand-alone kernels' rounding (same arithmetic; only the fp32 summation
- * order of the stream-K split can differ from the two-launch form).  Returns LL_ERR_SHAPE when
- * the shape is outside the decode engine (M > 64, n % 128, k % 128, group % 128): run the
- * two-step form then. */
-int ll_w4a16_decode_supported(int64_t m, int64_t n, int64_t k, int group_size); /* 1 / 0 */
-int ll_w4a16_gateup_swiglu(void* out, const void* x, const int32_t* qweight, const float* scales,
-                           const float* zeros, const void* packed_sz, int64_t m, int64_t n, int64_t k,
-                           int group_size, int64_t x_stride_m, int64_t qw_stride_n,
-                           int64_t s_stride_n, float* workspace, int32_t* counters, void* stream);
 
 /* Load-time weight layout of the decode engine (no reference counterpart; the reference reserves
  * lite_llama/models/quantization/_layout/__init__.py:1-6 for exactly this): a bit-exact permutation of
  * qweight [N, K/8] into the order the M <= 64 kernel streams it (per (128-row tile, 128-k chunk) 8 KB =
  * [wave 8][lane 64] x 16 B; inside a word even nibbles first).  packed: n * k / 2 bytes, n % 128 == 0,
  * k % 128 == 0.  ll_w4a16_matmul_prepacked consumes it together with ll_w4a16_pack_scales' output
- * (group_size = 128 * 2^j); epilogue bit 0: 0 = w4a16_matmul, 1 = the gate/up + swiglu fusion above; bits 8-9
+ * (group_size = 128 * 2^j); epilogue bit 0: 0 = w4a16_matmul, 1 = the gate/up + swiglu fusion (no reference counterpart: the
+ * reference runs gate_proj, up_proj and swiglu.py:45-65 as three launches; weight rows interleaved -- row 2j = gate_j, row
+ * 2j+1 = up_j, n = 2 * intermediate -- out [M, n/2] = silu(gate) * up with the stand-alone kernels' rounding); bits 8-9
  * (tests / tuning): 0 = tile width chosen by the host plan, 1 / 2 = force 128- / 256-row tiles (256 needs
  * n % 256 == 0).  Same arithmetic as ll_w4a16_matmul (only the fp32 summation order differs). */
 int ll_w4a16_pack_weights(void* packed, const int32_t* qweight, int64_t n, int64_t k, int64_t qw_stride_n,
@@ -230,20 +212,6 @@ int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* wpacked, con
  * xcd_shift), stream-K units per workgroup, owner / contributor split (contributors, chunks per tile left to them, their
  * range base / remainder), compute units assumed.  tests/test_host_cpu.py restates the kernel's per-workgroup decode on it. */
 int ll_w4a16_v3_plan(int64_t m, int64_t n, int64_t k, int group_size, int epilogue, int32_t* out16);
-/* ll_skip_rmsnorm_partials + ll_w4a16_matmul_prepacked in ONE launch (decode step, TP = 1; no reference counterpart: the
- * reference launches skip_rmsnorm, lite_llama/kernels/skip_rms_norm.py, then the projection): `x` [m][k] is an OUTPUT -- the
- * normalised rows, produced inside the launch (workgroup r < m: row r, bit-identical to ll_skip_rmsnorm_partials(x,
- * norm_partials, s_count, residual, norm_weight, m, k, eps)) while the weight stream already runs, and consumed by the
- * launch's activation loaders behind a launch-wide gate (agent-scope release / acquire).  `residual` [m][k] is updated in
- * place.  fp16; k <= 4096, k % 8 == 0, 1 <= s_count <= 12, the launch must have >= m workgroups (LL_ERR_SHAPE otherwise:
- * use the two launches).  A gate that never opens sets the launch's sticky error word (ll_w4a16_v3_workspace's `ints`
- * words are all zero at rest) instead of hanging. */
-int ll_w4a16_prepacked_normed_supported(int64_t m, int64_t n, int64_t k, int group_size, int epilogue, int s_count); /* 1 / 0 */
-int ll_w4a16_matmul_prepacked_normed(void* out, void* x, const void* wpacked, const void* spacked, const void* bias,
-                                     int64_t m, int64_t n, int64_t k, int group_size, int64_t x_stride_m,
-                                     float* workspace, int32_t* counters, int epilogue, const float* norm_partials,
-                                     int s_count, void* residual, const void* norm_weight, float eps, void* stream);
-
 /* ---- a9: w8a16_matmul  (kernels/quantization/w8a16.py:155-216) ---------------
  * qweight [N,K] uint8 (fp8-e4m3 bits) or int8; scales fp32 [ceil(N/gn), ceil(K/gk)]. */
 int ll_w8a16_matmul(void* out, const void* x, const void* qweight, const float* scales,

@@ -40,17 +40,12 @@ SIGNATURES = {
     "ll_gemm_workspace": [L, L, L, P, P],
     "ll_w4a16_matmul": [P, P, P, P, P, P, L, L, L, I, L, L, L, P, P, P],
     "ll_w4a16_pack_scales": [P, P, P, L, L, L, P],
-    "ll_w4a16_decode_supported": [L, L, L, I],
-    "ll_w4a16_gateup_swiglu": [P, P, P, P, P, P, L, L, L, I, L, L, L, P, P, P],
-    "ll_w4a16_matmul_packed": [P, P, P, P, P, P, P, L, L, L, I, L, L, L, P, P, P],
     "ll_w4a16_pack_weights": [P, P, L, L, L, P],
     "ll_w4a16_prepacked_supported": [L, L, L, I],
     "ll_w4a16_partials_count": [L, L, L, I],
     "ll_skip_rmsnorm_partials": [P, P, I, P, P, L, L, F, I, P],
     "ll_w4a16_matmul_prepacked": [P, P, P, P, P, L, L, L, I, L, P, P, I, P],
     "ll_w4a16_v3_plan": [L, L, L, I, I, P],
-    "ll_w4a16_prepacked_normed_supported": [L, L, L, I, I, I],
-    "ll_w4a16_matmul_prepacked_normed": [P, P, P, P, P, L, L, L, I, L, P, P, I, P, I, P, P, F, P],
     "ll_w8a16_matmul": [P, P, P, P, P, L, L, L, I, L, I, L, L, L, L, P, P, P],
     "ll_quantize_activations_int8": [P, P, P, L, L, L, P],
     "ll_dense16_matmul": [P, P, P, P, L, L, L, L, L, I, P, P],

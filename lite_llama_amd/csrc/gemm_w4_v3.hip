@@ -4,9 +4,9 @@
 // (out[m, n] = sum_k x[m, k] * (nib(n, k) - z[n, k/g]) * s[n, k/g] (+ bias), fp32 accumulation, fp16 out).
 //
 // Structure (what round 2 measured is in DESIGN.md 4.1; short form):
-//   * unit = 128 weight rows x 128 k; stream-K / tile-group split with static tile ownership as in
-//     gemm_w4_v2.hip (tail segment first, head segment last; write-through slabs + counters; waits only
-//     point at lower-numbered workgroups);
+//   * unit = 128 weight rows x 128 k; stream-K / tile-group split with static tile ownership (tail segment
+//     first, head segment last; write-through slabs + counters; waits only point at lower-numbered
+//     workgroups);
 //   * 12 waves per workgroup, one workgroup per CU.  Waves 8-11 are LOADERS and do nothing but LDS-DMA
 //     (global_load_lds: no registers, no ds_write, no permutes): waves 8/9 copy a unit's 8 KB of packed
 //     weights + 1 KB of (s, -z*s) pairs into a 6-slot ring five units ahead, waves 10/11 its [64 x 128]
@@ -99,16 +99,6 @@ struct V3Params {
   int oc_nc, oc_cown, oc_cbase, oc_crem;
   uint32_t oc_cown_magic;
   int epi;                     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu;  2: fp32 split-K partials [slot][m][n]
-  // In-launch add-and-normalise (ll_w4a16_matmul_prepacked_normed): the activation matrix x [m][k] does not exist yet when
-  // the launch starts -- workgroup r < m produces row r from the previous projection's split-K partials (the arithmetic of
-  // ll_skip_rmsnorm_partials, bit for bit) while the weight loaders already stream; the activation loaders of ALL workgroups
-  // wait on a launch-wide arrival counter (the rows are written through: they cross XCD L2s) before their first DMA.
-  const float* pre_part;       // [pre_s][m][k] fp32 partials; nullptr: x is an ordinary input
-  uint16_t* pre_res;           // residual [m][k], updated in place
-  const uint16_t* pre_w;       // norm weight [k]
-  float pre_eps;
-  int pre_s;
-  int pre_idx;                 // counters[pre_idx + 0..15]: arrivals (4 per row, spread), counters[pre_idx + 16]: workgroups past the gate
 #ifdef V3_TIMELINE
   unsigned long long* tl;  // debug: [workgroup][64] s_memrealtime stamps of wave LL_GEMM3_TL_WAVE (benchmarks/gemm3_timeline.py)
   int tlwave;
@@ -145,7 +135,7 @@ __device__ __forceinline__ uint32_t v3_and_or(uint32_t w, uint32_t mask, uint32_
 // One packed word -> eight fp16 weights in natural k order (the packer stores nibble 2i of a k-octet at
 // position i and nibble 2i+1 at position 4+i).  Exact unpack: (w & 0x000F000F) | 0x6400 = (1024 + q_i,
 // 1024 + q_{4+i}); the offset is removed exactly, then ONE fp16 fma with (s, -z*s): the same arithmetic as
-// gemm_w4_v2.hip / gemm_wq.hip.  Error against the reference's fp16(fp32((q - z) * s)): <= 3 fp16 ulps of the
+// gemm_wq.hip.  Error against the reference's fp16(fp32((q - z) * s)): <= 3 fp16 ulps of the
 // weight (roundings of s, of z*s and of the fma), stated in DESIGN.md.
 __device__ __forceinline__ f16x8 v3_dequant(uint32_t w, uint32_t s, uint32_t nzs, uint32_t magic) {
   const uint32_t w2 = w >> 8;
@@ -293,6 +283,14 @@ __device__ __forceinline__ void v3_dma_x(uint32_t dx, const void* xb, const uint
         "v"(voff[0]), "v"(voff[1]), "v"(voff[2]), "v"(voff[3]), "v"(voff[4]), "v"(voff[5]), "v"(voff[6]), "v"(voff[7]), "s"(xb)
       : "memory");
 }
+// Units a loader may request between the prologue barrier P0 and the barrier that ends unit 0 (the consumers wait there for
+// the loaders' ISSUE of these requests, ~0.65 us per unit and loader wave): A/B knob, see DESIGN.md 4.3
+#ifndef V3_OC_PREFETCH
+#define V3_OC_PREFETCH 1
+#endif
+#ifndef V3_START_FILL
+#define V3_START_FILL 8
+#endif
 template <int N>
 __device__ __forceinline__ void v3_vmcnt() {
   asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
@@ -312,121 +310,10 @@ __device__ __forceinline__ void v3_barrier() { asm volatile("" ::: "memory"); } 
 __device__ __forceinline__ void v3_barrier() { asm volatile("s_barrier" ::: "memory"); }
 #endif
 
-#ifndef V3_PRE_SPIN_LIMIT
-#define V3_PRE_SPIN_LIMIT (1 << 21)  // x ~1.5 us per poll: seconds, then the sticky error word
-#endif
-// Row `row` of the launch's activation matrix from split-K partials: skip_rmsnorm_partials_kernel<LL_F16, VPT, SMAX>
-// (norm_act.hip) run by waves 0..3 of a 12-wave workgroup -- same per-thread columns, same summation order, the same
-// 256-thread reduction (wave sums meet in LDS; the workgroup barrier inside is the launch's "pre" barrier, which the
-// other eight waves execute on their own paths), so the row equals the separate launch's bit for bit.
-template <int VPT, int SMAX>
-__device__ __forceinline__ void v3_pre_norm(const V3Params& p, int row, int tr, float* lds4) {
-  const int n = (int)p.k;
-  const float nf = (float)n;
-  const int64_t plane = p.m * (int64_t)n;
-  const int lane = tr & 63, wv = tr >> 6;  // (timeline builds)
-  (void)lane; (void)wv;
-  V3_TL(54)
-  uint16_t* y = const_cast<uint16_t*>(p.x);
-  uint16_t* r = p.pre_res;
-  U16x8 rv[VPT], wv8[VPT];
-  float sv[VPT][8];
-  bool ok[VPT];
-  float ssq = 0.f;
-#pragma unroll
-  for (int v = 0; v < VPT; ++v) {
-    const int col = (v * 256 + tr) * 8;
-    ok[v] = col < n;
-    const int64_t off = ok[v] ? (int64_t)row * n + col : 0;
-    rv[v] = *reinterpret_cast<const U16x8*>(r + off);
-    wv8[v] = *reinterpret_cast<const U16x8*>(p.pre_w + (ok[v] ? col : 0));
-    f32x4 pv[SMAX][2];
-#pragma unroll
-    for (int s = 0; s < SMAX; ++s) {
-      const float* src = p.pre_part + (s < p.pre_s ? s : 0) * plane + off;  // slots >= pre_s re-read slot 0 and are dropped below
-      pv[s][0] = *reinterpret_cast<const f32x4*>(src);
-      pv[s][1] = *reinterpret_cast<const f32x4*>(src + 4);
-    }
-#pragma unroll
-    for (int i = 0; i < 8; ++i) {
-      float a = 0.f;
-#pragma unroll
-      for (int s = 0; s < SMAX; ++s) a += s < p.pre_s ? pv[s][i >> 2][i & 3] : 0.f;
-      const float x = to_f32<LL_F16>(from_f32<LL_F16>(a)) + to_f32<LL_F16>(rv[v].v[i]);
-      rv[v].v[i] = from_f32<LL_F16>(x);
-      sv[v][i] = ok[v] ? x : 0.f;
-    }
-    if (ok[v]) *reinterpret_cast<U16x8*>(r + (int64_t)row * n + col) = rv[v];
-  }
-#pragma unroll
-  for (int v = 0; v < VPT; ++v)
-#pragma unroll
-    for (int i = 0; i < 8; ++i) ssq += sv[v][i] * sv[v][i] / nf;
-  const float ws = wave_sum(ssq);
-  if ((tr & 63) == 0) lds4[tr >> 6] = ws;
-  asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");
-  V3_TL(55)
-  v3_barrier();  // the launch's "pre" barrier
-  V3_TL(56)
-  const float var = lds4[0] + lds4[1] + lds4[2] + lds4[3];
-  const float rrms = 1.0f / sqrtf(var + p.pre_eps);
-#pragma unroll
-  for (int v = 0; v < VPT; ++v) {
-    if (ok[v]) {
-      U16x8 yv;
-#pragma unroll
-      for (int i = 0; i < 8; ++i) yv.v[i] = mul_storage<LL_F16>(from_f32<LL_F16>(sv[v][i] * rrms), wv8[v].v[i]);
-      // written through (sc1): the row must have left this XCD's L2 before its arrival is counted.  (An agent-scope release /
-      // acquire fence pair is the textbook form; its buffer_wbl2 / buffer_inv walk the whole L2 once per wave -- 768 walks
-      // per launch measured +21 us.  No invalidate is needed on the reading side: every L2 was invalidated at the launch
-      // boundary and nobody reads these addresses before the gate opens.)
-      asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(y + (int64_t)row * p.x_stride + (v * 256 + tr) * 8),
-                   "v"(__builtin_bit_cast(u32x4, yv)) : "memory");
-    }
-  }
-  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-  V3_TL(57)
-  // arrivals are counted in 16 words (same-address device-scope read-modify-writes are served one after the other, ~50 ns
-  // each: 256 of them on one word took longer than the rows)
-  if ((tr & 63) == 0)
-    __hip_atomic_fetch_add(p.counters + p.pre_idx + ((row * 4 + (tr >> 6)) & 15), 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-__device__ __forceinline__ void v3_pre_norm_dispatch(const V3Params& p, int row, int tr, float* lds4) {
-  const int nv = (int)(p.k / 8);
-  if (nv <= 256) { if (p.pre_s <= 6) v3_pre_norm<1, 6>(p, row, tr, lds4); else v3_pre_norm<1, 12>(p, row, tr, lds4); }
-  else { if (p.pre_s <= 6) v3_pre_norm<2, 6>(p, row, tr, lds4); else v3_pre_norm<2, 12>(p, row, tr, lds4); }
-}
-// The gate: every row has arrived (4 waves each, counted in words pre_idx + 0..15).
-__device__ __forceinline__ void v3_pre_gate(const V3Params& p, int lane) {
-  const int32_t* arr = p.counters + p.pre_idx;
-  const int want = lane < 16 ? (4 * (int)p.m - lane + 15) >> 4 : 0;  // arrivals i = 4 row + wave with i % 16 == lane
-  bool ok = false;
-  for (int spin = 0; spin < V3_PRE_SPIN_LIMIT; ++spin) {
-    const int seen = __hip_atomic_load(arr + (lane & 15), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if (__builtin_amdgcn_ballot_w64(seen < want) == 0) {
-      ok = true;
-      break;
-    }
-    __builtin_amdgcn_s_sleep(8);
-  }
-  if (!ok && lane == 0) __hip_atomic_store(p.counters + p.err_idx, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // sticky (see the merge wait)
-  asm volatile("" ::: "memory");  // (no acquire fence: see v3_pre_norm)
-}
-// Counted at the END of a workgroup's work (the read-modify-write's round trip would otherwise sit in front of the first
-// activation DMA -- and all workgroups pass the gate at the same moment): the last one through puts the words back to zero
-// (all arrivals precede any pass, all passes precede the reset; the next launch starts after this one has ended).
-__device__ __forceinline__ void v3_pre_pass(const V3Params& p, int lane, int wgs) {
-  int32_t* arr = p.counters + p.pre_idx;
-  int old = 0;
-  if (lane == 0) old = __hip_atomic_fetch_add(arr + 16, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  if (__builtin_amdgcn_readfirstlane(old) == wgs - 1 && lane <= 16)
-    __hip_atomic_store(arr + lane, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-}
-
 // One loader wave.  KIND 0: weight pieces 4L..4L+3 (1 KB each) + scale quarters 2L, 2L+1 (256 B each) of every
 // unit, V3_DW units ahead into a V3_RW-slot ring.  KIND 1: activation pieces 8L..8L+7 (4 rows x 256 B each),
 // V3_DX units ahead into a V3_RX-slot ring; LDS image row r, 16-B slot j <- source slot j ^ (r & 15).
-template <int KIND, int NF, bool PRE>
+template <int KIND, int NF>
 __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int cnt, int lane, int L) {
   using RG = V3Ring<NF>;
   using LD = V3Lds<NF>;
@@ -483,25 +370,7 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
   // unit ahead (RA) they multiply unit 0 while units 1, 2 land and meet the loaders again at B0.  (Round 2 requested two
   // units, waited for both, and refilled the ring two units per step: first unit finished 4.2-4.8 us after entry.)
   const int pre = cnt < 1 + AHEAD ? cnt : 1 + AHEAD;  // what the consumers' first two steps need; the rest of the ring after P0
-  // PRE (in-launch add-and-normalise): the "pre" barrier of a workgroup that produces a row (v3_pre_norm), then the gate --
-  // activation loader 0 polls the launch-wide arrival counter and the workgroup's twelve waves meet at the "gate" barrier
-  // (one polling wave per workgroup: 512 waves polling one word every 50 ns starved the producers' own atomics, +14 us).
-  // The weight loaders have their first units on the way before either barrier.
-  if constexpr (PRE && KIND == 1) {
-    const int wv = 10 + L;  // (timeline builds)
-    (void)wv;
-    if ((int)blockIdx.x < (int)p.m) v3_barrier();
-    V3_TL(54)
-    if (L == 0) v3_pre_gate(p, lane);
-    V3_TL(55)
-    v3_barrier();
-    V3_TL(56)
-  }
   for (int i = 0; i < pre; ++i) issue();
-  if constexpr (PRE && KIND == 0) {
-    if ((int)blockIdx.x < (int)p.m) v3_barrier();
-    v3_barrier();
-  }
   V3_TL(2)
   v3_wait_units<OPS>(issued - 1);  // unit 0 has landed
   v3_barrier();                    // P0
@@ -510,7 +379,8 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
   int u0 = 0;
   if constexpr (RG::RA) {
     // the consumers' first step: unit 0 alone (no operands read ahead)
-    const int fill = cnt < D ? cnt : D;
+    int fill = cnt < D ? cnt : D;
+    if (fill > issued + V3_START_FILL) fill = issued + V3_START_FILL;
     while (issued < fill) issue();
     const int need = cnt < 1 + AHEAD ? cnt : 1 + AHEAD;
     v3_wait_units<OPS>(issued - need);
@@ -522,7 +392,7 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
   for (int u = u0; u < cnt; ++u) {
     const int want = cnt < u + 1 + D ? cnt : u + 1 + D;
     if (issued < want) issue();
-    if (issued < want) issue();
+    if (issued < want && (u > 0 || V3_START_FILL >= 2)) issue();
     if (u < 12) { V3_TL(4 + 3 * u) }
     const int need = cnt < u + 1 + AHEAD ? cnt : u + 1 + AHEAD;
     v3_wait_units<OPS>(issued - need);
@@ -547,26 +417,12 @@ struct V3Ops {  // everything a consumer wave needs for one unit
   f16x8 a[4][MT];
 };
 
-#ifndef V3_PART_STORE
-#define V3_PART_STORE 0  // split-K partial planes: 0 plain stores, 1 write-through (sc1), 2 non-temporal -- A/B knob
-#endif
-#ifndef V3_WIDE_STORES
-#define V3_WIDE_STORES 1
-#endif
-#ifndef V3_MAGIC_DIV
-#define V3_MAGIC_DIV 1
-#endif
 __device__ __forceinline__ int v3_div(int x, uint32_t magic, int d) {
-#if V3_MAGIC_DIV
   (void)d;
   return magic ? (int)__umulhi((uint32_t)x, magic) : x;  // magic 0: d = 1
-#else
-  (void)magic;
-  return (int)((uint32_t)x / (uint32_t)d);
-#endif
 }
 
-template <int MT, int NF, bool PRE = false>
+template <int MT, int NF>
 __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3))) void wgemm3_kernel(const V3Params p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   const int tid = threadIdx.x;
@@ -609,20 +465,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     ue = ub + p.upw;
     if (ue > p.total_units) ue = p.total_units;
   }
-  const bool pre_wg = PRE && (int)blockIdx.x < (int)p.m;
-  if (ub >= ue) {
-    if constexpr (PRE) {  // a workgroup without units still owes its row and its pass of the gate
-      if (pre_wg) {
-        if (wv < 4) v3_pre_norm_dispatch(p, (int)blockIdx.x, tid, reinterpret_cast<float*>(lds + V3Lds<NF>::OFF_R));
-        else v3_barrier();
-      }
-      if (wv == 10) {  // (waits like everybody else: the last pass resets the words)
-        v3_pre_gate(p, lane);
-        v3_pre_pass(p, lane, (int)gridDim.x);
-      }
-    }
-    return;
-  }
+  if (ub >= ue) return;
   const int cnt = ue - ub;
   const int tA = v3_div(ub, wrap_magic, wrap), cA = ub - tA * wrap;
   const int tZ = v3_div(ue - 1, wrap_magic, wrap), cZ = (ue - 1) - tZ * wrap;
@@ -644,27 +487,14 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 
   if (wv >= 8) {
     // ======================================== loaders ======================================== //
-#ifdef V3_LOADER_PRIO
-    __builtin_amdgcn_s_setprio(V3_LOADER_PRIO);
-#endif
-    if (wv < 10) v3_loader<0, NF, PRE>(p, q, cnt, lane, wv - 8);
-    else v3_loader<1, NF, PRE>(p, q, cnt, lane, wv - 10);
-    if constexpr (PRE) {
-      if (wv == 10) v3_pre_pass(p, lane, (int)gridDim.x);
-    }
+    if (wv < 10) v3_loader<0, NF>(p, q, cnt, lane, wv - 8);
+    else v3_loader<1, NF>(p, q, cnt, lane, wv - 10);
     return;
   }
 
   // ======================================= consumers ======================================= //
   using RG = V3Ring<NF>;
   using LD = V3Lds<NF>;
-  if constexpr (PRE) {
-    if (pre_wg) {  // this workgroup's activation row (waves 0..3; the barrier inside is matched by everybody else's)
-      if (wv < 4) v3_pre_norm_dispatch(p, (int)blockIdx.x, tid, reinterpret_cast<float*>(lds + LD::OFF_R));
-      else v3_barrier();
-    }
-    v3_barrier();  // "gate": activation loader 0 has seen every row of the launch arrive
-  }
   const int ng = wv & 3, kh = wv >> 2;
   const int nl = lane & 31, h = lane >> 5;
   const int w_off = wv * 1024 + lane * 16;
@@ -696,6 +526,23 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     pending = 0;
   };
 
+  // Owner / contributor split: an owner's contributors finish `lead` units before it does, so the merge counter(s) of the one
+  // tile this wave will finish can be requested while the last two units are still being multiplied (a plain agent-scope
+  // load: the consumers have no other memory operation in flight, the compiler waits for it where the value is used).
+  int32_t* pf_ctr = nullptr;
+  int pf_a = -1, pf_b = -1;
+#if V3_OC_PREFETCH
+  if (p.oc_nc && (int)blockIdx.x >= p.oc_nc && !(NF == 1 && MT == 1 && kh == 1)) {
+    const int t_own = (int)blockIdx.x - p.oc_nc;
+    const int blk_own = t_own * NF + (NF == 2 ? kh : 0);
+    pf_ctr = p.counters + (blk_own * 4 + ng) * 2 + ((NF == 1 && MT == 2) ? kh : 0);
+  }
+#endif
+  auto pf_request = [&]() {
+    pf_a = __hip_atomic_load(pf_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    if constexpr (NF == 2 && MT == 2) pf_b = __hip_atomic_load(pf_ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+  };
+
   // Finish NM (1 or 2) 32-row batch halves mt0, mt0 + 1 of row group ng, 128-row block f of tile t, whose chunks
   // [c_lo, c_hi] this workgroup has just summed into v0 (and v1) -- k-halves already added.
   auto flush = [&](f32x16& v0, f32x16& v1, auto nm_tag, int mt0, int t, int f, int c_lo, int c_hi) {
@@ -723,13 +570,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 #pragma unroll
           for (int g = 0; g < 4; ++g) {
             const f32x4 o = {v[4 * g], v[4 * g + 1], v[4 * g + 2], v[4 * g + 3]};
-#if V3_PART_STORE == 1
-            asm volatile("global_store_dwordx4 %0, %1, off sc1" ::"v"(dst + 8 * g), "v"(o) : "memory");
-#elif V3_PART_STORE == 2
-            asm volatile("global_store_dwordx4 %0, %1, off nt" ::"v"(dst + 8 * g), "v"(o) : "memory");
-#else
-            *reinterpret_cast<f32x4*>(dst + 8 * g) = o;
-#endif
+            *reinterpret_cast<f32x4*>(dst + 8 * g) = o;  // plain stores: write-through (sc1) and nt both measured slower (rounds 3, 4)
           }
         }
       }
@@ -761,7 +602,16 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     if (c_lo != 0) {
       // owner: chunks [0, c_lo) were summed by the `slot` lower-numbered contributors
       bool arrived = false;
-      for (int spin = 0; spin < V3_SPIN_LIMIT; ++spin) {
+      if (pf_a >= 0) {  // (owner / contributor split) the counter words were requested two units ago: no round trip here
+        int seen = pf_a;
+        if constexpr (NM == 2) seen = (pf_b & 0xffff) < (seen & 0xffff) ? pf_b : seen;
+        seen = __builtin_amdgcn_readfirstlane(seen);
+        if ((seen & 0xffff) >= c_lo) {
+          arrived = true;
+          slot = seen >> 16;
+        }
+      }
+      for (int spin = 0; !arrived && spin < V3_SPIN_LIMIT; ++spin) {
         int seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if constexpr (NM == 2) {
           const int s1 = __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
@@ -884,17 +734,6 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       }
       V3_TL(58)
       const int64_t n0 = (int64_t)blk * V3_BN + ng * 32 + 16 * h;  // first of the 16 rows this lane stores after the swap
-#if !V3_WIDE_STORES
-      if (row_ok) {
-#pragma unroll
-        for (int g = 0; g < 4; ++g) {
-          const int64_t nn = (int64_t)blk * V3_BN + ng * 32 + 8 * g + 4 * h;
-          if (p.epi) *reinterpret_cast<uint32_t*>(p.out + mrow * (p.n >> 1) + (nn >> 1)) = sw[g];
-          else *reinterpret_cast<uint2*>(p.out + mrow * p.n + nn) = uint2{lo[g], hi[g]};
-        }
-      }
-      continue;
-#endif
       if (p.epi) {
         swap32(sw[0], sw[2]);
         swap32(sw[1], sw[3]);
@@ -1033,34 +872,6 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     }
   };
 
-  // Round 3 experiment (V3_INTERLEAVE = 1, 128-row tiles; OFF by default): ONE instruction stream per unit in which the next
-  // unit's operand reads and the step's scalar bookkeeping sit BETWEEN the current unit's MFMAs instead of in front of / behind
-  // them.  In-kernel cycle stamps of a consumer wave: issuing the ten reads up front 250 - 330 cycles (eight waves hit the LDS
-  // pipe at once), the MFMAs 510 (= the matrix pipe's bound), bookkeeping after the barrier 300 - 400, waiting at the barrier
-  // 250 - 520 -- the consumers WAIT for the loaders (issue 0.56 us + landing wait 0.24 us per unit), so shortening the consumer
-  // stream buys nothing: measured 17.9 vs 17.35 us on `down` (slightly worse), +-0 on q|k|v and o.
-#ifndef V3_INTERLEAVE
-#define V3_INTERLEAVE 0
-#endif
-  auto fused_step = [&](const V3Ops<MT, NF>& cur, V3Ops<MT, NF>& nxt, int wbase, int xbase, auto&& between) {
-    const unsigned char* wb = lds + wbase;
-    const unsigned char* xb = lds + xbase;
-    nxt.w[0] = *reinterpret_cast<const u32x4*>(wb + w_off);
-    nxt.s[0] = *reinterpret_cast<const u32x2*>(wb + s_off);
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t word = j == 0 ? cur.w[0].x : j == 1 ? cur.w[0].y : j == 2 ? cur.w[0].z : cur.w[0].w;
-      const f16x8 wfrag = v3_dequant(word, cur.s[0].x, cur.s[0].y, magic);
-      acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, cur.a[j][0], acc0, 0, 0, 0);
-      if constexpr (MT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, cur.a[j][1], acc1, 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt) nxt.a[j][mt] = *reinterpret_cast<const f16x8*>(xb + x_off[j] + mt * 32 * 256);
-      if (j == 1) between();
-      __builtin_amdgcn_sched_barrier(0);
-    }
-  };
-
   V3Walk cc = v3_walk_begin(q);
   int seg_lo = cc.c;
   int wnext = LD::OFF_W + RG::RA * LD::W_SLOT, xnext = LD::OFF_X + RG::RA * V3_X_SLOT;  // ring slots of the next unit to READ
@@ -1093,6 +904,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 #define V3_STEP(CUR, NXT)                                                                   \
   {                                                                                         \
     if (done == 5) { V3_TLC(44) }                                                           \
+    if (pf_ctr && done + 2 == cnt) pf_request();                                            \
     read_ops(RG::RA ? NXT : CUR, wnext, xnext);                                             \
     __builtin_amdgcn_sched_barrier(0); /* keep the reads up here (hipcc sinks them to their use otherwise) */ \
     if (done == 5) { V3_TLC(45) }                                                           \
@@ -1113,38 +925,6 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     if (done == 5) { V3_TLC(48) }                                                           \
     ++done;                                                                                 \
   }
-#if V3_INTERLEAVE && !defined(V3_ABLATE) && !defined(V3_TIMELINE)
-#define V3_FSTEP(CUR, NXT)                                                                  \
-  {                                                                                         \
-    bool se_ = false;                                                                       \
-    int t_ = 0, c_ = 0;                                                                     \
-    const int wb_ = wnext, xb_ = xnext;                                                     \
-    fused_step(CUR, NXT, wb_, xb_, [&]() { /* scalar bookkeeping, under the MFMAs */        \
-      wnext = wnext + LD::W_SLOT == LD::OFF_W + RG::RW * LD::W_SLOT ? LD::OFF_W : wnext + LD::W_SLOT; \
-      xnext = xnext + V3_X_SLOT == LD::OFF_X + RG::RX * V3_X_SLOT ? LD::OFF_X : xnext + V3_X_SLOT; \
-      se_ = v3_walk_ends(cc);                                                               \
-      t_ = cc.t;                                                                            \
-      c_ = cc.c;                                                                            \
-      v3_walk_next(cc, q);                                                                  \
-    });                                                                                     \
-    v3_barrier();                                                                           \
-    if (pending) post_pending();                                                            \
-    if (se_) {                                                                              \
-      segment_end(t_, seg_lo, c_);                                                          \
-      seg_lo = cc.c;                                                                        \
-    }                                                                                       \
-    ++done;                                                                                 \
-  }
-  if constexpr (RG::RA && NF == 1) {
-    if (done < cnt) for (;;) {
-      V3_FSTEP(opA, opB)
-      if (done >= cnt) break;
-      V3_FSTEP(opB, opA)
-      if (done >= cnt) break;
-    }
-  } else
-#undef V3_FSTEP_GUARD
-#endif
   if (done < cnt) for (;;) {
     V3_STEP(opA, opB)
     if (done >= cnt) break;
@@ -1174,6 +954,31 @@ __device__ __forceinline__ uint32_t v3_nib_perm(uint32_t w) {
   od = (od | (od >> 4)) & 0x00FF00FFu;
   od = (od | (od >> 8)) & 0x0000FFFFu;
   return ev | (od << 16);
+}
+
+// (s, -z*s) as fp16 pairs, transposed to [group][row]: a unit's 128 rows become 1 KB contiguous (the fp32 [N, K/g] grids would
+// cost 256 scattered 4-byte requests per unit -- twice the weight stream's).  fp32 product, one rounding each.
+__global__ void w4a16_pack_scales_kernel(uint2* packed, const float* scales, const float* zeros, int64_t n,
+                                         int64_t groups, int64_t s_stride) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= n * groups) return;
+  const int64_t g = i / n, r = i - g * n;
+  const float s = scales[r * s_stride + g], z = zeros[r * s_stride + g];
+  const uint32_t hs = f32_to_f16_bits(s), hz = f32_to_f16_bits(-z * s);
+  uint2 o;
+  o.x = hs | (hs << 16);
+  o.y = hz | (hz << 16);
+  packed[i] = o;
+}
+
+extern "C" int ll_w4a16_pack_scales(void* packed, const float* scales, const float* zeros, int64_t n,
+                                    int64_t groups, int64_t s_stride_n, void* stream) {
+  if (n <= 0 || groups <= 0) return LL_ERR_SHAPE;
+  if (!packed || !scales || !zeros) return LL_ERR_ARG;
+  const int64_t total = n * groups;
+  w4a16_pack_scales_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
+      (uint2*)packed, scales, zeros, n, groups, s_stride_n);
+  return LL_LAUNCH_CHECK();
 }
 
 __global__ void w4a16_pack_weights_kernel(u32x4* dst, const uint32_t* qw, int64_t total, int chunks, int64_t qw_stride) {
@@ -1375,20 +1180,13 @@ extern "C" int ll_w4a16_v3_workspace(int64_t m, int64_t n, int64_t k, int64_t* f
     const int64_t f = (int64_t)pl.nblocks * pl.nf * pl.slots * V3_SLAB;
     if (floats && f > *floats) *floats = f;
   }
-  if (ints) *ints = n / V3_BN * 8 + 1 + 17;  // merge counters + the error word + the in-launch norm's gate (16 arrival words, 1 pass word)
+  if (ints) *ints = n / V3_BN * 8 + 1;  // merge counters + the error word
   return LL_OK;
 }
 
-struct V3Pre {  // in-launch add-and-normalise (V3Params::pre_*)
-  const float* part = nullptr;
-  int s_count = 0;
-  void* residual = nullptr;
-  const void* weight = nullptr;
-  float eps = 0.f;
-};
 static int v3_launch(void* out, const void* x, const void* wpacked, const void* spacked, const void* bias, int64_t m, int64_t n,
                      int64_t k, int group_size, int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,
-                     const V3Pre& pre, void* stream) {
+                     void* stream) {
   if (m < 0 || n <= 0 || k <= 0 || group_size <= 0) return LL_ERR_SHAPE;
   if (m == 0) return LL_OK;
   if (!ll_w4a16_prepacked_supported(m, n, k, group_size) || x_stride_m % 8 != 0 || ((epilogue & 1) && (n & 1))) return LL_ERR_SHAPE;
@@ -1404,10 +1202,6 @@ static int v3_launch(void* out, const void* x, const void* wpacked, const void* 
   p.workspace = workspace; p.counters = counters;
   p.m = m; p.n = n; p.k = k; p.x_stride = x_stride_m;
   p.x_cstride = V3_CK * 2;
-  if (getenv("LL_GEMM3_XCM")) {  // experiment: chunk-major activations [k/128][64][128]
-    p.x_stride = V3_CK;
-    p.x_cstride = V3_BM * V3_CK * 2;
-  }
   p.w_bytes = (uint32_t)(n * k / 2);
   p.s_bytes = (uint32_t)(n * (k / group_size) * 8);
   p.x_bytes = (uint32_t)((m - 1) * x_stride_m * 2 + k * 2);
@@ -1440,31 +1234,9 @@ static int v3_launch(void* out, const void* x, const void* wpacked, const void* 
     (void)hipFuncSetAttribute((const void*)wgemm3_kernel<2, 1>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<1>::BYTES);
     (void)hipFuncSetAttribute((const void*)wgemm3_kernel<1, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<2>::BYTES);
     (void)hipFuncSetAttribute((const void*)wgemm3_kernel<2, 2>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<2>::BYTES);
-    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<1, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<1>::BYTES);
-    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<2, 1, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<1>::BYTES);
-    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<1, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<2>::BYTES);
-    (void)hipFuncSetAttribute((const void*)wgemm3_kernel<2, 2, true>, hipFuncAttributeMaxDynamicSharedMemorySize, V3Lds<2>::BYTES);
     attr_set[dev] = true;
   }
-  if (pre.part) {
-    // one row per workgroup, 256 threads x (1 or 2) x 8 columns, up to 12 partials; the gate's two words follow the error word
-    if (pl.grid < m || k % 8 != 0 || k > 4096 || pre.s_count < 1 || pre.s_count > 12 || x_stride_m < k) return LL_ERR_SHAPE;
-    if (!pre.residual || !pre.weight || !ll_aligned16(pre.part) || !ll_aligned16(pre.residual) || !ll_aligned16(pre.weight))
-      return LL_ERR_ARG;
-    p.pre_part = pre.part; p.pre_s = pre.s_count; p.pre_res = (uint16_t*)pre.residual; p.pre_w = (const uint16_t*)pre.weight;
-    p.pre_eps = pre.eps; p.pre_idx = p.err_idx + 1;
-  }
   const dim3 grid((unsigned)pl.grid);
-  if (pre.part) {
-    if (pl.nf == 2) {
-      if (m <= 32) wgemm3_kernel<1, 2, true><<<grid, V3_THREADS, V3Lds<2>::BYTES, st>>>(p);
-      else wgemm3_kernel<2, 2, true><<<grid, V3_THREADS, V3Lds<2>::BYTES, st>>>(p);
-    } else {
-      if (m <= 32) wgemm3_kernel<1, 1, true><<<grid, V3_THREADS, V3Lds<1>::BYTES, st>>>(p);
-      else wgemm3_kernel<2, 1, true><<<grid, V3_THREADS, V3Lds<1>::BYTES, st>>>(p);
-    }
-    return LL_LAUNCH_CHECK();
-  }
   if (pl.nf == 2) {
     if (m <= 32) wgemm3_kernel<1, 2><<<grid, V3_THREADS, V3Lds<2>::BYTES, st>>>(p);
     else wgemm3_kernel<2, 2><<<grid, V3_THREADS, V3Lds<2>::BYTES, st>>>(p);
@@ -1479,31 +1251,5 @@ extern "C" int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* w
                                          const void* bias, int64_t m, int64_t n, int64_t k, int group_size,
                                          int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,
                                          void* stream) {
-  return v3_launch(out, x, wpacked, spacked, bias, m, n, k, group_size, x_stride_m, workspace, counters, epilogue, V3Pre{}, stream);
-}
-
-// 1 / 0: ll_w4a16_matmul_prepacked_normed serves the shape (same epilogue word; s_count = number of norm partials)
-extern "C" int ll_w4a16_prepacked_normed_supported(int64_t m, int64_t n, int64_t k, int group_size, int epilogue, int s_count) {
-  if (m < 1 || !ll_w4a16_prepacked_supported(m, n, k, group_size)) return 0;
-  const bool partials = (epilogue & 3) == 2;
-  if (partials && !ll_w4a16_partials_count(m, n, k, group_size)) return 0;
-  const V3Plan pl = v3_plan(n, k, (epilogue >> 8) & 3, partials);
-  return pl.grid >= m && k % 8 == 0 && k <= 4096 && s_count >= 1 && s_count <= 12 ? 1 : 0;
-}
-
-// ll_skip_rmsnorm_partials + ll_w4a16_matmul_prepacked in ONE launch (decode step, TP = 1): ``x`` [m][k] is an OUTPUT here --
-// the normalised rows, written by the launch itself (workgroup r < m: row r, values bit-identical to
-// ll_skip_rmsnorm_partials(x, norm_partials, s_count, residual, norm_weight, m, k, eps)) while the weight stream is already
-// running, then consumed by every workgroup's activation loaders behind a launch-wide gate -- one kernel boundary and the
-// GEMM's cold start less per add-and-normalise.  ``residual`` [m][k] is updated in place.  fp16, k <= 4096, k % 8 == 0,
-// 1 <= s_count <= 12, and a launch of at least m workgroups (LL_ERR_SHAPE otherwise: run the two launches).  ``counters`` as
-// for ll_w4a16_matmul_prepacked (ll_w4a16_v3_workspace sizes it; all words zero at rest).
-extern "C" int ll_w4a16_matmul_prepacked_normed(void* out, void* x, const void* wpacked, const void* spacked, const void* bias,
-                                                int64_t m, int64_t n, int64_t k, int group_size, int64_t x_stride_m,
-                                                float* workspace, int32_t* counters, int epilogue, const float* norm_partials,
-                                                int s_count, void* residual, const void* norm_weight, float eps, void* stream) {
-  if (!norm_partials) return LL_ERR_ARG;
-  V3Pre pre;
-  pre.part = norm_partials; pre.s_count = s_count; pre.residual = residual; pre.weight = norm_weight; pre.eps = eps;
-  return v3_launch(out, x, wpacked, spacked, bias, m, n, k, group_size, x_stride_m, workspace, counters, epilogue, pre, stream);
+  return v3_launch(out, x, wpacked, spacked, bias, m, n, k, group_size, x_stride_m, workspace, counters, epilogue, stream);
 }

@@ -643,14 +643,7 @@ static Plan make_plan(int64_t m, int64_t n, int64_t k) {
   return pl;
 }
 
-// second-generation W4A16 engine (gemm_w4_v2.hip)
-extern "C" int ll_w4a16_v2_workspace(int64_t m, int64_t n, int64_t k, int64_t* floats, int64_t* ints);
-extern "C" int ll_w4a16_v2_supported(int64_t m, int64_t n, int64_t k, int group_size);
 extern "C" int ll_w4a16_v3_workspace(int64_t m, int64_t n, int64_t k, int64_t* floats, int64_t* ints);  // gemm_w4_v3.hip
-extern "C" int ll_w4a16_v2_launch(void* out, const void* x, const int32_t* qweight, const float* scales,
-                                  const float* zeros, const void* packed, const void* bias, int64_t m, int64_t n, int64_t k,
-                                  int group_size, int64_t x_stride_m, int64_t qw_stride_n, int64_t s_stride_n,
-                                  float* workspace, int32_t* counters, int epilogue, void* stream);
 
 // the decode-shaped 8-bit engine (gemm_w8_skinny.hip): served shapes leave S fp32 / int32 partial planes in the workspace
 extern "C" int64_t ll_dense8_partial_words(int64_t m, int64_t n, int64_t k);
@@ -665,10 +658,7 @@ extern "C" int ll_gemm_workspace(int64_t m, int64_t n, int64_t k, int64_t* works
   const Plan pl = make_plan(m, n, k);
   const int64_t tiles = (int64_t)pl.mblocks * pl.nblocks;
   int64_t f = tiles * pl.slots * GEMM_SLAB, c = tiles * 4, f2 = 0, c2 = 0;
-  ll_w4a16_v2_workspace(m, n, k, &f2, &c2);  // the scratch must fit whichever engine is dispatched
-  if (f2 > f) f = f2;
-  if (c2 > c) c = c2;
-  ll_w4a16_v3_workspace(m, n, k, &f2, &c2);
+  ll_w4a16_v3_workspace(m, n, k, &f2, &c2);  // the scratch must fit whichever engine is dispatched
   const int64_t f3 = ll_dense8_partial_words(m, n, k);
   if (f3 > f) f = f3;
   const int64_t f4 = ll_dense16_partial_words(m, n, k);
@@ -701,11 +691,12 @@ static int launch_wgemm(GemmParams& p, hipStream_t st) {
   return LL_LAUNCH_CHECK();
 }
 
-extern "C" int ll_w4a16_matmul_packed(void* out, const void* x, const int32_t* qweight, const float* scales,
-                                      const float* zeros, const void* packed_sz, const void* bias, int64_t m,
-                                      int64_t n, int64_t k, int group_size, int64_t x_stride_m,
-                                      int64_t qw_stride_n, int64_t s_stride_n, float* workspace,
-                                      int32_t* counters, void* stream) {
+// Reference-layout entry (any M, any group size): the generic engine.  Decode-shaped calls reach the pre-packed engine
+// (gemm_w4_v3.hip) through the Python mirror, which builds the load-time layout once per weight.
+extern "C" int ll_w4a16_matmul(void* out, const void* x, const int32_t* qweight, const float* scales,
+                               const float* zeros, const void* bias, int64_t m, int64_t n, int64_t k,
+                               int group_size, int64_t x_stride_m, int64_t qw_stride_n,
+                               int64_t s_stride_n, float* workspace, int32_t* counters, void* stream) {
   if (m < 0 || n <= 0 || k <= 0 || group_size <= 0 || k % group_size != 0) return LL_ERR_SHAPE;
   if (k % 32 != 0 || x_stride_m % 8 != 0 || qw_stride_n % 4 != 0) return LL_ERR_SHAPE;
   if (!ll_aligned16(x) || !ll_aligned16(qweight)) return LL_ERR_ARG;
@@ -716,41 +707,11 @@ extern "C" int ll_w4a16_matmul_packed(void* out, const void* x, const int32_t* q
   p.m = m; p.n = n; p.k = k; p.x_stride = x_stride_m; p.w_stride = qw_stride_n;
   p.s_stride_n = s_stride_n; p.s_stride_k = 1; p.group_n = 1; p.group_k = group_size;
   hipStream_t st = (hipStream_t)stream;
-  if (workspace && counters && ll_w4a16_v2_supported(m, n, k, group_size))
-    return ll_w4a16_v2_launch(out, x, qweight, scales, zeros, packed_sz, bias, m, n, k, group_size, x_stride_m,
-                              qw_stride_n, s_stride_n, workspace, counters, 0, stream);
   if (group_size % 64 == 0) return launch_wgemm<FMT_W4, 1>(p, st);
   if (group_size == 32) return launch_wgemm<FMT_W4, 2>(p, st);
   if (group_size == 16) return launch_wgemm<FMT_W4, 4>(p, st);
   if (group_size == 8) return launch_wgemm<FMT_W4, 8>(p, st);
   return LL_ERR_SHAPE;
-}
-
-extern "C" int ll_w4a16_decode_supported(int64_t m, int64_t n, int64_t k, int group_size) {
-  return ll_w4a16_v2_supported(m, n, k, group_size) ? 1 : 0;
-}
-
-// Fused gate/up projection + swiglu for the decode engine: weight rows are interleaved
-// (row 2j = gate_j, row 2j+1 = up_j), out[m, n/2] = silu(gate) * up.  Only the decode engine
-// implements it; LL_ERR_SHAPE tells the caller to run the two-step form instead.
-extern "C" int ll_w4a16_gateup_swiglu(void* out, const void* x, const int32_t* qweight, const float* scales,
-                                      const float* zeros, const void* packed_sz, int64_t m, int64_t n, int64_t k,
-                                      int group_size, int64_t x_stride_m, int64_t qw_stride_n,
-                                      int64_t s_stride_n, float* workspace, int32_t* counters, void* stream) {
-  if (m <= 0 || n <= 0 || k <= 0 || group_size <= 0 || k % group_size != 0 || (n & 1)) return LL_ERR_SHAPE;
-  if (x_stride_m % 8 != 0 || qw_stride_n % 4 != 0) return LL_ERR_SHAPE;
-  if (!ll_aligned16(x) || !ll_aligned16(qweight) || !workspace || !counters) return LL_ERR_ARG;
-  if (!ll_w4a16_v2_supported(m, n, k, group_size)) return LL_ERR_SHAPE;
-  return ll_w4a16_v2_launch(out, x, qweight, scales, zeros, packed_sz, nullptr, m, n, k, group_size, x_stride_m,
-                            qw_stride_n, s_stride_n, workspace, counters, 1, stream);
-}
-
-extern "C" int ll_w4a16_matmul(void* out, const void* x, const int32_t* qweight, const float* scales,
-                               const float* zeros, const void* bias, int64_t m, int64_t n, int64_t k,
-                               int group_size, int64_t x_stride_m, int64_t qw_stride_n,
-                               int64_t s_stride_n, float* workspace, int32_t* counters, void* stream) {
-  return ll_w4a16_matmul_packed(out, x, qweight, scales, zeros, nullptr, bias, m, n, k, group_size, x_stride_m,
-                                qw_stride_n, s_stride_n, workspace, counters, stream);
 }
 
 extern "C" int ll_w8a16_matmul(void* out, const void* x, const void* qweight, const float* scales,

@@ -70,43 +70,12 @@ class PartialSums:
         return out
 
 
-class PendingNorm:
-    """An add-and-normalise over split-K partials that has NOT run yet (decode-step extension, TP = 1): the projection
-    that consumes the normalised rows produces them inside its own launch (``ll_w4a16_matmul_prepacked_normed`` -- one
-    kernel boundary and the GEMM's cold start less).  ``out`` is the [rows, n] tensor the rows WILL be in: valid after a
-    consumer has taken the norm into its launch (``take()``) or after :meth:`materialise` (the separate launch; idempotent).
-    Whoever holds a PendingNorm must do one of the two before anything reads ``out``."""
-
-    __slots__ = ("X", "residual", "weight", "eps", "out", "done")
-
-    def __init__(self, X: "PartialSums", residual, weight, eps, out):
-        self.X, self.residual, self.weight, self.eps, self.out, self.done = X, residual, weight, float(eps), out, False
-
-    def materialise(self) -> torch.Tensor:
-        if not self.done:
-            s, m, n = self.X.parts.shape
-            L.check(
-                L.lib().ll_skip_rmsnorm_partials(self.out.data_ptr(), self.X.parts.data_ptr(), s, self.residual.data_ptr(),
-                                                 self.weight.data_ptr(), m, n, self.eps, L.dtype_code(self.X.dtype),
-                                                 L.stream_ptr()),
-                "skip_rmsnorm_partials",
-            )
-            self.done = True
-        return self.out
-
-    def take(self):
-        """-> (partials ptr, s_count, residual ptr, weight ptr, eps) for a launch that does the norm itself."""
-        self.done = True
-        return self.X.parts.data_ptr(), self.X.parts.shape[0], self.residual.data_ptr(), self.weight.data_ptr(), self.eps
-
-
 @torch.no_grad()
-def skip_rmsnorm_partials(X: PartialSums, residual, weight, eps=1e-5, defer: bool = False):
+def skip_rmsnorm_partials(X: PartialSums, residual, weight, eps=1e-5):
     """:func:`skip_rmsnorm` over a :class:`PartialSums` input: ``x = fp16(sum of the partials)`` -- the value the
     projection itself would have stored -- then the same add-and-normalise.  ``residual`` is required.
-    ``defer``: the caller hands the result to a projection that can normalise inside its own launch -- with
-    ``LL_NORM_IN_GEMM=1`` in the environment the first return value may then be a :class:`PendingNorm` (same values,
-    produced later).  Off by default: the in-launch form is bit-identical but slower."""
+    (Round 3's in-launch form -- the consuming projection normalising inside its own launch -- measured 10 us slower per
+    pair and was removed in round 4: DESIGN.md 4.2.)"""
     if residual is None:
         raise ValueError("skip_rmsnorm_partials needs a residual (the projection follows a normalised block)")
     L.require_cuda(X.parts, residual, weight)
@@ -118,9 +87,6 @@ def skip_rmsnorm_partials(X: PartialSums, residual, weight, eps=1e-5, defer: boo
     if weight.dtype != X.dtype:
         weight = weight.to(X.dtype)
     Y = torch.empty((m, n), dtype=X.dtype, device=residual.device)
-    if (defer and not X.tp_reduce and X.dtype == torch.float16 and n % 8 == 0 and n <= 4096 and s <= 12 and m <= 64
-            and os.environ.get("LL_NORM_IN_GEMM")):  # opt-in: measured SLOWER than the two launches
-        return PendingNorm(X, residual, weight.contiguous(), eps, Y.view(X.shape)), residual.view(X.shape)
     if X.tp_reduce:
         # tensor parallelism: the partials are this rank's share; one launch adds them, exchanges the fp16 sums with the
         # peers (one-shot all-reduce over peer-mapped buffers, fp32 adds in rank order) and normalises

@@ -53,12 +53,10 @@ def w4a16_matmul(
     *,
     group_size: int = 128,
     bias: torch.Tensor | None = None,
-    packed_scales: torch.Tensor | None = None,
 ) -> torch.Tensor:
     """``x @ dequant(qweight).T (+ bias)``; ``W[n,k] = (nib(n,k) - zeros[n,k//g]) * scales[n,k//g]``.
-
-    ``packed_scales`` (extension, from :func:`pack_w4a16_scales`) is a load-time re-layout of
-    ``scales``/``zeros`` that the decode engine streams 4x cheaper; results are bit-identical."""
+    Decode-shaped calls (<= 64 rows) run on the pre-packed engine over load-time layouts built once per weight
+    (:func:`_auto_prepacked`); every other shape on the generic engine over the reference layout."""
     if x.dtype != torch.float16:
         raise ValueError(f"w4a16 activations must be fp16, got {x.dtype}")
     if qweight.dtype != torch.int32:
@@ -82,55 +80,20 @@ def w4a16_matmul(
         scales = scales.contiguous()
     if bias is not None and bias.dtype != torch.float16:
         bias = bias.half()
-    if packed_scales is not None:
-        L.require_cuda(packed_scales)
-        if tuple(packed_scales.shape) != (k // group_size, n, 2) or packed_scales.dtype != torch.int32 \
-                or not packed_scales.is_contiguous():
-            raise ValueError("packed_scales must be the int32 [K/g, N, 2] tensor made by pack_w4a16_scales")
     pre = _auto_prepacked(m, n, k, group_size, qweight, scales, zeros)
     if pre is not None:  # decode-shaped call of the reference signature: the load-time layouts, made once per weight
         return w4a16_matmul_prepacked(x, pre[0], pre[1], group_size=group_size, bias=bias)
     out = torch.empty((m, n), dtype=x.dtype, device=x.device)
     ws, cnt = L.gemm_workspace(x.device, m, n, k)
     L.check(
-        L.lib().ll_w4a16_matmul_packed(
+        L.lib().ll_w4a16_matmul(
             out.data_ptr(), a.data_ptr(), qweight.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
-            L.ptr(packed_scales), L.ptr(bias), m, n, k, int(group_size), a.stride(0), qweight.stride(0), scales.stride(0),
+            L.ptr(bias), m, n, k, int(group_size), a.stride(0), qweight.stride(0), scales.stride(0),
             ws.data_ptr(), cnt.data_ptr(), L.stream_ptr(),
         ),
         "w4a16_matmul",
     )
     return out.reshape(*leading, n)
-
-
-def w4a16_gate_up_swiglu(x, qweight, scales, zeros, *, group_size=128, packed_scales=None):
-    """Extension: ``silu(x @ Wg.T) * (x @ Wu.T)`` in ONE launch, where ``qweight/scales/zeros`` hold the
-    gate and up projections row-interleaved (row ``2j`` = gate_j, row ``2j+1`` = up_j).  Same arithmetic as
-    ``swiglu_forward(w4a16_matmul(x, Wg..), w4a16_matmul(x, Wu..))`` (only the fp32 summation order of the
-    stream-K split can differ).  Returns ``None`` when the shape is
-    outside the decode engine (more than 64 rows, ...): the caller then runs the two-step form."""
-    L.require_cuda(x, qweight, scales, zeros, packed_scales)
-    n, k_packed = qweight.shape
-    k = k_packed * 8
-    leading = x.shape[:-1]
-    a = _flatten(x, k)
-    m = a.shape[0]
-    if (x.dtype != torch.float16 or qweight.dtype != torch.int32 or qweight.stride(1) != 1 or n % 2
-            or scales.dtype != torch.float32 or zeros.dtype != torch.float32 or scales.stride(1) != 1
-            or zeros.stride() != scales.stride() or m == 0
-            or not L.lib().ll_w4a16_decode_supported(m, n, k, int(group_size))):
-        return None
-    out = torch.empty((m, n // 2), dtype=x.dtype, device=x.device)
-    ws, cnt = L.gemm_workspace(x.device, m, n, k)
-    L.check(
-        L.lib().ll_w4a16_gateup_swiglu(
-            out.data_ptr(), a.data_ptr(), qweight.data_ptr(), scales.data_ptr(), zeros.data_ptr(),
-            L.ptr(packed_scales), m, n, k, int(group_size), a.stride(0), qweight.stride(0), scales.stride(0),
-            ws.data_ptr(), cnt.data_ptr(), L.stream_ptr(),
-        ),
-        "w4a16_gate_up_swiglu",
-    )
-    return out.reshape(*leading, n // 2)
 
 
 def pack_w4a16_scales(scales: torch.Tensor, zeros: torch.Tensor) -> torch.Tensor:
@@ -172,28 +135,11 @@ def w4a16_prepacked_supported(m: int, n: int, k: int, group_size: int) -> bool:
     return bool(L.lib().ll_w4a16_prepacked_supported(m, n, k, int(group_size)))
 
 
-def _launch_prepacked(out_ptr, a, m, n, k, packed_weight, packed_scales, bias, group_size, epilogue, pending, what):
-    """The decode-engine launch; with ``pending`` (kernels/norm_act.py::PendingNorm whose ``out`` IS ``a``'s storage) and a
-    served shape the launch produces its own activation rows (ll_w4a16_matmul_prepacked_normed), else the pending norm runs
-    as its own launch first."""
+def _launch_prepacked(out_ptr, a, m, n, k, packed_weight, packed_scales, bias, group_size, epilogue, what):
+    """The decode-engine launch."""
     ws, cnt = L.gemm_workspace(a.device, m, n, k)
-    lib = L.lib()
-    if pending is not None and not pending.done:
-        if (pending.out.data_ptr() == a.data_ptr() and a.stride(0) == k and
-                lib.ll_w4a16_prepacked_normed_supported(m, n, k, int(group_size), epilogue, pending.X.parts.shape[0])):
-            parts, s_count, res, wgt, eps = pending.take()
-            L.check(
-                lib.ll_w4a16_matmul_prepacked_normed(
-                    out_ptr, a.data_ptr(), packed_weight.data_ptr(), packed_scales.data_ptr(), L.ptr(bias), m, n, k,
-                    int(group_size), a.stride(0), ws.data_ptr(), cnt.data_ptr(), epilogue, parts, s_count, res, wgt, eps,
-                    L.stream_ptr(),
-                ),
-                what + " (in-launch add-and-normalise)",
-            )
-            return
-        pending.materialise()
     L.check(
-        lib.ll_w4a16_matmul_prepacked(
+        L.lib().ll_w4a16_matmul_prepacked(
             out_ptr, a.data_ptr(), packed_weight.data_ptr(), packed_scales.data_ptr(), L.ptr(bias), m, n, k,
             int(group_size), a.stride(0), ws.data_ptr(), cnt.data_ptr(), epilogue, L.stream_ptr(),
         ),
@@ -202,15 +148,13 @@ def _launch_prepacked(out_ptr, a, m, n, k, packed_weight, packed_scales, bias, g
 
 
 def w4a16_matmul_prepacked(x, packed_weight, packed_scales, *, group_size: int = 128, bias=None, gate_up_swiglu=False,
-                           _tile_blocks: int = 0, pending=None):
+                           _tile_blocks: int = 0):
     """Decode-engine form of :func:`w4a16_matmul` over the load-time layouts (``pack_w4a16_weights`` /
     ``pack_w4a16_scales``); at most 64 rows.  ``gate_up_swiglu`` applies the fused epilogue of
-    :func:`w4a16_gate_up_swiglu` (rows interleaved gate/up).  Same arithmetic as ``w4a16_matmul``.
+    the fused gate|up launch (rows interleaved gate/up: out = silu(gate) * up).  Same arithmetic as ``w4a16_matmul``.
     ``_tile_blocks`` (tests / tuning): 0 = tile width chosen by the host plan, 1 / 2 = 128- / 256-row tiles."""
     if x.dtype != torch.float16:
         raise ValueError(f"w4a16 activations must be fp16, got {x.dtype}")
-    if pending is not None and not pending.done and (x.data_ptr() != pending.out.data_ptr() or not x.is_contiguous()):
-        pending.materialise()  # not the pending norm's own rows: they are read before the launch
     L.require_cuda(x, packed_weight, packed_scales, bias)
     if packed_weight.dtype != torch.int32 or packed_weight.dim() != 5 or not packed_weight.is_contiguous():
         raise ValueError("packed_weight must be the int32 [N/128, K/128, 8, 64, 4] tensor made by pack_w4a16_weights")
@@ -230,17 +174,15 @@ def w4a16_matmul_prepacked(x, packed_weight, packed_scales, *, group_size: int =
     n_out = n // 2 if gate_up_swiglu else n
     out = torch.empty((m, n_out), dtype=x.dtype, device=x.device)
     _launch_prepacked(out.data_ptr(), a, m, n, k, packed_weight, packed_scales, bias, group_size,
-                      (1 if gate_up_swiglu else 0) | ((int(_tile_blocks) & 3) << 8), pending, "w4a16_matmul_prepacked")
+                      (1 if gate_up_swiglu else 0) | ((int(_tile_blocks) & 3) << 8), "w4a16_matmul_prepacked")
     return out.reshape(*leading, n_out)
 
 
-def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 128, pending=None):
+def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 128):
     """Decode-step extension: the projection as ``S`` fp32 split-K partial sums (:class:`PartialSums`) for
     :func:`skip_rmsnorm_partials` to add up -- the GEMM has no cross-workgroup merge then.  ``None`` when the shape
     is not served (the caller runs :func:`w4a16_matmul_prepacked`)."""
     from .norm_act import PartialSums
-    if pending is not None and not pending.done and (x.data_ptr() != pending.out.data_ptr() or not x.is_contiguous()):
-        pending.materialise()
     L.require_cuda(x, packed_weight, packed_scales)
     n, k = packed_weight.shape[0] * 128, packed_weight.shape[1] * 128
     if x.dtype != torch.float16 or x.shape[-1] != k or n % 8:
@@ -253,8 +195,7 @@ def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 
     if s < 1:
         return None
     parts = torch.empty((s, m, n), dtype=torch.float32, device=x.device)
-    _launch_prepacked(parts.data_ptr(), a, m, n, k, packed_weight, packed_scales, None, group_size, 2, pending,
-                      "w4a16_matmul_partials")
+    _launch_prepacked(parts.data_ptr(), a, m, n, k, packed_weight, packed_scales, None, group_size, 2, "w4a16_matmul_partials")
     return PartialSums(parts, (*x.shape[:-1], n), x.dtype)
 
 

@@ -207,38 +207,26 @@ class MergedColumnLinear:
             return out[..., 0::2], out[..., 1::2]
         return torch.split(out, [l.output_size for l in self.layers], dim=-1)
 
-    def partials(self, x: torch.Tensor, pending=None):
+    def partials(self, x: torch.Tensor):
         """The merged projection left as fp32 split-K partials (:class:`PartialSums`, bias NOT added -- returned next
         to it) for a consumer that adds them up (``decode_attention_partials``); ``None`` when not served."""
         h = self._holder
         if h is None or h.interleaved or not hasattr(h.quant_method, "apply_partials") or get_tp_world_size() != 1 \
                 or collective_forced():
             return None
-        if pending is not None and getattr(h.quant_method, "accepts_pending_norm", False):
-            parts = h.quant_method.apply_partials(h, x, allow_bias=True, pending=pending)
-        else:
-            if pending is not None:
-                pending.materialise()
-            parts = h.quant_method.apply_partials(h, x, allow_bias=True)
+        parts = h.quant_method.apply_partials(h, x, allow_bias=True)
         return None if parts is None else (parts, h.bias)
 
-    def swiglu(self, x: torch.Tensor, pending=None) -> torch.Tensor:
+    def swiglu(self, x: torch.Tensor) -> torch.Tensor:
         """``silu(gate(x)) * up(x)`` for a (gate, up) pair: one launch when interleaved and the shape is
         in the decode engine, else the merged GEMM followed by ``swiglu_forward``."""
         from .kernels import swiglu_forward
 
         h = self._holder
         if h.interleaved:
-            if pending is not None and getattr(h.quant_method, "accepts_pending_norm", False):
-                y = h.quant_method.apply_gate_up_swiglu(h, x, pending=pending)
-            else:
-                if pending is not None:
-                    pending.materialise()
-                y = h.quant_method.apply_gate_up_swiglu(h, x)
+            y = h.quant_method.apply_gate_up_swiglu(h, x)
             if y is not None:
                 return y
-        if pending is not None:
-            pending.materialise()  # (idempotent) ``x`` is read below
         gate, up = self(x)
         return swiglu_forward(gate, up)
 

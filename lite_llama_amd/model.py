@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from .distributed.parallel_state import all_reduce_tp, divide, get_tp_rank, get_tp_world_size
 from .distributed.partition import ShardPlan, make_plan, scale_unit, set_active_plan
 from .kernels.attention import decode_attention, decode_attention_partials, decode_attention_partials_supported
-from .kernels.norm_act import PartialSums, PendingNorm, rope_and_cache, skip_rmsnorm_partials
+from .kernels.norm_act import PartialSums, rope_and_cache, skip_rmsnorm_partials
 from .kernels import (
     flash_attention2_no_pad,
     flash_decoding,
@@ -258,9 +258,6 @@ class Attention(nn.Module):
         object.__setattr__(self, "_qkv", MergedColumnLinear([self.q_proj, self.kv_proj]))
 
     def forward(self, x, atten_info, layer_index, position_embeddings, partials_ok=False):
-        pend = None
-        if isinstance(x, PendingNorm):  # the add-and-normalise before this block has not run: q|k|v's launch does it
-            pend, x = x, x.out
         batch, seq_len, _ = x.shape
         x2 = x.view(-1, self.hidden_size)
         fp8_pool = atten_info.kv_buffer[layer_index].element_size() == 1  # extension: e4m3 KV cache, unfused route
@@ -270,9 +267,7 @@ class Attention(nn.Module):
                                                         self.head_dim)):
             # decode, int4, TP = 1: the fused q|k|v projection leaves fp32 split-K partials and the one-launch attention
             # adds them up (+ bias) while its first K/V gathers are in flight -- the GEMM has no merge at all
-            pq = self._qkv.partials(x2, pending=pend)
-            if pend is not None:
-                pend.materialise()  # (no-op when the projection took it)
+            pq = self._qkv.partials(x2)
             if pq is not None:
                 tables = position_embeddings
                 out = decode_attention_partials(pq[0], pq[1], self.num_heads, self.num_kv_heads, self.head_dim, tables[0],
@@ -288,12 +283,8 @@ class Attention(nn.Module):
             else:
                 xq, xkv = self._qkv(x2)
         elif self._qkv.refresh():
-            if pend is not None:
-                pend.materialise()
             xq, xkv = self._qkv(x2)  # one launch; strided column views of [n, q + 2 kv]
         else:
-            if pend is not None:
-                pend.materialise()
             xq = self.q_proj(x2)
             xkv = self.kv_proj(x2)
         n = batch * seq_len
@@ -335,12 +326,10 @@ class Attention(nn.Module):
         return self.o_proj(out.view(batch, seq_len, self.q_size))
 
 
-def add_norm(hidden_states, residual, weight, eps, defer=False):
-    """``skip_rmsnorm`` that also accepts a projection left as split-K partials (kernels/norm_act.py::PartialSums).
-    ``defer``: the consumer (Attention / FusedMLP below) can take the normalisation into its projection's launch -- the
-    first return value may be a :class:`PendingNorm`."""
+def add_norm(hidden_states, residual, weight, eps):
+    """``skip_rmsnorm`` that also accepts a projection left as split-K partials (kernels/norm_act.py::PartialSums)."""
     if isinstance(hidden_states, PartialSums):
-        return skip_rmsnorm_partials(hidden_states, residual, weight, eps, defer=defer)
+        return skip_rmsnorm_partials(hidden_states, residual, weight, eps)
     return skip_rmsnorm(hidden_states, residual, weight, eps)
 
 
@@ -358,13 +347,8 @@ class FusedMLP(nn.Module):
         object.__setattr__(self, "_gate_up", MergedColumnLinear([self.gate_proj, self.up_proj], interleave=True))
 
     def forward(self, x, partials_ok=False):
-        pend = None
-        if isinstance(x, PendingNorm):  # the add-and-normalise before this block has not run: gate|up's launch does it
-            pend, x = x, x.out
         if self._gate_up.refresh():
-            return self.down_proj(self._gate_up.swiglu(x, pending=pend), partials_ok)  # one launch (int4 decode) or merged GEMM + swiglu
-        if pend is not None:
-            pend.materialise()
+            return self.down_proj(self._gate_up.swiglu(x), partials_ok)  # one launch (int4 decode) or merged GEMM + swiglu
         return self.down_proj(swiglu_forward(self.gate_proj(x), self.up_proj(x)), partials_ok)
 
 
@@ -443,10 +427,9 @@ class DecoderLayer(nn.Module):
     def forward(self, hidden_states, atten_info, layer_index, position_embeddings, residual=None):
         """``hidden_states`` in and out may be a :class:`PartialSums` (decode, int4, TP = 1): the row-parallel
         projections leave fp32 split-K partials and the add-and-normalise that follows adds them up."""
-        hidden_states, residual = add_norm(hidden_states, residual, self.input_layernorm_weight, self.eps, defer=True)
+        hidden_states, residual = add_norm(hidden_states, residual, self.input_layernorm_weight, self.eps)
         hidden_states = self.self_attn(hidden_states, atten_info, layer_index, position_embeddings, partials_ok=True)
-        hidden_states, residual = add_norm(hidden_states, residual, self.post_attention_layernorm_weight, self.eps,
-                                           defer=isinstance(self.mlp, FusedMLP))
+        hidden_states, residual = add_norm(hidden_states, residual, self.post_attention_layernorm_weight, self.eps)
         if isinstance(self.mlp, FusedMLP):
             hidden_states = self.mlp(hidden_states, partials_ok=True)
         else:

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..kernels import fused_moe, smoothquant_matmul, w4a16_matmul, w8a16_matmul
-from ..kernels.quantization import (dense16_linear, pack_w4a16_scales, pack_w4a16_weights, w4a16_gate_up_swiglu, w4a16_matmul_partials,
+from ..kernels.quantization import (dense16_linear, pack_w4a16_scales, pack_w4a16_weights, w4a16_matmul_partials,
                                     w4a16_matmul_prepacked, w4a16_prepacked_supported)
 from .config import FP8, INT4, INT8, SMOOTHQUANT, QuantConfig
 from .params import (
@@ -86,43 +86,31 @@ class W4A16LinearMethod(LinearQuantMethod):
         if pre is not None:
             return w4a16_matmul_prepacked(x, pre, self._packed(layer), group_size=layer.quant.group_k, bias=layer.bias)
         return w4a16_matmul(x, layer.weight, layer.weight_scale, layer.weight_zeros,
-                            group_size=layer.quant.group_k, bias=layer.bias,
-                            packed_scales=self._packed(layer))
+                            group_size=layer.quant.group_k, bias=layer.bias)
 
-    accepts_pending_norm = True  # apply_partials / apply_gate_up_swiglu take ``pending`` (kernels/norm_act.py::PendingNorm)
-
-    def apply_partials(self, layer, x, allow_bias: bool = False, pending=None):
+    def apply_partials(self, layer, x, allow_bias: bool = False):
         """Decode-shaped projection left as fp32 split-K partials for ``skip_rmsnorm_partials`` /
         ``decode_attention_partials`` (extension); ``None`` -> the caller runs :meth:`apply`.  The partials never
         include the bias: a consumer that adds it itself passes ``allow_bias``."""
         if (layer.bias is not None and not allow_bias) or os.environ.get("LL_W4_NO_PARTIALS"):
             return None
-        if pending is not None and getattr(layer, "act_perm", None) is not None:
-            pending.materialise()  # the gather below reads the rows
         x = _ordered_input(layer, x)
         pre = self._prepacked(layer, x)
         if pre is None:
             return None
-        return w4a16_matmul_partials(x, pre, self._packed(layer), group_size=layer.quant.group_k, pending=pending)
+        return w4a16_matmul_partials(x, pre, self._packed(layer), group_size=layer.quant.group_k)
 
-    def apply_gate_up_swiglu(self, layer, x, pending=None):
+    def apply_gate_up_swiglu(self, layer, x):
         """``layer`` holds gate/up row-interleaved (linear.py::MergedColumnLinear): one launch for
-        both projections and the activation; ``None`` -> the caller falls back to the two-step form.
-        ``pending``: ``x`` is the output of an add-and-normalise that has not run yet -- the decode engine's launch
-        does it (or it is run here before anything else reads ``x``)."""
+        both projections and the activation; ``None`` -> the caller falls back to the two-step form."""
         if layer.bias is not None:
             return None
-        if pending is not None and getattr(layer, "act_perm", None) is not None:
-            pending.materialise()
         x = _ordered_input(layer, x)
         pre = self._prepacked(layer, x)
         if pre is not None:
             return w4a16_matmul_prepacked(x, pre, self._packed(layer), group_size=layer.quant.group_k,
-                                          gate_up_swiglu=True, pending=pending)
-        if pending is not None:
-            pending.materialise()
-        return w4a16_gate_up_swiglu(x, layer.weight, layer.weight_scale, layer.weight_zeros,
-                                    group_size=layer.quant.group_k, packed_scales=self._packed(layer))
+                                          gate_up_swiglu=True)
+        return None
 
     @staticmethod
     def _packed(layer):

@@ -30,8 +30,7 @@ def test_abi_exports_match_header():
 def test_w4a16_decode_plan_host_side():
     """Host-side launch plan of the pre-packed W4A16 engine (no device needed: without one the plan assumes 256 CUs): the
     split-K partial launches of the headline model -- q|k|v keeps five k-slices, o and down take the power-of-two split of
-    the XCD-aware slice map (a launch that would fill < 85 % of the CUs keeps the plain split) -- and the shape rules of the
-    in-launch add-and-normalise entry."""
+    the XCD-aware slice map (a launch that would fill < 85 % of the CUs keeps the plain split)."""
     from lite_llama_amd import _lib
 
     lib = _lib.lib()
@@ -42,12 +41,6 @@ def test_w4a16_decode_plan_host_side():
     assert counts == {(4608, 3584): 5, (3584, 3584): 8, (3584, 18944): 8}, counts
     assert all(1 <= c <= 12 for c in counts.values())                         # what ll_skip_rmsnorm_partials accepts
     assert lib.ll_w4a16_partials_count(64, 37888, 3584, 128) == 1             # many tiles: one plane (= no split)
-    # in-launch norm: needs >= m workgroups, k <= 4096, 1..12 partials
-    assert lib.ll_w4a16_prepacked_normed_supported(64, 4608, 3584, 128, 2, 9) == 1
-    assert lib.ll_w4a16_prepacked_normed_supported(64, 37888, 3584, 128, 1, 5) == 1
-    assert lib.ll_w4a16_prepacked_normed_supported(64, 3584, 18944, 128, 0, 5) == 0   # k > 4096
-    assert lib.ll_w4a16_prepacked_normed_supported(64, 4608, 3584, 128, 2, 13) == 0
-    assert lib.ll_w4a16_prepacked_normed_supported(64, 128, 256, 128, 0, 2) == 0      # one tile x <= 2 chunks: fewer workgroups than rows
 
 
 def test_kernel_names_match_reference_surface():

@@ -447,9 +447,9 @@ def test_w4a16_oracle(M, N, K_, gs):
 @pytest.mark.parametrize("M,N,K_,gs", [(64, 18944, 3584, 128), (64, 3584, 18944, 128), (17, 1024, 3584, 128),
                                        (64, 4608, 3584, 256), (1, 128, 512, 128), (64, 37888, 3584, 128)])
 def test_w4a16_decode_engine_shapes_and_packed_scales(M, N, K_, gs):
-    """The decode engine's stream-K paths (tiles split over 1..10 workgroups) at the real Qwen2.5-7B
-    shapes: vs the oracle on a row sample, and bit-identical with/without the packed scale grid."""
-    from lite_llama_amd.kernels.quantization import pack_w4a16_scales
+    """The reference signature at the real Qwen2.5-7B decode shapes (the call reaches the pre-packed engine through the
+    load-time layouts built once per weight: stream-K / owner-contributor / tile-group plans): vs the oracle on a row
+    sample, and bit-identical over repeated launches (the merge scratch must come back to zero)."""
     g = torch.Generator().manual_seed(N + K_)
     x = torch.randn(M, K_, dtype=torch.float16, generator=g) * 0.5
     qw = torch.randint(-(2**31), 2**31 - 1, (N, K_ // 8), dtype=torch.int64, generator=g).to(torch.int32)
@@ -457,16 +457,13 @@ def test_w4a16_decode_engine_shapes_and_packed_scales(M, N, K_, gs):
     zr = torch.randint(0, 16, (N, K_ // gs), generator=g).float()
     xd, qd, sd, zd = x.to(DEV), qw.to(DEV), sc.to(DEV), zr.to(DEV)
     y0 = K().w4a16_matmul(xd, qd, sd, zd, group_size=gs)
-    pk = pack_w4a16_scales(sd, zd)
-    for _ in range(3):  # repeated launches reuse the stream-K scratch (counters must come back to zero)
-        y1 = K().w4a16_matmul(xd, qd, sd, zd, group_size=gs, packed_scales=pk)
-        assert torch.equal(y0, y1)
+    assert getattr(qd, "_ll_prepacked", None) is not None   # the decode engine's layouts were built for this weight
+    for _ in range(3):
+        assert torch.equal(y0, K().w4a16_matmul(xd, qd, sd, zd, group_size=gs))
     rows = torch.randperm(N, generator=g)[:256].sort().values
     ref = O.w4a16_matmul(x, qw[rows], sc[rows], zr[rows], group_size=gs)
     close(y0[:, rows.to(DEV)], ref, 5e-2)
     close(y0[:, rows.to(DEV)], ref, 1e-2)
-    with pytest.raises(ValueError):
-        K().w4a16_matmul(xd, qd, sd, zd, group_size=gs, packed_scales=pk[:, : N // 2])
 
 
 def test_w4a16_float_zero_points_and_errors():
@@ -762,7 +759,8 @@ def test_rope_and_cache_equals_rope_then_update_kv_buffer(HQ, HKV, D, B, S):
 
 @pytest.mark.parametrize("M,I,K_,gs", [(64, 18944, 3584, 128), (5, 512, 256, 128), (33, 1024, 1024, 256)])
 def test_w4a16_gate_up_swiglu_equals_two_gemms_and_swiglu(M, I, K_, gs):
-    from lite_llama_amd.kernels.quantization import pack_w4a16_scales, w4a16_gate_up_swiglu
+    """The fused gate|up launch (rows interleaved, swiglu in the epilogue) against swiglu_forward over the two projections."""
+    from lite_llama_amd.kernels.quantization import pack_w4a16_scales, pack_w4a16_weights, w4a16_matmul_prepacked
     g = torch.Generator().manual_seed(I + K_)
     x = (torch.randn(M, K_, generator=g) * 0.5).half().to(DEV)
 
@@ -775,15 +773,15 @@ def test_w4a16_gate_up_swiglu_equals_two_gemms_and_swiglu(M, I, K_, gs):
     ref = K().swiglu_forward(K().w4a16_matmul(x, qg, sg, zg, group_size=gs), K().w4a16_matmul(x, qu, su, zu, group_size=gs))
     il = lambda a, b: torch.stack([a, b], dim=1).reshape(2 * I, -1).contiguous()
     q2, s2, z2 = il(qg, qu), il(sg, su), il(zg, zu)
-    for pk in (None, pack_w4a16_scales(s2, z2)):
-        got = w4a16_gate_up_swiglu(x, q2, s2, z2, group_size=gs, packed_scales=pk)
-        assert got is not None
-        # same arithmetic; the stream-K split points of the 2I-row launch differ from those of the two
-        # I-row launches, so the fp32 summation order (and rarely the last fp16 bit) may differ
-        torch.testing.assert_close(got.float(), ref.float(), rtol=2e-3, atol=2e-3)
-        assert (got == ref).float().mean() > 0.99
-        assert torch.equal(got, w4a16_gate_up_swiglu(x, q2, s2, z2, group_size=gs, packed_scales=pk))  # deterministic
-    assert w4a16_gate_up_swiglu(x.repeat(14, 1)[:65], q2, s2, z2, group_size=gs) is None  # > 64 rows
+    pw, pk = pack_w4a16_weights(q2), pack_w4a16_scales(s2, z2)
+    got = w4a16_matmul_prepacked(x, pw, pk, group_size=gs, gate_up_swiglu=True)
+    # same arithmetic; the split points of the 2I-row launch differ from those of the two I-row launches, so the fp32
+    # summation order (and rarely the last fp16 bit) may differ
+    torch.testing.assert_close(got.float(), ref.float(), rtol=2e-3, atol=2e-3)
+    assert (got == ref).float().mean() > 0.99
+    assert torch.equal(got, w4a16_matmul_prepacked(x, pw, pk, group_size=gs, gate_up_swiglu=True))  # deterministic
+    with pytest.raises(ValueError):
+        w4a16_matmul_prepacked(x.repeat(14, 1)[:65], pw, pk, group_size=gs, gate_up_swiglu=True)  # > 64 rows
 
 
 def test_decode_advance_equals_the_separate_tensor_ops():
@@ -816,13 +814,12 @@ def test_decode_advance_equals_the_separate_tensor_ops():
 
 
 def test_w4a16_decode_engine_random_shapes_match_generic_engine():
-    """Plan edge cases of the decode engine (stream-K vs tile groups, 1..12 contributors per tile, M = 1..64,
-    K/N from one unit to hundreds): equal to the generic engine up to the fp32 summation order, and
-    bit-identical with / without the packed scale grid."""
+    """Plan edge cases of the decode engine (stream-K, owner / contributor split, tile groups, M = 1..64, K/N from one unit
+    to hundreds) through the reference signature: equal to the generic engine (``LL_W4_NO_AUTO_PREPACK``: no load-time
+    layout, reference-format weights) up to the fp32 summation order."""
     import os
     import random
 
-    from lite_llama_amd.kernels.quantization import pack_w4a16_scales
     rnd = random.Random(11)
     try:
         for it in range(36):
@@ -836,16 +833,15 @@ def test_w4a16_decode_engine_random_shapes_match_generic_engine():
             sc = torch.rand(n, k // gs, generator=g, device=DEV) * 0.01 + 0.005
             zr = torch.randint(0, 16, (n, k // gs), generator=g, device=DEV).float()
             bias = (torch.randn(n, generator=g, device=DEV) * 0.1).half() if it % 3 == 0 else None
-            os.environ.pop("LL_GEMM_V1", None)
-            y2 = K().w4a16_matmul(x, qw, sc, zr, group_size=gs, bias=bias, packed_scales=pack_w4a16_scales(sc, zr))
-            y2b = K().w4a16_matmul(x, qw, sc, zr, group_size=gs, bias=bias)
-            os.environ["LL_GEMM_V1"] = "1"  # read per call by the dispatcher
+            os.environ.pop("LL_W4_NO_AUTO_PREPACK", None)
+            y2 = K().w4a16_matmul(x, qw, sc, zr, group_size=gs, bias=bias)
+            assert getattr(qw, "_ll_prepacked", None) is not None
+            os.environ["LL_W4_NO_AUTO_PREPACK"] = "1"  # read per call
             y1 = K().w4a16_matmul(x, qw, sc, zr, group_size=gs, bias=bias)
             scale = y1.float().abs().max().item() + 1e-6
             assert (y2.float() - y1.float()).abs().max().item() <= 2e-3 * scale + 2e-3, (m, n, k, gs)
-            assert torch.equal(y2, y2b), (m, n, k, gs)
     finally:
-        os.environ.pop("LL_GEMM_V1", None)
+        os.environ.pop("LL_W4_NO_AUTO_PREPACK", None)
 
 
 # ------------------------------------------------------------------------------------- #

@@ -475,58 +475,3 @@ def test_engine_penalised_decode_follows_the_reference_loop():
     without = lg0.float().argmax(-1)
     with_pen = O.apply_repetition_penalty(lg0, first.view(B, 1), torch.ones(B, 1, dtype=torch.bool), sp.repetition_penalty).float().argmax(-1)
     assert torch.equal(toks[:, 0], with_pen) or not torch.equal(without, with_pen)
-
-
-@pytest.mark.gpu
-def test_in_launch_norm_route_is_bit_identical(monkeypatch):
-    """``LL_NORM_IN_GEMM=1`` (opt-in, measured slower -- DESIGN.md 4.2): the add-and-normalise over the o / down partials runs
-    INSIDE the gate|up / q|k|v launches (ll_w4a16_matmul_prepacked_normed).  Two layers at the headline widths, batch 64:
-    logits and the new KV rows equal the default route's bit for bit, and the in-launch form really ran three times
-    (layer 0's post-attention norm, layer 1's two norms)."""
-    from lite_llama_amd.kernels.norm_act import PendingNorm
-    from lite_llama_amd.model import CausalLM, tiny_geometry
-    from lite_llama_amd.quantization import QuantConfig
-
-    B, CTX = 64, 300
-    H, I, L, HQ, HKV, D, V = 3584, 18944, 2, 28, 4, 128, 2048
-    g = torch.Generator().manual_seed(99)
-    geo = tiny_geometry(hidden_size=H, intermediate_size=I, num_layers=L, num_heads=HQ, num_kv_heads=HKV,
-                        head_dim=D, vocab_size=V, rope_theta=1000000.0, qkv_bias=True)
-    m = CausalLM(geo)
-    params = {}
-    for name, t in m.state_dict().items():
-        if name.endswith("norm_weight") or name.endswith("layernorm_weight"):
-            params[name] = (1 + 0.1 * torch.randn(t.shape, generator=g)).half()
-        elif name.endswith("bias"):
-            params[name] = (0.01 * torch.randn(t.shape, generator=g)).half()
-        else:
-            params[name] = (0.02 * torch.randn(t.shape, generator=g)).half()
-    m.load_state_dict(params, strict=True)
-    m = m.to("cuda")
-    m.quantize_(QuantConfig.int4_groupwise(128))
-    m.rotary_emb.ensure(CTX + 8, "cuda")
-    rows = B * (CTX + 1)
-    kv0 = [(torch.randn(rows, 2 * HKV, D, generator=g) * 0.5).half().cuda() for _ in range(L)]
-    table = torch.arange(rows, dtype=torch.int32).view(B, CTX + 1)
-    ids = torch.randint(0, V, (B, 1), generator=g).cuda()
-    pos = torch.full((B, 1), CTX).cuda()
-
-    def run():
-        kv = [k.clone() for k in kv0]
-        info = types.SimpleNamespace(
-            kv_buffer=kv, cur_select_index=table[:, CTX].contiguous().cuda(), b_req_tokens_table=table.clone().cuda(),
-            b_start_loc=None, b_req_idx=torch.arange(B, dtype=torch.int32, device="cuda"),
-            b_seq_len=torch.full((B,), CTX + 1, dtype=torch.int32, device="cuda"), max_actual_seq_len=CTX + 1)
-        with torch.no_grad():
-            return m(ids, pos, info).clone(), kv
-
-    ref, kv_ref = run()
-    taken = []
-    real_take = PendingNorm.take
-    monkeypatch.setattr(PendingNorm, "take", lambda self: (taken.append(1), real_take(self))[1])
-    monkeypatch.setenv("LL_NORM_IN_GEMM", "1")
-    got, kv_got = run()
-    assert len(taken) == 3, taken
-    assert torch.equal(got, ref)
-    for a, b in zip(kv_got, kv_ref):
-        assert torch.equal(a, b)

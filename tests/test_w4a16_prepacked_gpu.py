@@ -244,91 +244,6 @@ def test_decode_attention_over_qkv_partials(ctx, dtype_bias):
     close(got, want, 4e-3)
 
 
-@pytest.mark.parametrize("m,n,k,s,form,served", [
-    (64, 4608, 3584, 9, "partials", True),    # down's partials -> input norm -> q|k|v (headline shape)
-    (64, 37888, 3584, 5, "swiglu", True),     # o's partials -> post-attention norm -> gate|up + swiglu (headline shape)
-    (64, 4608, 3584, 12, "plain", True),
-    (17, 4608, 3584, 5, "plain", True),       # one batch half, fewer rows than workgroups with a row
-    (1, 4096, 4096, 3, "plain", True),
-    (64, 1024, 2048, 6, "plain", None),
-    (40, 512, 1024, 2, "partials", None),     # few tiles: served only if the launch has >= m workgroups
-])
-def test_prepacked_with_in_launch_norm_equals_two_launches(m, n, k, s, form, served, monkeypatch):
-    """ll_w4a16_matmul_prepacked_normed: the add-and-normalise over split-K partials produced INSIDE the projection's launch
-    (one row per workgroup, activation loaders gated on a launch-wide counter) -- normalised rows, residual and projection
-    output bit-identical to ll_skip_rmsnorm_partials followed by ll_w4a16_matmul_prepacked; repeated launches (the gate's
-    words return to zero), eager and captured."""
-    from lite_llama_amd import _lib as L
-    from lite_llama_amd.kernels.norm_act import PartialSums, PendingNorm, skip_rmsnorm_partials
-    from lite_llama_amd.quantization.params import quantize_int4_groupwise
-
-    monkeypatch.setenv("LL_NORM_IN_GEMM", "1")  # opt-in route
-    g = torch.Generator().manual_seed(m * 7 + n + s)
-    w = torch.randn(n, k, generator=g) * 0.05
-    qw, sc, zr = quantize_int4_groupwise(w, 128)
-    pw, ps = Q().pack_w4a16_weights(qw.to(DEV)), Q().pack_w4a16_scales(sc.to(DEV), zr.to(DEV))
-    parts = (torch.randn(s, m, k, generator=g) * 0.3).to(DEV)
-    res0 = (torch.randn(m, k, generator=g)).half().to(DEV)
-    nw = (1.0 + 0.1 * torch.randn(k, generator=g)).half().to(DEV)
-    epi = {"plain": 0, "swiglu": 1, "partials": 2}[form]
-    ok = bool(L.lib().ll_w4a16_prepacked_normed_supported(m, n, k, 128, epi, s))
-    if served is not None:
-        assert ok == served
-
-    def project(x, pending):
-        if form == "partials":
-            return Q().w4a16_matmul_partials(x, pw, ps, group_size=128, pending=pending).parts
-        return Q().w4a16_matmul_prepacked(x, pw, ps, group_size=128, gate_up_swiglu=form == "swiglu", pending=pending)
-
-    # two launches
-    r_ref = res0.clone()
-    y_ref, _ = skip_rmsnorm_partials(PartialSums(parts, (m, k), torch.float16), r_ref, nw, 1e-6)
-    out_ref = project(y_ref, None)
-
-    def fused():
-        r = res0.clone()
-        pend, _ = skip_rmsnorm_partials(PartialSums(parts, (m, k), torch.float16), r, nw, 1e-6, defer=True)
-        assert isinstance(pend, PendingNorm) and not pend.done
-        out = project(pend.out, pend)
-        assert pend.done
-        return pend.out, r, out
-
-    for _ in range(3):
-        y, r, out = fused()
-        assert torch.equal(y, y_ref) and torch.equal(r, r_ref)
-        assert torch.equal(out, out_ref)
-    torch.cuda.synchronize()
-    assert L.gemm_scratch_error(torch.device(DEV)) == 0  # every word of the counter buffer is back to zero
-    if ok:
-        # captured: the same launch replayed (the gate re-arms itself)
-        r_buf = res0.clone()
-        st = torch.cuda.Stream()
-        st.wait_stream(torch.cuda.current_stream())
-        with torch.cuda.stream(st):
-            pend, _ = skip_rmsnorm_partials(PartialSums(parts, (m, k), torch.float16), r_buf, nw, 1e-6, defer=True)
-            project(pend.out, pend)  # warm-up outside the capture
-        torch.cuda.current_stream().wait_stream(st)
-        graph = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(graph):
-            pend, _ = skip_rmsnorm_partials(PartialSums(parts, (m, k), torch.float16), r_buf, nw, 1e-6, defer=True)
-            out_g = project(pend.out, pend)
-        for it in range(4):
-            r_buf.copy_(res0)
-            if it % 2:  # other inputs through the same addresses: a stale activation row in some L2 would show
-                parts.neg_()
-                r_alt = res0.clone()
-                y_alt, _ = skip_rmsnorm_partials(PartialSums(parts, (m, k), torch.float16), r_alt, nw, 1e-6)
-                out_alt = project(y_alt, None)
-            graph.replay()
-            if it % 2:
-                assert torch.equal(pend.out, y_alt) and torch.equal(r_buf, r_alt) and torch.equal(out_g, out_alt)
-                parts.neg_()
-            else:
-                assert torch.equal(pend.out, y_ref) and torch.equal(r_buf, r_ref) and torch.equal(out_g, out_ref)
-        torch.cuda.synchronize()
-        assert L.gemm_scratch_error(torch.device(DEV)) == 0
-
-
 def test_sticky_merge_error_word_is_seen_from_an_indexless_device_and_only_on_this_streams_sets():
     """``gemm_scratch_error(torch.device("cuda"))`` -- what ``DecodeEngine`` passes by default -- matched no
     scratch set (its index is None, the sets are keyed by the tensors' device index), so a poisoned merge could never raise.
