@@ -197,6 +197,10 @@ int ll_w4a16_pack_scales(void* packed, const float* scales, const float* zeros, 
  * n % 256 == 0).  Same arithmetic as ll_w4a16_matmul (only the fp32 summation order differs). */
 int ll_w4a16_pack_weights(void* packed, const int32_t* qweight, int64_t n, int64_t k, int64_t qw_stride_n,
                           void* stream);
+/* The inverse (bit-exact): packed -> qweight [N, K/8] in the reference layout (models/quantization/params/int4.py:33-49), so
+ * that the load-time layout can be the only resident copy of the weights. */
+int ll_w4a16_unpack_weights(int32_t* qweight, const void* packed, int64_t n, int64_t k, int64_t qw_stride_n,
+                            void* stream);
 int ll_w4a16_prepacked_supported(int64_t m, int64_t n, int64_t k, int group_size); /* 1 / 0 */
 /* epilogue 2 of ll_w4a16_matmul_prepacked = split-K partial mode (decode-step fusion, no reference counterpart):
  * `out` is an fp32 [S][M][N] buffer, S = ll_w4a16_partials_count(...) (0 = shape not served: use epilogue 0);

@@ -41,6 +41,7 @@ SIGNATURES = {
     "ll_w4a16_matmul": [P, P, P, P, P, P, L, L, L, I, L, L, L, P, P, P],
     "ll_w4a16_pack_scales": [P, P, P, L, L, L, P],
     "ll_w4a16_pack_weights": [P, P, L, L, L, P],
+    "ll_w4a16_unpack_weights": [P, P, L, L, L, P],
     "ll_w4a16_prepacked_supported": [L, L, L, I],
     "ll_w4a16_partials_count": [L, L, L, I],
     "ll_skip_rmsnorm_partials": [P, P, I, P, P, L, L, F, I, P],

@@ -1009,6 +1009,46 @@ extern "C" int ll_w4a16_pack_weights(void* packed, const int32_t* qweight, int64
   return LL_LAUNCH_CHECK();
 }
 
+// The inverse permutation (bit-exact): packed -> qweight [N, K/8] in the reference layout.  With it the load-time layout can be
+// the ONLY resident copy of the int4 weights (lite_llama_amd/quantization/methods.py::compact): the reference-format tensor
+// is rebuilt on demand for the calls the decode engine does not serve (more than 64 rows) and for checkpoint export.
+__device__ __forceinline__ uint32_t v3_nib_unperm(uint32_t p) {
+  uint32_t ev = p & 0xFFFFu, od = p >> 16;
+  ev = (ev | (ev << 8)) & 0x00FF00FFu;
+  ev = (ev | (ev << 4)) & 0x0F0F0F0Fu;
+  od = (od | (od << 8)) & 0x00FF00FFu;
+  od = (od | (od << 4)) & 0x0F0F0F0Fu;
+  return ev | (od << 4);
+}
+
+__global__ void w4a16_unpack_weights_kernel(uint32_t* qw, const u32x4* src, int64_t total, int chunks, int64_t qw_stride) {
+  const int64_t i = (int64_t)blockIdx.x * blockDim.x + threadIdx.x;
+  if (i >= total) return;
+  const int lane = (int)(i & 63), w = (int)((i >> 6) & 7);
+  const int64_t blk = i >> 9;
+  const int64_t t = blk / chunks;
+  const int c = (int)(blk - t * chunks);
+  const int64_t row = t * V3_BN + (w & 3) * 32 + (lane & 31);
+  const int word0 = c * 16 + (w >> 2) * 8 + (lane >> 5) * 4;
+  const u32x4 s = src[i];
+  u32x4 o;
+  o.x = v3_nib_unperm(s.x);
+  o.y = v3_nib_unperm(s.y);
+  o.z = v3_nib_unperm(s.z);
+  o.w = v3_nib_unperm(s.w);
+  *reinterpret_cast<u32x4*>(qw + row * qw_stride + word0) = o;
+}
+
+extern "C" int ll_w4a16_unpack_weights(int32_t* qweight, const void* packed, int64_t n, int64_t k, int64_t qw_stride_n,
+                                       void* stream) {
+  if (n <= 0 || k <= 0 || n % V3_BN != 0 || k % V3_CK != 0 || qw_stride_n % 4 != 0) return LL_ERR_SHAPE;
+  if (!packed || !qweight || !ll_aligned16(packed) || !ll_aligned16(qweight)) return LL_ERR_ARG;
+  const int64_t total = n * k / 32;  // 16-byte pieces
+  w4a16_unpack_weights_kernel<<<dim3((unsigned)((total + 255) / 256)), 256, 0, (hipStream_t)stream>>>(
+      (uint32_t*)qweight, (const u32x4*)packed, total, (int)(k / V3_CK), qw_stride_n);
+  return LL_LAUNCH_CHECK();
+}
+
 // ---------------------------------------------------------------------------------- //
 // host side
 // ---------------------------------------------------------------------------------- //

@@ -131,6 +131,18 @@ def pack_w4a16_weights(qweight: torch.Tensor) -> torch.Tensor:
     return packed
 
 
+def unpack_w4a16_weights(packed: torch.Tensor) -> torch.Tensor:
+    """Inverse of :func:`pack_w4a16_weights` (bit-exact): the int32 ``[N, K/8]`` reference-format tensor."""
+    L.require_cuda(packed)
+    if packed.dtype != torch.int32 or packed.dim() != 5 or tuple(packed.shape[2:]) != (8, 64, 4) or not packed.is_contiguous():
+        raise ValueError("packed must be the int32 [N/128, K/128, 8, 64, 4] tensor made by pack_w4a16_weights")
+    n, k = packed.shape[0] * 128, packed.shape[1] * 128
+    qweight = torch.empty((n, k // 8), dtype=torch.int32, device=packed.device)
+    L.check(L.lib().ll_w4a16_unpack_weights(qweight.data_ptr(), packed.data_ptr(), n, k, qweight.stride(0), L.stream_ptr()),
+            "unpack_w4a16_weights")
+    return qweight
+
+
 def w4a16_prepacked_supported(m: int, n: int, k: int, group_size: int) -> bool:
     return bool(L.lib().ll_w4a16_prepacked_supported(m, n, k, int(group_size)))
 

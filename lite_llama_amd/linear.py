@@ -192,6 +192,52 @@ class MergedColumnLinear:
         self._key = self._snapshot()
         return ok
 
+    def _repoint_members(self, name: str) -> None:
+        """Members' parameters are views of the holder's merged tensor: rebuild them after the tensor was replaced."""
+        h = self._holder
+        cat = getattr(h, name)
+        off = 0
+        for i, l in enumerate(self.layers):
+            rows = l._parameters[name].shape[0]
+            view = cat[i::2] if h.interleaved else cat[off:off + rows]
+            l._parameters[name] = nn.Parameter(view, requires_grad=False)
+            off += rows
+
+    def compact(self) -> int:
+        """One resident copy of the merged int4 weights (quantization/methods.py::W4A16LinearMethod.compact): the holder's
+        ``weight`` aliases the load-time layout; the members' ``weight`` parameters keep their shapes (views of the same
+        storage -- permuted words, not reference rows) and rebuild their reference rows on demand.  Bytes released."""
+        h = self._holder
+        if h is None or not hasattr(h.quant_method, "compact") or not self.refresh():
+            return 0
+        freed = h.quant_method.compact(h)
+        if freed:
+            off = 0
+            rows_of = []
+            for i, l in enumerate(self.layers):
+                rows = l._parameters["weight"].shape[0]
+                rows_of.append(slice(i, None, 2) if h.interleaved else slice(off, off + rows))
+                off += rows
+            self._repoint_members("weight")
+            for l, rows in zip(self.layers, rows_of):
+                l._w4_compact_member = (h, rows)
+                for attr in ("_w4_prepacked",):
+                    if hasattr(l, attr):
+                        delattr(l, attr)
+            self._key = self._snapshot()
+        return freed
+
+    def expand(self) -> None:
+        h = self._holder
+        if h is None or not getattr(h, "_w4_compact", False):
+            return
+        h.quant_method.expand(h)
+        self._repoint_members("weight")
+        for l in self.layers:
+            if hasattr(l, "_w4_compact_member"):
+                delattr(l, "_w4_compact_member")
+        self._key = self._snapshot()
+
     def invalidate(self) -> None:
         """A checkpoint was copied THROUGH the members' parameters (views of the merged storage: the storage itself is up
         to date, no version counter moved): drop the layouts derived from it."""

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..kernels import fused_moe, smoothquant_matmul, w4a16_matmul, w8a16_matmul
-from ..kernels.quantization import (dense16_linear, pack_w4a16_scales, pack_w4a16_weights, w4a16_matmul_partials,
+from ..kernels.quantization import (dense16_linear, pack_w4a16_scales, pack_w4a16_weights, unpack_w4a16_weights, w4a16_matmul_partials,
                                     w4a16_matmul_prepacked, w4a16_prepacked_supported)
 from .config import FP8, INT4, INT8, SMOOTHQUANT, QuantConfig
 from .params import (
@@ -85,8 +85,63 @@ class W4A16LinearMethod(LinearQuantMethod):
         pre = self._prepacked(layer, x)
         if pre is not None:
             return w4a16_matmul_prepacked(x, pre, self._packed(layer), group_size=layer.quant.group_k, bias=layer.bias)
-        return w4a16_matmul(x, layer.weight, layer.weight_scale, layer.weight_zeros,
+        return w4a16_matmul(x, self.reference_weight(layer), layer.weight_scale, layer.weight_zeros,
                             group_size=layer.quant.group_k, bias=layer.bias)
+
+    # ---- one resident copy of the int4 weights (round 4) ------------------------------------------------------------
+    @staticmethod
+    def _as_packed(t):
+        n, kp = t.shape
+        return t.view(n // 128, kp // 16, 8, 64, 4)
+
+    def reference_weight(self, layer):
+        """``qweight [N, K/8]`` in the reference layout: the parameter itself -- or, for a compacted layer, a transient
+        tensor rebuilt from the load-time layout (bit-exact inverse permutation, ``ll_w4a16_unpack_weights``)."""
+        member = getattr(layer, "_w4_compact_member", None)
+        if member is not None:  # a member of a compacted merged storage: its rows of the merged reference tensor
+            holder, rows = member
+            return self.reference_weight(holder)[rows].contiguous()
+        if getattr(layer, "_w4_compact", False):
+            return unpack_w4a16_weights(self._as_packed(layer.weight.data))
+        return layer.weight
+
+    def compact(self, layer) -> int:
+        """Make the decode engine's load-time layout the ONLY resident copy of the layer's int4 weights: ``layer.weight``
+        keeps its shape and dtype but now ALIASES the packed storage (a permutation of the same words; graphs captured over
+        the packed tensor stay valid), the reference-format tensor is freed and rebuilt on demand (:meth:`reference_weight`)
+        for calls of more than 64 rows and for export.  Returns the bytes released (0: not served / already compact).
+        ``state_dict()`` of a compacted model holds permuted words: call ``expand`` (or ``model.expand_weights()``) before
+        saving or loading a checkpoint."""
+        if getattr(layer, "_w4_compact", False) or getattr(layer, "_w4_compact_member", None) is not None:
+            return 0
+        w = layer.weight
+        n, kp = w.shape
+        if (not w.is_cuda or os.environ.get("LL_W4_NO_PREPACK") or torch.cuda.is_current_stream_capturing()
+                or not w4a16_prepacked_supported(1, n, kp * 8, layer.quant.group_k) or self._packed(layer) is None):
+            return 0
+        cached = getattr(layer, "_w4_prepacked", None)
+        pre = cached[1] if cached is not None and cached[0] == (w.data_ptr(), w._version) else pack_w4a16_weights(w.data)
+        flat = pre.view(n, kp)
+        if isinstance(w, nn.Parameter):
+            w.data = flat
+        else:
+            layer.weight = flat
+        layer._w4_compact = True
+        layer._w4_prepacked = ((layer.weight.data_ptr(), layer.weight._version), pre)
+        return n * kp * 4
+
+    def expand(self, layer) -> None:
+        """Undo :meth:`compact`: ``layer.weight`` is the reference-format tensor again (a fresh allocation)."""
+        if not getattr(layer, "_w4_compact", False):
+            return
+        ref = unpack_w4a16_weights(self._as_packed(layer.weight.data))
+        if isinstance(layer.weight, nn.Parameter):
+            layer.weight.data = ref
+        else:
+            layer.weight = ref
+        layer._w4_compact = False
+        if hasattr(layer, "_w4_prepacked"):
+            delattr(layer, "_w4_prepacked")
 
     def apply_partials(self, layer, x, allow_bias: bool = False):
         """Decode-shaped projection left as fp32 split-K partials for ``skip_rmsnorm_partials`` /
@@ -133,10 +188,14 @@ class W4A16LinearMethod(LinearQuantMethod):
         the checkpoint-facing tensor and serves every other shape).  ``None`` -> reference-format path."""
         n, kp = layer.weight.shape
         m = x.numel() // x.shape[-1] if x.shape[-1] else 0
-        if m < 1 or m > 64 or not layer.weight.is_cuda or os.environ.get("LL_W4_NO_PREPACK"):
+        if getattr(layer, "_w4_compact_member", None) is not None:
+            return None  # (a member of a compacted merged storage called on its own: reference route over rebuilt rows)
+        if m < 1 or m > 64 or not layer.weight.is_cuda or (os.environ.get("LL_W4_NO_PREPACK") and not getattr(layer, "_w4_compact", False)):
             return None
         if not w4a16_prepacked_supported(m, n, kp * 8, layer.quant.group_k):
             return None
+        if getattr(layer, "_w4_compact", False):  # the parameter IS the load-time layout
+            return self._as_packed(layer.weight.data) if self._packed(layer) is not None else None
         key = (layer.weight.data_ptr(), layer.weight._version)
         cached = getattr(layer, "_w4_prepacked", None)
         if cached is not None and cached[0] == key:

@@ -319,6 +319,8 @@ def load_weights(model: nn.Module, weights: Iterable[tuple[str, torch.Tensor]], 
     omits the target (``tie_word_embeddings``); ``shard`` narrows incoming tensors to this rank's slice.  ``int4``
     (extension) turns ``qweight / qzeros / scales / g_idx`` keys into native W4A16 parameters; without it such keys
     are unknown parameters, as in the reference."""
+    if hasattr(model, "expand_weights"):
+        model.expand_weights()  # a compacted model's parameters alias the decode engine's layout: reference format first
     params = dict(model.named_parameters())
     filled = dict.fromkeys(params, 0)
     assembler = _Int4Assembler(model, int4) if int4 is not None else None

@@ -274,3 +274,86 @@ def test_sticky_merge_error_word_is_seen_from_an_indexless_device_and_only_on_th
         word.zero_()
     torch.cuda.synchronize()
     assert L.gemm_scratch_error(torch.device("cuda")) is False
+
+
+def test_unpack_is_the_exact_inverse_of_pack():
+    """``ll_w4a16_unpack_weights`` (round 4: the load-time layout as the ONLY resident copy of the weights) restores the
+    reference-format words bit for bit -- every shape class of the packer, incl. a strided source."""
+    g = torch.Generator().manual_seed(3)
+    for n, k in [(128, 128), (256, 384), (4608, 3584), (3584, 18944)]:
+        qw = torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64, generator=g).to(torch.int32).to(DEV)
+        back = Q().unpack_w4a16_weights(Q().pack_w4a16_weights(qw))
+        assert back.shape == qw.shape and torch.equal(back, qw)
+    with pytest.raises(ValueError):
+        Q().unpack_w4a16_weights(qw)   # not a packed tensor
+
+
+def test_compacted_model_keeps_one_copy_of_the_int4_weights_and_the_same_numbers():
+    """``CausalLM.compact_weights()``: the parameters alias the decode engine's layout, the
+    reference-format tensors are released and rebuilt on demand.  A small int4 model: prefill logits (80 rows: the generic
+    engine over a rebuilt reference tensor) and greedy decode tokens (eager and captured: the pre-packed engine over the
+    aliased storage) are BIT-equal before and after; the resident weight bytes shrink by the int4 payload; ``expand_weights``
+    restores every parameter bit for bit; graphs captured BEFORE the compaction keep replaying (the packed storage did not
+    move)."""
+    import types
+
+    from lite_llama_amd.executor import DecodeEngine
+    from lite_llama_amd.model import CausalLM, tiny_geometry
+    from lite_llama_amd.quantization import QuantConfig
+
+    geo = tiny_geometry(hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, num_kv_heads=2, head_dim=64,
+                        vocab_size=1024, qkv_bias=True)
+    torch.manual_seed(21)
+    model = CausalLM(geo)
+    sd = {k: (torch.randn_like(v.float()) * (0.05 if v.dim() > 1 else 0.02) + (1.0 if "norm" in k else 0.0)).to(v.dtype)
+          for k, v in model.state_dict().items()}
+    model.load_state_dict(sd, strict=True)
+    model = model.to(DEV)
+    model.quantize_(QuantConfig.int4_groupwise(128))
+    ids = torch.randint(0, 1024, (2, 40), device=DEV)
+    lens = torch.tensor([40, 37], dtype=torch.int32, device=DEV)
+
+    def run(use_graph):
+        eng = DecodeEngine(model, max_batch=2, max_seq_len=128, device=DEV)
+        first = eng.prefill(ids, lens)
+        toks = eng.decode(first, 6, use_graph=use_graph)
+        torch.cuda.synchronize()
+        return first.clone(), toks.clone(), eng
+
+    def prefill_logits():
+        B, LP = 2, 40
+        sel = torch.arange(B * LP, dtype=torch.int32, device=DEV)
+        table = torch.zeros(B, 64, dtype=torch.int32, device=DEV)
+        for i, n in enumerate([40, 37]):
+            table[i, :n] = sel[i * LP: i * LP + n]
+        info = types.SimpleNamespace(kv_buffer=[torch.zeros(128, 4, 64, dtype=torch.float16, device=DEV) for _ in range(2)],
+                                     cur_select_index=sel, b_req_tokens_table=table,
+                                     b_start_loc=torch.arange(B, dtype=torch.int32, device=DEV) * LP,
+                                     b_req_idx=torch.arange(B, dtype=torch.int32, device=DEV), b_seq_len=lens,
+                                     max_actual_seq_len=LP)
+        with torch.no_grad():
+            out = model(ids, torch.arange(LP, device=DEV).unsqueeze(0).expand(B, LP), info)
+        return torch.cat([out[0, :40], out[1, :37]]).clone()   # (pad positions are uninitialised, as in the reference)
+
+    ref_params = {k: v.detach().clone() for k, v in model.named_parameters()}
+    logits0 = prefill_logits()
+    first0, toks0, eng_before = run(True)
+    bytes0 = model.weight_bytes()
+    int4_bytes = sum(p.numel() * 4 for n, p in model.named_parameters() if p.dtype == torch.int32)
+    freed = model.compact_weights()
+    assert freed == int4_bytes and model.compact_weights() == 0          # every int4 parameter, once
+    bytes1 = model.weight_bytes()
+    assert bytes0 - bytes1 == int4_bytes, (bytes0, bytes1, int4_bytes)   # one copy of the payload is gone
+    for k, v in model.named_parameters():
+        assert v.shape == ref_params[k].shape and v.dtype == ref_params[k].dtype
+    assert torch.equal(prefill_logits(), logits0)                        # > 64 rows: rebuilt reference tensor, generic engine
+    for use_graph in (False, True):
+        first1, toks1, _ = run(use_graph)
+        assert torch.equal(first1, first0) and torch.equal(toks1, toks0)
+    again = eng_before.decode(eng_before.prefill(ids, lens), 6, use_graph=True)   # the engine whose graph was captured BEFORE
+    assert torch.equal(again, toks0)
+    model.expand_weights()
+    for k, v in model.named_parameters():
+        assert torch.equal(v, ref_params[k]), k
+    first2, toks2, _ = run(True)
+    assert torch.equal(first2, first0) and torch.equal(toks2, toks0)
