@@ -42,8 +42,10 @@ PEAK_HBM = 8.0e12  # B/s, MI355X HBM3E peak (MI355X_MICROARCH.md)
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=64)
-    ap.add_argument("--warmup", type=int, default=8)
+    # defaults = the reference's protocol (benchmarks/common.py:101-137): 128 generated tokens after a 512-token
+    # prompt, two 8-token warm-ups
+    ap.add_argument("--steps", type=int, default=128)
+    ap.add_argument("--warmup", type=int, default=16)
     ap.add_argument("--model", default="qwen2.5-7b")
     ap.add_argument("--batch", type=int, default=64)
     ap.add_argument("--ctx", type=int, default=512, help="context tokens per sequence when decoding starts")
@@ -63,6 +65,10 @@ def parse():
                     help="also time the DROP-IN route: the reference's own 12-launch decoder layer through the 16 kernel names only "
                          "(what integration.install() gives a reference caller), as a second labelled value")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-secondary", action="store_true",
+                    help="skip the second measured point (SURVEY 8d: prompt 2048) that the N = 1 line carries as \"secondary\"")
+    ap.add_argument("--keep-reference-weights", action="store_true",
+                    help="keep the reference-format int4 tensors next to the decode engine's layout (2 x the int4 payload)")
     ap.add_argument("--cpu-layers", type=int, default=1, help="decoder layers in the CPU oracle sample")
     return ap.parse_args()
 
@@ -152,14 +158,16 @@ def gemm_roofline(model, batch, quant, iters=6):
     avg_s = e0.elapsed_time(e1) * 1e-3 / (iters * nl)
     bytes_per_launch = nbytes / nl
     achieved = bytes_per_launch / avg_s
-    traffic, traffic_source = None, None
+    traffic, traffic_source, traffic_parts = None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
     if quant == "int4" and solo and os.path.exists(tpath):  # the stored counters are those of the int4 engine at TP = 1 only
         try:
             tj = json.load(open(tpath))
             traffic = tj.get("wgemm_bytes_per_launch")
+            traffic_parts = {"fetch": tj.get("wgemm_fetch_bytes_per_launch"), "write": tj.get("wgemm_write_bytes_per_launch")}
             traffic_source = ("stored profile value, not a live counter: " + tj.get("summary", "profiles/pmc_traffic.json")
-                              + " (separate rocprofv3 --pmc FETCH_SIZE pass, x2 gfx950 correction)")
+                              + " (separate rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE passes; FETCH x2 per the gfx950 correction, "
+                                "WRITE_SIZE uncalibrated)")
         except Exception:
             traffic = None
     kernel = {
@@ -175,7 +183,7 @@ def gemm_roofline(model, batch, quant, iters=6):
         "covers": "the dense linear projections (attention q|k|v / o" + ("" if getattr(model.geo, "num_experts", 0) else ", gate|up, down")
                   + "); one launch = one projection incl. its activation quantiser / finish kernels where the format has them",
         "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
-        "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic, "traffic_source": traffic_source,
+        "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic, "traffic_parts": traffic_parts, "traffic_source": traffic_source,
         "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
         "launches_timed": launches, "timed_as": how,
     }
@@ -258,6 +266,34 @@ def reference_order_step(model, engine, batch, ctx, steps, warmup):
             "launches_per_layer": 13,
             "what": "the reference's decoder layer through the 16 exported kernel names only, reference-format parameters, "
                     "hipGraph replay, fixed context (drop-in route 1 of INTEGRATION.md)"}
+
+
+def second_point(model, args, dev, act_dtype, geo, tp, ctx=2048):
+    """The second measured point of SURVEY 8(d): decode after a 2048-token prompt (the reference's graph bucket <= 4096,
+    executor/cuda_graph.py:27-28) -- 17 partitions per row: the attention's global-merge path, the fused q|k|v finished by
+    the projection itself.  Same model, a fresh engine, hipGraph replays."""
+    from lite_llama_amd.executor import DecodeEngine
+
+    steps, warmup = min(args.steps, 32), 4
+    eng = DecodeEngine(model, max_batch=args.batch, max_seq_len=ctx + steps + warmup + 8, device=dev, kv_dtype=act_dtype)
+    first = eng.synthetic_context(args.batch, ctx, seed=11)
+    marks = {}
+
+    def on_step(i):
+        if i == warmup:
+            torch.cuda.synchronize()
+            marks["t0"] = time.perf_counter()
+
+    eng.decode(first, warmup + steps, use_graph=not args.no_graph, on_step=on_step)
+    torch.cuda.synchronize()
+    dt = (time.perf_counter() - marks["t0"]) / steps
+    w_lin, w_head, kv_bytes = algorithmic_bytes(geo, args.quant, args.batch, ctx + warmup + steps / 2, tp)
+    out = {"workload": f"{args.model} {args.quant} decode, batch {args.batch}, ctx {ctx}->{ctx + warmup + steps}",
+           "value": round(args.batch / dt, 1), "unit": "tokens/s", "ms_per_step": round(dt * 1e3, 4), "steps": steps, "warmup": warmup,
+           "step_roofline_frac_of_8TBps": round((w_lin + w_head + kv_bytes) / dt / PEAK_HBM, 4)}
+    del eng
+    torch.cuda.empty_cache()
+    return out
 
 
 def moe_roofline(model, batch, iters=6):
@@ -604,6 +640,9 @@ def main():
             raise SystemExit("--dtype bf16 needs --quant none (the quantised GEMMs follow the reference: fp16 activations only)")
         model = model.to(torch.bfloat16)
         act_dtype = torch.bfloat16
+    released = 0
+    if quant is not None and not args.keep_reference_weights:
+        released = model.compact_weights()  # int4: the load-time layout becomes the only resident copy of the weights
     torch.cuda.synchronize()
     t_build = time.perf_counter() - t_build
 
@@ -696,7 +735,22 @@ def main():
                           "achieved_GBps_per_gpu": round(step_bytes / (elapsed / args.steps) / 1e9, 1),
                           "frac_of_8TBps": round(step_bytes / (elapsed / args.steps) / PEAK_HBM, 4)},
     }
+    w_lin_alg, w_head_alg, _ = algorithmic_bytes(geo, args.quant, args.batch, 0, tp)
+    result["memory"] = {
+        "weights_resident_bytes": int(model.weight_bytes()),   # every distinct parameter / load-time-layout storage of this rank
+        "weights_algorithmic_bytes": int(w_lin_alg + w_head_alg),  # linear weights in reference format + fp16 lm_head
+        "reference_layout_released_bytes": int(released),
+        "kv_pool_bytes": int(sum(t.numel() * t.element_size() for t in engine.info.kv_buffer)),
+        "allocated_after_warmup_bytes": int(torch.cuda.memory_allocated()),
+        "note": "resident = embedding + norms + biases + the int4 load-time layout (0.5 B / weight) + the fp32 scale / zero grids "
+                "and their fp16 pair layout (2 x 0.0625 B / weight) + fp16 lm_head",
+    }
     if rank == 0:
+        if world == 1 and not args.no_secondary and not args.scattered and not args.kv_block_size and args.ctx != 2048:
+            try:  # "report a second point at prompt_len = 2048" -- same model, its own engine, fewer steps
+                result["secondary"] = [second_point(model, args, dev, act_dtype, geo, tp)]
+            except Exception as exc:
+                result["secondary"] = [{"error": f"{type(exc).__name__}: {exc}"}]
         rf = gemm_roofline(model, args.batch, args.quant)
         if geo.num_experts and quant is not None:
             try:  # the dominant kernel of a MoE model is the grouped expert GEMM; the dense projections stay as a second object

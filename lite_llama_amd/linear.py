@@ -145,6 +145,9 @@ class MergedColumnLinear:
         first = self.layers[0]
         if not first.weight.is_cuda or torch.cuda.is_current_stream_capturing():
             return False
+        for l in self.layers:  # a member compacted on its own holds permuted words: merge reference-format rows only
+            if getattr(l, "_w4_compact", False):
+                l.quant_method.expand(l)
         self._holder = None
         ok = all(type(l.quant_method) is type(first.quant_method) and l.quant == first.quant
                  and l.input_size == first.input_size for l in self.layers)
@@ -207,8 +210,10 @@ class MergedColumnLinear:
         """One resident copy of the merged int4 weights (quantization/methods.py::W4A16LinearMethod.compact): the holder's
         ``weight`` aliases the load-time layout; the members' ``weight`` parameters keep their shapes (views of the same
         storage -- permuted words, not reference rows) and rebuild their reference rows on demand.  Bytes released."""
+        if not self.refresh():  # (builds the merged storage if no forward has run yet)
+            return 0
         h = self._holder
-        if h is None or not hasattr(h.quant_method, "compact") or not self.refresh():
+        if h is None or not hasattr(h.quant_method, "compact"):
             return 0
         freed = h.quant_method.compact(h)
         if freed:

@@ -336,8 +336,18 @@ def test_compacted_model_keeps_one_copy_of_the_int4_weights_and_the_same_numbers
         return torch.cat([out[0, :40], out[1, :37]]).clone()   # (pad positions are uninitialised, as in the reference)
 
     ref_params = {k: v.detach().clone() for k, v in model.named_parameters()}
+    # compaction BEFORE any forward (what bench.py does: the merged q|k|v / gate|up storages do not exist yet) ...
+    assert model.compact_weights() == sum(p.numel() * 4 for p in model.parameters() if p.dtype == torch.int32)
+    logits_c = prefill_logits()
+    first_c, toks_c, _ = run(True)
+    model.expand_weights()
+    for k, v in model.named_parameters():
+        assert torch.equal(v, ref_params[k]), k
+    # ... equals the uncompacted model
     logits0 = prefill_logits()
+    assert torch.equal(logits_c, logits0)
     first0, toks0, eng_before = run(True)
+    assert torch.equal(first_c, first0) and torch.equal(toks_c, toks0)
     bytes0 = model.weight_bytes()
     int4_bytes = sum(p.numel() * 4 for n, p in model.named_parameters() if p.dtype == torch.int32)
     freed = model.compact_weights()

@@ -1,0 +1,56 @@
+"""profiles/pmc_traffic.json from the two PMC passes of tools/profile_round.sh (FETCH_SIZE and WRITE_SIZE each in its own
+rocprofv3 --pmc run over the decode step's eager launches): launch-weighted bytes of the dominant GEMM and of the decode
+attention.  FETCH_SIZE (KB) x 1024 x 2 (the gfx950 correction of MI355X_MICROARCH.md, "HBM"); WRITE_SIZE (KB) x 1024,
+uncalibrated.  bench.py prints `roofline.traffic` = fetch + write from this file (a stored profile value, labelled so).
+
+    python tools/pmc_traffic.py FETCH.db WRITE.db TAG      # TAG e.g. r04_v1: names the summaries under profiles/
+"""
+import json, os, sqlite3, sys
+
+
+def per_kernel(path, counter, sub):
+    db = sqlite3.connect(path)
+    cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
+    name_col = "kernel_name" if "kernel_name" in cols else "name"
+    rows = db.execute(f"select {name_col}, count(*), avg(value) from counters_collection where counter_name = ? and {name_col} like ? "
+                      f"group by {name_col}", (counter, f"%{sub}%")).fetchall()
+    return {r[0]: (r[1], r[2]) for r in rows}
+
+
+def weighted(d):
+    n = sum(c for c, _ in d.values())
+    return (sum(c * v for c, v in d.values()) / n, n) if n else (None, 0)
+
+
+def main():
+    fetch_db, write_db, tag = sys.argv[1], sys.argv[2], sys.argv[3]
+    gf, gw = per_kernel(fetch_db, "FETCH_SIZE", "wgemm3"), per_kernel(write_db, "WRITE_SIZE", "wgemm3")
+    af, aw = per_kernel(fetch_db, "FETCH_SIZE", "fd_stage1"), per_kernel(write_db, "WRITE_SIZE", "fd_stage1")
+    f_kb, n_f = weighted(gf)
+    w_kb, _ = weighted(gw)
+    out = {
+        "wgemm_fetch_bytes_per_launch": int(f_kb * 1024 * 2) if f_kb else None,
+        "wgemm_write_bytes_per_launch": int(w_kb * 1024) if w_kb else None,
+        "algorithmic_bytes_per_launch": 32772096,
+        "gfx950_correction": 2.0,
+        "per_kernel_KB": {"FETCH_SIZE": {k[:60]: [c, round(v, 1)] for k, (c, v) in gf.items()},
+                          "WRITE_SIZE": {k[:60]: [c, round(v, 1)] for k, (c, v) in gw.items()}},
+        "launches": f"{n_f} eager launches of the decode step's own GEMM forms (fused q|k|v partials, o partials, fused gate|up + "
+                    "swiglu, down partials; M = 64)",
+        "command": "rocprofv3 --kernel-trace --pmc FETCH_SIZE -- python bench.py --no-graph --no-cpu-baseline --no-secondary "
+                   "--steps 3 --warmup 1 (WRITE_SIZE in its own pass)",
+        "summary": f"profiles/{tag.split('_')[0]}_pmc_FETCH_SIZE_gemm_{tag.split('_')[1]}.txt, "
+                   f"profiles/{tag.split('_')[0]}_pmc_WRITE_SIZE_gemm_{tag.split('_')[1]}.txt",
+    }
+    out["wgemm_bytes_per_launch"] = (out["wgemm_fetch_bytes_per_launch"] or 0) + (out["wgemm_write_bytes_per_launch"] or 0)
+    a_f, _ = weighted(af)
+    a_w, _ = weighted(aw)
+    if a_f:
+        out["attention_fetch_bytes_per_launch"] = int(a_f * 1024 * 2)
+        out["attention_write_bytes_per_launch"] = int(a_w * 1024) if a_w else None
+    json.dump(out, open(os.path.join(os.path.dirname(os.path.dirname(os.path.abspath(__file__))), "gpurun_out", "pmc_traffic.json"), "w"), indent=1)
+    print(json.dumps(out, indent=1))
+
+
+if __name__ == "__main__":
+    main()
