@@ -129,12 +129,17 @@ class _OneShot:
         except Exception as exc:
             problem = f"rank {self.rank}: {type(exc).__name__}: {exc}"
         gathered = [None] * self.world
-        dist.all_gather_object(gathered, (self.rank, handles if problem is None else None, problem), group=_TP_GROUP)
+        me = torch.cuda.current_device()
+        ident = (me, str(getattr(torch.cuda.get_device_properties(me), "uuid", "")) or None)
+        dist.all_gather_object(gathered, (self.rank, handles if problem is None else None, problem, ident), group=_TP_GROUP)
+        # which device every rank's staging buffer lives on: (index, uuid) -- distinct entries = the peer mappings cross
+        # devices (xGMI / PCIe peer access), equal entries = ranks sharing one device (the debugging set-up of the tests)
+        self.peer_devices = [g[3] for g in gathered]
         failures = [g[2] for g in gathered if g[2]]
         stage, flags = [None] * self.world, [None] * self.world
         if not failures:
             try:
-                for r, hs, _ in gathered:
+                for r, hs, _, _ in gathered:
                     if r == self.rank:
                         stage[r], flags[r] = self._mine[0].value, self._mine[1].value
                         continue
@@ -157,6 +162,10 @@ class _OneShot:
         self.stage_arr = (ctypes.c_void_p * self.world)(*stage)
         self.flag_arr = (ctypes.c_void_p * self.world)(*flags)
         self.epoch_done = torch.zeros(2, dtype=torch.int32, device=torch.device("cuda", torch.cuda.current_device()))
+
+    def crosses_devices(self) -> bool:
+        """True when no two ranks of the group stage on the same device (the real multi-GPU set-up)."""
+        return len(set(self.peer_devices)) == self.world
 
     def fits(self, t: torch.Tensor) -> bool:
         """Decided from what is IDENTICAL on every rank of the group (dtype, element count) -- never from this rank's

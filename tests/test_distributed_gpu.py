@@ -73,18 +73,19 @@ def _run(which="tp2"):
 def _worker(rank, world, port, q, which="tp2", oneshot=False):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["LL_DIST_BACKEND"] = "gloo"
     os.environ["LL_TP_SPIN_LOG2"] = "28"  # ranks time-slicing ONE GPU: the late rank gets 1 / N of the device while the others spin
     from lite_llama_amd.distributed import parallel_state as ps
+    from tests._dist import assert_real_multi_gpu, place_rank
 
     try:
-        torch.cuda.set_device(0)
+        _, distinct = place_rank(rank, world)  # one device per rank over RCCL when the box has them, else device 0 + gloo
         ps.init_tensor_parallel(rank, world, master_port=port)
         assert ps.get_tp_world_size() == world
         if oneshot:  # the collective of the real multi-GPU run: one-shot kernel over IPC mappings, fused with the norms
             import torch.distributed as dist
             ps.enable_oneshot_all_reduce(2 * 7 * 512)
             dist.barrier()
+        assert_real_multi_gpu(ps, distinct)
         first, toks, logits = _run(which)
         if oneshot:
             assert ps.oneshot_error() == 0

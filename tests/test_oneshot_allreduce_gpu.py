@@ -25,16 +25,17 @@ def _free_port():
 def _worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["LL_DIST_BACKEND"] = "gloo"   # host channel for the handle exchange (RCCL refuses two ranks on one device)
     import torch.distributed as dist
 
     from lite_llama_amd.distributed import parallel_state as ps
 
     try:
-        torch.cuda.set_device(0)
+        from tests._dist import assert_real_multi_gpu, place_rank
+        dev_index, distinct = place_rank(rank, world)  # one device per rank over RCCL when the box has them, else device 0 + gloo
         ps.init_tensor_parallel(rank, world, master_port=port)
         ps.enable_oneshot_all_reduce(64 * 3584, blocks=32)
-        dev = torch.device("cuda", 0)
+        assert_real_multi_gpu(ps, distinct)
+        dev = torch.device("cuda", dev_index)
         report = {}
         for dtype in (torch.float16, torch.bfloat16):
             for it, n in enumerate([64 * 3584, 8, 1000 * 8, 64 * 3584, 33 * 1024 + 8, 64 * 3584]):
@@ -97,16 +98,17 @@ def test_two_ranks_on_one_gpu_exchange_through_ipc():
 def _tp_decode_worker(rank, world, port, q, oneshot, fused=True):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["LL_DIST_BACKEND"] = "gloo"
     if not fused:
         os.environ["LL_TP_NO_FUSED_NORM"] = "1"   # GEMM -> one-shot all-reduce -> norm as three launches
     from lite_llama_amd.distributed import parallel_state as ps
 
     try:
-        torch.cuda.set_device(0)
+        from tests._dist import assert_real_multi_gpu, place_rank
+        dev_index, distinct = place_rank(rank, world)  # one device per rank over RCCL when the box has them, else device 0 + gloo
         ps.init_tensor_parallel(rank, world, master_port=port)
         if oneshot:
             ps.enable_oneshot_all_reduce(2 * 7 * 512)
+        assert_real_multi_gpu(ps, distinct)
         import torch.distributed as dist
 
         from tests.test_distributed_gpu import _run
@@ -156,7 +158,6 @@ def test_tp2_decode_over_the_oneshot_kernel_matches_the_backend_collective():
 def _fused_worker(rank, world, port, q):
     os.environ["MASTER_ADDR"] = "127.0.0.1"
     os.environ["MASTER_PORT"] = str(port)
-    os.environ["LL_DIST_BACKEND"] = "gloo"
     import torch.distributed as dist
 
     from lite_llama_amd.distributed import parallel_state as ps
@@ -164,10 +165,12 @@ def _fused_worker(rank, world, port, q):
     from lite_llama_amd.kernels.norm_act import PartialSums, skip_rmsnorm_partials
 
     try:
-        torch.cuda.set_device(0)
+        from tests._dist import assert_real_multi_gpu, place_rank
+        dev_index, distinct = place_rank(rank, world)  # one device per rank over RCCL when the box has them, else device 0 + gloo
         ps.init_tensor_parallel(rank, world, master_port=port)
         ps.enable_oneshot_all_reduce(64 * 3584)
-        dev = torch.device("cuda", 0)
+        assert_real_multi_gpu(ps, distinct)
+        dev = torch.device("cuda", dev_index)
         report = {}
         for case, (rows, n, s, dtype) in enumerate([(64, 3584, 5, torch.float16), (64, 3584, 9, torch.float16), (7, 512, 1, torch.float16),
                                                      (33, 2048, 12, torch.bfloat16), (64, 3584, 6, torch.float16)]):
