@@ -82,14 +82,34 @@ class RowParallelLinear(LinearBase):
                 from .distributed.parallel_state import fused_reduce_norm_available
                 rows = x.numel() // x.shape[-1] if x.shape[-1] else 0
                 if fused_reduce_norm_available(rows, self.output_size, x.dtype) and not os.environ.get("LL_TP_NO_FUSED_NORM"):
-                    if self._tp_partials_ok(rows):
+                    if self._tp_fused_agreed(rows):
                         out = self.quant_method.apply_partials(self, x)
-                        if out is None:  # the peers took the fused launch: a different collective here would hang or race
+                        if out is None:  # (cannot happen after the agreement below; never a silent divergence)
                             raise RuntimeError("row-parallel projection: this rank's shard cannot leave split-K partials "
-                                               "although its shape class can (set LL_TP_NO_FUSED_NORM=1 on every rank)")
+                                               "although the group agreed on the fused launch")
                         out.tp_reduce = True
                         return out
         return all_reduce_tp(self.apply_linear(x))
+
+    def _tp_fused_agreed(self, rows: int) -> bool:
+        """The fused partials + all-reduce + norm launch is taken only if EVERY rank of the group can take it (ADVICE round
+        3: under extension plans a rank's contracted size differs -- 19 vs 18 groups -- and the engine's split count for it
+        may be 0 on one rank only; the odd rank raised while its peers spun).  Decided ONCE per (layer, row count) by a MIN
+        all-reduce of the local answers -- ``LL_W4_NO_PARTIALS`` on any rank simply turns the route off for the group -- on
+        the first eager call (every rank walks the same call sequence); a call inside a graph capture that finds no
+        decision takes the unfused route, on every rank alike."""
+        cache = self.__dict__.setdefault("_tp_fused_cache", {})
+        if rows in cache:
+            return cache[rows]
+        if torch.cuda.is_current_stream_capturing():
+            return False
+        from .distributed.parallel_state import all_reduce_min
+        mine = 0
+        if self._tp_partials_ok(rows) and not os.environ.get("LL_W4_NO_PARTIALS"):
+            from . import _lib as L
+            mine = 1 if L.lib().ll_w4a16_partials_count(rows, self.output_size, self.input_size, self.quant.group_k) > 0 else 0
+        cache[rows] = bool(all_reduce_min(mine))
+        return cache[rows]
 
     def _tp_partials_ok(self, rows: int) -> bool:
         """Whether EVERY rank's shard of this projection can leave split-K partials -- from properties all ranks share

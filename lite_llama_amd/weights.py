@@ -366,8 +366,13 @@ def invalidate_derived_layouts(model: nn.Module) -> None:
     """Drop every load-time layout derived from a parameter (the int4 decode engine's pre-packed weights / scale pairs,
     merged q|k|v and gate|up storages): ``view.copy_`` writes through ``param.data`` and bumps no version counter, so the
     caches' (pointer, version) keys cannot see a checkpoint loaded after a warm-up forward."""
+    for p_ in model.parameters():  # the drop-in route keeps its layouts ON the weight tensor (kernels/quantization.py::_auto_prepacked)
+        if hasattr(p_, "_ll_prepacked"):
+            delattr(p_, "_ll_prepacked")
+        if hasattr(p_.data, "_ll_prepacked"):
+            delattr(p_.data, "_ll_prepacked")
     for mod in model.modules():
-        for attr in ("_w4_prepacked", "_w4_packed"):
+        for attr in ("_w4_prepacked", "_w4_packed", "_tp_fused_cache"):
             if hasattr(mod, attr):
                 delattr(mod, attr)
         for val in list(vars(mod).values()):
