@@ -233,6 +233,17 @@ int ll_w8a8_matmul(void* out, const int8_t* qa, const float* a_scale, const int8
                    int64_t qw_stride_n, int32_t* acc_out /* nullable: raw int32 accumulators [M,N] */,
                    int32_t* workspace, int32_t* counters, void* stream);
 
+/* Split-K partial mode of the decode-shaped 8-bit / 16-bit engine (no reference counterpart; the int4 engine's epilogue 2 for
+ * the other formats): partials [S][M][N] fp32 with the block scales applied, summed by the projection's consumer
+ * (ll_skip_rmsnorm_partials, ll_decode_attention_partials) -- no finish launch.  wfmt: 1 fp8 e4m3 / 2 int8 (fp16
+ * activations; scales as in ll_w8a16_matmul) / 4 fp16 / 5 bf16 weights (activations of the weight's type, scales NULL;
+ * w_stride in elements).  ll_dense_partials_count: S for (shape, format, cap) -- 0 = not served; ll_dense_partials returns
+ * the S it wrote (the same number), 0 when alignment rules decline the call, < 0 on error. */
+int ll_dense_partials_count(int64_t m, int64_t n, int64_t k, int wfmt, int max_splits);
+int ll_dense_partials(float* partials, const void* x, const void* w, const float* scales, int64_t m, int64_t n, int64_t k,
+                      int group_n, int64_t group_k, int wfmt, int64_t x_stride, int64_t w_stride, int64_t s_stride_n,
+                      int64_t s_stride_k, int max_splits, void* stream);
+
 /* ---- unquantised 16-bit linears at decode shapes (models/quantization/methods/unquantized.py:21-22 and the lm_head of
  * models/base.py:486-489: torch F.linear, i.e. a vendor GEMM, in the reference) -------------------------------------------
  * out[m, n] = x[m, :] . w[n, :] (+ bias[n]); x [m, k] (row stride x_stride elements), w [n, k] (row stride w_stride), bias,

@@ -287,10 +287,11 @@ __global__ __launch_bounds__(256) void dense8_finish(uint16_t* __restrict__ out,
   *reinterpret_cast<uint2*>(out + i) = uint2{(uint32_t)o[0] | ((uint32_t)o[1] << 16), (uint32_t)o[2] | ((uint32_t)o[3] << 16)};
 }
 
-int d8_splits(int64_t n, int64_t k, int kch = 128) {
+int d8_splits(int64_t n, int64_t k, int kch = 128, int cap = 1 << 30) {
   const int tiles = (int)((n + 127) / 128), chunks = (int)(k / kch);
   int s = (768 + tiles - 1) / tiles;   // ~3 resident workgroups per CU ...
   if (s > chunks / 2) s = chunks / 2;  // ... of at least two chunks each (the tile prefetch needs something to hide behind)
+  if (s > cap) s = cap;                // (partial mode: what the consumer of the planes adds up in one pass)
   if (s < 1) s = 1;
   return s;
 }
@@ -398,4 +399,57 @@ extern "C" int ll_dense16_matmul(void* out, const void* x, const void* w, const 
     dense8_finish<false, LL_BF16><<<fgrid, 256, 0, st>>>((uint16_t*)out, partials, used, m, n, (const uint16_t*)bias, nullptr,
                                                         nullptr, nullptr);
   return hipGetLastError() == hipSuccess ? 1 : LL_ERR_LAUNCH;
+}
+
+
+// ---------------------------------------------------------------------------------------------------------------- //
+// Split-K partial mode of the skinny engine (round 4; the int4 engine's epilogue 2 for the other formats): the launch
+// leaves its fp32 partial planes [S][M][N] -- block scales already applied (a9) / plain products (16-bit) -- for the
+// consumer of the projection to add up: ll_skip_rmsnorm_partials after a row-parallel projection, ll_decode_attention_partials
+// after the fused q|k|v one.  No dense8_finish launch, no second pass over the output.  wfmt: 1 fp8 e4m3, 2 int8 (fp16
+// activations, block scales), 4 fp16, 5 bf16 weights (activations of the same type).  Not for a10 (int32 planes need the
+// per-token scales first).  Returns the number of planes written (>= 1), 0 when the shape is not served, < 0 on error.
+// ---------------------------------------------------------------------------------------------------------------- //
+extern "C" int ll_dense_partials_count(int64_t m, int64_t n, int64_t k, int wfmt, int max_splits) {
+  const bool w16 = wfmt == D8_F16 || wfmt == D8_BF16;
+  if (wfmt != D8_FP8 && wfmt != D8_I8 && !w16) return 0;
+  const int kch = w16 ? 64 : 128;
+  if (m < 1 || m > 64 || n < 4 || n % 4 != 0 || k < kch || k % kch != 0 || max_splits < 1) return 0;
+  const int chunks = (int)(k / kch);
+  const int splits = d8_splits(n, k, kch, max_splits);
+  const int cps = (chunks + splits - 1) / splits;
+  return (chunks + cps - 1) / cps;
+}
+
+extern "C" int ll_dense_partials(float* partials, const void* x, const void* w, const float* scales, int64_t m, int64_t n,
+                                 int64_t k, int group_n, int64_t group_k, int wfmt, int64_t x_stride, int64_t w_stride,
+                                 int64_t s_stride_n, int64_t s_stride_k, int max_splits, void* stream) {
+  const bool w16 = wfmt == D8_F16 || wfmt == D8_BF16;
+  const int used = ll_dense_partials_count(m, n, k, wfmt, max_splits);
+  if (used == 0) return 0;
+  if (!partials || !x || !w || (!w16 && !scales)) return LL_ERR_ARG;
+  const int eb = w16 ? 2 : 1;
+  if ((w_stride * eb) % 16 != 0 || x_stride % 8 != 0 || !ll_aligned16(w) || !ll_aligned16(x) || !ll_aligned16(partials)) return 0;
+  if (!w16 && group_k < k && group_k % 64 != 0) return 0;
+  D8Params p{};
+  p.part = partials; p.x = x; p.w = (const unsigned char*)w; p.scales = scales;
+  p.m = m; p.n = n; p.k = k; p.x_stride = x_stride; p.w_stride = w_stride * eb;
+  p.s_stride_n = s_stride_n; p.s_stride_k = s_stride_k; p.group_n = group_n > 0 ? group_n : 1;
+  p.group_k = group_k > 0 ? group_k : k;
+  const int kch = w16 ? 64 : 128;
+  p.chunks = (int)(k / kch);
+  p.nt_w = d8_nt(n * k * eb);
+  p.cps = (p.chunks + used - 1) / used;
+  if ((p.chunks + p.cps - 1) / p.cps != used) return LL_ERR_SHAPE;  // (cannot happen: `used` is a fixed point of the split rule)
+  dim3 grid((unsigned)((n + 127) / 128), (unsigned)used);
+  hipStream_t st = (hipStream_t)stream;
+#define LL_D8P(WF)                                                       \
+  if (m > 32) dense8_kernel<WF, 2><<<grid, 256, 0, st>>>(p);             \
+  else dense8_kernel<WF, 1><<<grid, 256, 0, st>>>(p)
+  if (wfmt == D8_FP8) { LL_D8P(D8_FP8); }
+  else if (wfmt == D8_I8) { LL_D8P(D8_I8); }
+  else if (wfmt == D8_F16) { LL_D8P(D8_F16); }
+  else { LL_D8P(D8_BF16); }
+#undef LL_D8P
+  return hipGetLastError() == hipSuccess ? used : LL_ERR_LAUNCH;
 }

@@ -320,6 +320,51 @@ def smoothquant_matmul(
     return out
 
 
+def dense_matmul_partials(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor | None = None, *, group_n: int = 1,
+                          group_k: int = 0, max_splits: int = 12):
+    """Decode-step extension for the 8-bit and the unquantised 16-bit formats (the int4 route's
+    :func:`w4a16_matmul_partials`): the projection ``x @ dequant(weight).T`` left as ``S <= max_splits`` fp32 split-K partial
+    planes (:class:`PartialSums`) for its consumer to add up -- no finish launch.  ``weight``: uint8 (fp8 e4m3 bits) / int8
+    with ``scales`` (one fp32 per ``group_n x group_k`` block) and fp16 activations, or fp16 / bf16 (``scales`` None,
+    activations of the same type).  ``None`` when the call is not served (more than 64 rows, shapes off the engine's grid)."""
+    from .norm_act import PartialSums
+    if not x.is_cuda or weight.dim() != 2 or weight.stride(1) != 1 or os.environ.get("LL_DENSE_NO_PARTIALS"):
+        return None
+    n, k = weight.shape
+    if weight.dtype in (torch.float16, torch.bfloat16):
+        if x.dtype != weight.dtype or scales is not None:
+            return None
+        wfmt = 4 if weight.dtype == torch.float16 else 5
+    elif weight.dtype in (torch.uint8, torch.int8):
+        if x.dtype != torch.float16 or scales is None:
+            return None
+        wfmt = 1 if weight.dtype == torch.uint8 else 2
+        if scales.dtype != torch.float32:
+            scales = scales.float()
+        if scales.dim() == 1:
+            scales = scales.unsqueeze(-1)
+    else:
+        return None
+    if x.shape[-1] != k:
+        return None
+    a = _flatten(x, k)
+    m = a.shape[0]
+    s = L.lib().ll_dense_partials_count(m, n, k, wfmt, int(max_splits)) if 1 <= m <= 64 else 0
+    if s < 1:
+        return None
+    parts = torch.empty((s, m, n), dtype=torch.float32, device=x.device)
+    gk = int(min(group_k, k)) if group_k else k
+    rc = L.lib().ll_dense_partials(parts.data_ptr(), a.data_ptr(), weight.data_ptr(), L.ptr(scales), m, n, k, int(group_n), gk, wfmt,
+                                   a.stride(0), weight.stride(0), scales.stride(0) if scales is not None else 0,
+                                   scales.stride(1) if scales is not None else 0, int(max_splits), L.stream_ptr())
+    if rc == 0:
+        return None
+    if rc < 0:
+        L.check(rc, "dense_matmul_partials")
+    assert rc == s
+    return PartialSums(parts, (*x.shape[:-1], n), x.dtype)
+
+
 def dense16_wins(m: int, n: int, k: int) -> bool:
     """Where the hand-written kernel measured FASTER than the library GEMM on MI355X (benchmarks/dense16_shapes.py, round 3,
     same box, hipGraph replays over rotating weights): batches of <= 32 rows with a long contraction (Qwen2.5-1.5B down

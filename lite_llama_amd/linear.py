@@ -285,7 +285,7 @@ class MergedColumnLinear:
         if h is None or h.interleaved or not hasattr(h.quant_method, "apply_partials") or get_tp_world_size() != 1 \
                 or collective_forced():
             return None
-        parts = h.quant_method.apply_partials(h, x, allow_bias=True)
+        parts = h.quant_method.apply_partials(h, x, allow_bias=True, max_splits=8)  # the attention kernel adds <= 8 planes
         return None if parts is None else (parts, h.bias)
 
     def swiglu(self, x: torch.Tensor) -> torch.Tensor:

@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..kernels import fused_moe, smoothquant_matmul, w4a16_matmul, w8a16_matmul
-from ..kernels.quantization import (dense16_linear, pack_w4a16_scales, pack_w4a16_weights, unpack_w4a16_weights, w4a16_matmul_partials,
+from ..kernels.quantization import (dense16_linear, dense_matmul_partials, pack_w4a16_scales, pack_w4a16_weights, unpack_w4a16_weights, w4a16_matmul_partials,
                                     w4a16_matmul_prepacked, w4a16_prepacked_supported)
 from .config import FP8, INT4, INT8, SMOOTHQUANT, QuantConfig
 from .params import (
@@ -62,6 +62,13 @@ class UnquantizedLinearMethod(LinearQuantMethod):
     def apply(self, layer, x):
         out = dense16_linear(x, layer.weight, layer.bias, policy="auto")  # decode shapes where the own kernel measured faster
         return out if out is not None else F.linear(x, layer.weight, layer.bias)
+
+    def apply_partials(self, layer, x, allow_bias: bool = False, max_splits: int = 12):
+        """Decode-shaped projection left as fp32 split-K partials for its consumer (round 4, as the int4 method's): ``None``
+        -> the caller runs :meth:`apply`."""
+        if layer.bias is not None and not allow_bias:
+            return None
+        return dense_matmul_partials(x, layer.weight, max_splits=max_splits)
 
 
 def _ordered_input(layer, x):
@@ -143,7 +150,7 @@ class W4A16LinearMethod(LinearQuantMethod):
         if hasattr(layer, "_w4_prepacked"):
             delattr(layer, "_w4_prepacked")
 
-    def apply_partials(self, layer, x, allow_bias: bool = False):
+    def apply_partials(self, layer, x, allow_bias: bool = False, max_splits: int = 12):
         """Decode-shaped projection left as fp32 split-K partials for ``skip_rmsnorm_partials`` /
         ``decode_attention_partials`` (extension); ``None`` -> the caller runs :meth:`apply`.  The partials never
         include the bias: a consumer that adds it itself passes ``allow_bias``."""
@@ -153,7 +160,8 @@ class W4A16LinearMethod(LinearQuantMethod):
         pre = self._prepacked(layer, x)
         if pre is None:
             return None
-        return w4a16_matmul_partials(x, pre, self._packed(layer), group_size=layer.quant.group_k)
+        out = w4a16_matmul_partials(x, pre, self._packed(layer), group_size=layer.quant.group_k)
+        return out if out is None or out.parts.shape[0] <= max_splits else None  # (the host plan never exceeds 12; q|k|v: 5)
 
     def apply_gate_up_swiglu(self, layer, x):
         """``layer`` holds gate/up row-interleaved (linear.py::MergedColumnLinear): one launch for
@@ -233,6 +241,15 @@ class W8A16LinearMethod(LinearQuantMethod):
         q = layer.quant
         return w8a16_matmul(x, layer.weight, layer.weight_scale_inv, group_n=q.group_n,
                             group_k=min(q.group_k, layer.input_size), bias=layer.bias)
+
+    def apply_partials(self, layer, x, allow_bias: bool = False, max_splits: int = 12):
+        """Decode-shaped projection left as fp32 split-K partials (block scales applied) for its consumer; ``None`` -> the
+        caller runs :meth:`apply`."""
+        if layer.bias is not None and not allow_bias:
+            return None
+        q = layer.quant
+        return dense_matmul_partials(x, layer.weight, layer.weight_scale_inv, group_n=q.group_n,
+                                     group_k=min(q.group_k, layer.input_size), max_splits=max_splits)
 
     def convert_from_fp16(self, layer, quant):
         qw, sc = _quantize_8bit(layer.weight.data, quant, layer.input_size)

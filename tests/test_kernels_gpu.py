@@ -998,3 +998,61 @@ def test_dense16_linear_matches_fp32_reference(M, N, K_, dt, with_bias):
     assert dense16_linear(x.to(DEV).view(1, M, K_), w.to(DEV)).shape == (1, M, N)
     assert dense16_linear(torch.zeros(65, K_, dtype=dt, device=DEV), w.to(DEV)) is None
     assert dense16_linear(x.to(DEV), w.to(DEV).float()) is None
+
+
+@pytest.mark.parametrize("fmt", ["f16", "bf16", "fp8_block", "int8_channel", "int8_group"])
+@pytest.mark.parametrize("M,N,K_,cap", [(64, 2048, 1536, 8), (32, 1536, 8960, 12), (7, 5120, 2048, 8), (64, 2048, 4096, 12), (1, 128, 128, 12)])
+def test_dense_partials_sum_to_the_finished_projection(fmt, M, N, K_, cap):
+    """Split-K partial mode of the 8-bit / 16-bit decode engine (round 4): the fp32 planes add up to what the finished
+    projection stores (same kernel, same split order: equal after the one rounding), their count respects the consumer's
+    cap, and the add-and-normalise over the planes equals skip_rmsnorm over the finished projection."""
+    from lite_llama_amd.kernels.norm_act import skip_rmsnorm_partials
+    from lite_llama_amd.kernels.quantization import dense16_linear, dense_matmul_partials
+
+    g = torch.Generator().manual_seed(M + N + K_)
+    dt = torch.bfloat16 if fmt == "bf16" else torch.float16
+    x = (torch.randn(M, K_, generator=g) * 0.5).to(dt).to(DEV)
+    if fmt in ("f16", "bf16"):
+        w = (torch.randn(N, K_, generator=g) * 0.05).to(dt).to(DEV)
+        parts = dense_matmul_partials(x, w, max_splits=cap)
+        full = dense16_linear(x, w)
+        ref = (x.float() @ w.float().T)
+    else:
+        if fmt == "fp8_block":
+            qw = torch.randint(0, 256, (N, K_), generator=g, dtype=torch.int64).to(torch.uint8)   # e4m3 bit patterns ...
+            qw = torch.where((qw & 0x7F) == 0x7F, qw - 1, qw)                                    # ... without the two NaN codes
+            sc = torch.rand((N + 127) // 128, (K_ + 127) // 128, generator=g) * 0.0002 + 0.0001
+            gn, gk = 128, 128
+        elif fmt == "int8_channel":
+            qw = torch.randint(-127, 128, (N, K_), generator=g, dtype=torch.int8)
+            sc = torch.rand(N, 1, generator=g) * 0.001 + 0.0005
+            gn, gk = 1, K_
+        else:
+            qw = torch.randint(-127, 128, (N, K_), generator=g, dtype=torch.int8)
+            sc = torch.rand(N, K_ // 128, generator=g) * 0.001 + 0.0005
+            gn, gk = 1, 128
+        qw, sc = qw.to(DEV), sc.to(DEV)
+        parts = dense_matmul_partials(x, qw, sc, group_n=gn, group_k=gk, max_splits=cap)
+        full = K().w8a16_matmul(x, qw, sc, group_n=gn, group_k=gk)
+        ref = O.w8a16_matmul(x.cpu(), qw.cpu(), sc.cpu(), group_n=gn, group_k=gk).float().to(DEV)
+    assert parts is not None and 1 <= parts.parts.shape[0] <= cap and parts.parts.shape[1:] == (M, N)
+    summed = parts.parts.sum(0)
+    tol = 2e-2 if dt == torch.float16 else 6e-2
+    close(summed.to(dt), ref.to(dt), tol)
+    if full is not None:
+        close(summed.to(dt), full, 4e-3 if dt == torch.float16 else 3.2e-2)   # same products; the plane count may differ from the finished form's
+    res = (torch.randn(M, N, generator=g) * 0.5).to(dt).to(DEV)
+    nw = (1 + 0.1 * torch.randn(N, generator=g)).to(dt).to(DEV)
+    if N <= 8192:
+        r1, r2 = res.clone(), res.clone()
+        y1, _ = skip_rmsnorm_partials(parts, r1, nw, 1e-6)
+        acc = torch.zeros(M, N, device=DEV)
+        for sl in range(parts.parts.shape[0]):   # the kernel's order: plane 0 first, one fp32 add per plane
+            acc = acc + parts.parts[sl]
+        y2, _ = K().skip_rmsnorm(acc.to(dt), r2, nw, 1e-6)
+        assert torch.equal(r1, r2)                            # x = dtype(sum of planes): the same value on both sides
+        close(y1, y2, 4e-3 if dt == torch.float16 else 3.2e-2)  # (the two kernels reduce the row's squares in different orders)
+        assert (y1 == y2).float().mean().item() > 0.98
+    assert dense_matmul_partials(torch.zeros(65, K_, dtype=dt, device=DEV), w if fmt in ("f16", "bf16") else qw,
+                                 None if fmt in ("f16", "bf16") else sc, group_n=1 if fmt in ("f16", "bf16") else gn,
+                                 group_k=0 if fmt in ("f16", "bf16") else gk) is None
