@@ -105,18 +105,3 @@ for name, n, k, epi in shapes:
             print("  unit 3, shader cycles (median): reads issued %d | compute issued %d | barrier %d | bookkeeping %d | step total %d" % (
                 d[:, 0].median(), d[:, 1].median(), d[:, 2].median(), d[:, 3].median(), (c[m, 4] - c[m, 0]).median()))
         print(f"  last segment end: begin {stat(50)} exchanged {stat(51)} counter seen {stat(52)} merged {stat(53)} | wave done {stat(60)}")
-        ocn = int(os.environ.get("OCN", 0))  # owner / contributor split: workgroups < OCN are contributors
-        if ocn and epi:
-            idx = torch.nonzero(live).squeeze(1)
-            for label, rows_ in (("contributors", idx < ocn), ("owners", idx >= ocn)):
-                tt = t[rows_]
-
-                def st2(col):
-                    v = tt[:, col]
-                    m = v > 0
-                    if m.sum() == 0:
-                        return "      -      "
-                    d = (v[m] - t0) / 100.0
-                    return f"{d.min():6.2f}/{d.median():6.2f}/{d.max():6.2f}"
-
-                print(f"  {label:12s} (min/median/max us after the first entry): last segment begin {st2(50)} exchanged {st2(51)} counter seen {st2(52)} merged {st2(53)} epilogue math / slab stores issued {st2(58)} output stores issued {st2(59)} | wave done {st2(60)}")

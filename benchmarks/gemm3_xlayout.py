@@ -15,7 +15,7 @@ pads = [int(p) for p in os.environ.get("PADS", "0,64").split(",")]
 shapes = [("qkv", 4608, 3584, 2), ("o", 3584, 3584, 2), ("gateup", 37888, 3584, 1), ("down", 3584, 18944, 2)]
 if os.environ.get("ONLY"):
     shapes = [s for s in shapes if s[0] in os.environ["ONLY"].split(",")]
-res = {"oc": os.environ.get("LL_GEMM3_OC", "default"), "lib": os.environ.get("LL_LIB_OVERRIDE", "default"), "xcm": bool(os.environ.get("LL_GEMM3_XCM")), "copies": os.environ.get("COPIES", "rot")}
+res = {"lib": os.environ.get("LL_LIB_OVERRIDE", "default"), "xcm": bool(os.environ.get("LL_GEMM3_XCM")), "copies": os.environ.get("COPIES", "rot")}
 for name, n, k, mode in shapes:
     wbytes = n * k // 2 + n * (k // 128) * 8
     copies = int(os.environ.get("COPIES", 0)) or max(2, int(700e6 // wbytes))

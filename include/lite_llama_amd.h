@@ -213,8 +213,8 @@ int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* wpacked, con
                               void* stream);
 /* Host-side introspection (tests; no device work): the launch plan ll_w4a16_matmul_prepacked uses for (n, k,
  * epilogue) as 16 ints -- grid, 128-row blocks per tile, tiles, chunks, slab slots, tile-group split (gt, gbase, grem, lead,
- * xcd_shift), stream-K units per workgroup, owner / contributor split (contributors, chunks per tile left to them, their
- * range base / remainder), compute units assumed.  tests/test_host_cpu.py restates the kernel's per-workgroup decode on it. */
+ * xcd_shift), stream-K units per workgroup, four reserved zeros, compute units assumed.  tests/test_host_cpu.py restates the
+ * kernel's per-workgroup decode on it. */
 int ll_w4a16_v3_plan(int64_t m, int64_t n, int64_t k, int group_size, int epilogue, int32_t* out16);
 /* ---- a9: w8a16_matmul  (kernels/quantization/w8a16.py:155-216) ---------------
  * qweight [N,K] uint8 (fp8-e4m3 bits) or int8; scales fp32 [ceil(N/gn), ceil(K/gk)]. */

@@ -90,14 +90,6 @@ struct V3Params {
                   // ONE k-slice of the activation matrix (1 / gt of it) instead of all of it; -1: b = tile * gt + slice
   uint32_t chunks_magic, gt_magic, upw_magic;  // ceil(2^32 / d): x / d = umulhi(x, magic) for the unit / workgroup indices of a launch (< 2^20)
   int gshift;                  // log2(group_size / 128)
-  // Owner / contributor split (round 4; tiles <= workgroups < 2 tiles, non-partial epilogues): workgroups [0, oc_nc) are
-  // CONTRIBUTORS -- they share the chunks [0, oc_cown) of every tile (a stream of tiles * oc_cown units cut into oc_nc equal
-  // ranges of >= oc_cown units, so a tile's region is cut at most once: the piece that starts at chunk 0 is slab 0, the other
-  // slab 1); workgroup oc_nc + t is the OWNER of tile t and sums chunks [oc_cown, chunks).  The owners run `lead` units longer
-  // than the contributors, so every slab and counter has landed long before an owner looks (the stream-K split of round 2 / 3
-  // had a contributor finishing WITH its owner on ~95 of 148 tiles: store ack, counter, poll, slab read = ~7 us of tail).
-  int oc_nc, oc_cown, oc_cbase, oc_crem;
-  uint32_t oc_cown_magic;
   int epi;                     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu;  2: fp32 split-K partials [slot][m][n]
 #ifdef V3_TIMELINE
   unsigned long long* tl;  // debug: [workgroup][64] s_memrealtime stamps of wave LL_GEMM3_TL_WAVE (benchmarks/gemm3_timeline.py)
@@ -161,7 +153,7 @@ __device__ __forceinline__ f16x8 v3_dequant(uint32_t w, uint32_t s, uint32_t nzs
 // and two countdowns; the per-unit path is three scalar adds and two compares, the fix-up at the end of a tile
 // or segment is a (rare) branch.
 struct V3Seq {
-  int chunks;  // the numbering's wrap length: chunks of a tile (contributors of the owner / contributor split: of a tile's region)
+  int chunks;
   int t0, c0, n0, t1, c1, n1, t2, c2, n2;
 };
 struct V3Walk {
@@ -285,9 +277,6 @@ __device__ __forceinline__ void v3_dma_x(uint32_t dx, const void* xb, const uint
 }
 // Units a loader may request between the prologue barrier P0 and the barrier that ends unit 0 (the consumers wait there for
 // the loaders' ISSUE of these requests, ~0.65 us per unit and loader wave): A/B knob, see DESIGN.md 4.3
-#ifndef V3_OC_PREFETCH
-#define V3_OC_PREFETCH 1
-#endif
 #ifndef V3_START_FILL
 #define V3_START_FILL 8
 #endif
@@ -347,7 +336,7 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
 #pragma unroll
       for (int f = 0; f < NF; ++f) {  // the tile's 128-row blocks lc.t * NF + f
         const int blk = lc.t * NF + f;
-        const char* wb = (const char*)p.wp + (size_t)(uint32_t)((blk * p.chunks + lc.c) * (V3_BN * V3_CK / 2));
+        const char* wb = (const char*)p.wp + (size_t)(uint32_t)((blk * q.chunks + lc.c) * (V3_BN * V3_CK / 2));
         const char* sb = (const char*)p.sp + (size_t)(uint32_t)(((lc.c >> p.gshift) * (int)p.n + blk * V3_BN) * 8);
         v3_dma_w(dst + f * V3_W_BLOCK + 4 * L * 1024, dst + f * V3_W_BLOCK + 8192 + 2 * L * 256, wb, sb, voff);
       }
@@ -433,8 +422,6 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   V3_TLC(61)
   int ub, ue;
   int my_slice = -1;
-  int wrap = chunks;  // chunks of a tile this workgroup's unit numbering runs over before it moves to the next tile
-  uint32_t wrap_magic = p.chunks_magic;
   if (p.gt) {
     int gtile, j;
     if (p.xcd_shift >= 0) {
@@ -449,17 +436,6 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     const int lo = j * p.gbase + (j < p.grem ? j : p.grem);
     ub = gtile * chunks + lo;
     ue = j == p.gt - 1 ? (gtile + 1) * chunks : ub + p.gbase + (j < p.grem ? 1 : 0);
-  } else if (p.oc_nc) {
-    const int b = (int)blockIdx.x;
-    if (b < p.oc_nc) {  // contributor: a range of the [tile][chunk < oc_cown] stream (numbered with wrap = oc_cown)
-      ub = b * p.oc_cbase + (b < p.oc_crem ? b : p.oc_crem);
-      ue = ub + p.oc_cbase + (b < p.oc_crem ? 1 : 0);
-      wrap = p.oc_cown;
-      wrap_magic = p.oc_cown_magic;
-    } else {  // owner of tile b - oc_nc: chunks [oc_cown, chunks)
-      ub = (b - p.oc_nc) * chunks + p.oc_cown;
-      ue = (b - p.oc_nc + 1) * chunks;
-    }
   } else {
     ub = blockIdx.x * p.upw;
     ue = ub + p.upw;
@@ -467,19 +443,19 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   }
   if (ub >= ue) return;
   const int cnt = ue - ub;
-  const int tA = v3_div(ub, wrap_magic, wrap), cA = ub - tA * wrap;
-  const int tZ = v3_div(ue - 1, wrap_magic, wrap), cZ = (ue - 1) - tZ * wrap;
+  const int tA = v3_div(ub, p.chunks_magic, chunks), cA = ub - tA * chunks;
+  const int tZ = v3_div(ue - 1, p.chunks_magic, chunks), cZ = (ue - 1) - tZ * chunks;
   int LT = 0, LH = cnt;  // a range inside one tile runs as a single "head" segment
   if (tA != tZ) {
-    LT = (cZ != wrap - 1) ? cZ + 1 : 0;
-    LH = (cA != 0) ? wrap - cA : 0;
+    LT = (cZ != chunks - 1) ? cZ + 1 : 0;
+    LH = (cA != 0) ? chunks - cA : 0;
   }
   const int NFU = cnt - LT - LH;  // units of whole tiles
   const int tF = tA + ((LH > 0 && tA != tZ) ? 1 : 0);
   // segments in execution order, empty ones squeezed out (selects only: a runtime-indexed array would live in scratch)
   const bool hasT = LT > 0, hasF = NFU > 0;
   V3Seq q;
-  q.chunks = wrap;
+  q.chunks = chunks;
   q.t0 = hasT ? tZ : (hasF ? tF : tA); q.c0 = hasT ? 0 : (hasF ? 0 : cA); q.n0 = hasT ? LT : (hasF ? NFU : LH);
   q.t1 = (hasT && hasF) ? tF : tA; q.c1 = (hasT && hasF) ? 0 : cA; q.n1 = hasT ? (hasF ? NFU : LH) : (hasF ? LH : 0);
   q.t2 = tA; q.c2 = cA; q.n2 = (hasT && hasF) ? LH : 0;
@@ -526,36 +502,12 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     pending = 0;
   };
 
-  // Owner / contributor split: an owner's contributors finish `lead` units before it does, so the merge counter(s) of the one
-  // tile this wave will finish can be requested while the last two units are still being multiplied (a plain agent-scope
-  // load: the consumers have no other memory operation in flight, the compiler waits for it where the value is used).
-  int32_t* pf_ctr = nullptr;
-  int pf_a = -1, pf_b = -1;
-#if V3_OC_PREFETCH
-  if (p.oc_nc && (int)blockIdx.x >= p.oc_nc && !(NF == 1 && MT == 1 && kh == 1)) {
-    const int t_own = (int)blockIdx.x - p.oc_nc;
-    const int blk_own = t_own * NF + (NF == 2 ? kh : 0);
-    pf_ctr = p.counters + (blk_own * 4 + ng) * 2 + ((NF == 1 && MT == 2) ? kh : 0);
-  }
-#endif
-  auto pf_request = [&]() {
-    pf_a = __hip_atomic_load(pf_ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-    if constexpr (NF == 2 && MT == 2) pf_b = __hip_atomic_load(pf_ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
-  };
-
   // Finish NM (1 or 2) 32-row batch halves mt0, mt0 + 1 of row group ng, 128-row block f of tile t, whose chunks
   // [c_lo, c_hi] this workgroup has just summed into v0 (and v1) -- k-halves already added.
   auto flush = [&](f32x16& v0, f32x16& v1, auto nm_tag, int mt0, int t, int f, int c_lo, int c_hi) {
     constexpr int NM = decltype(nm_tag)::value;
-    // slab / plane index of this piece (an owner: the number of slabs to add).  Owner / contributor split: a tile's region is
-    // cut at most once -- the piece that starts at chunk 0 is slab 0, the other one slab 1 -- and an owner reads the number of
-    // pieces from the counter word (every piece adds 0x10000 + its chunk count).
-    int slot;
-    if (p.oc_nc) slot = c_lo == 0 ? 0 : 1;
-    else {
-      const int w0 = p.gt ? t * p.gt : v3_div(t * chunks, p.upw_magic, p.upw);  // first contributor of the tile
-      slot = my_slice >= 0 ? my_slice : (int)blockIdx.x - w0;
-    }
+    const int w0 = p.gt ? t * p.gt : v3_div(t * chunks, p.upw_magic, p.upw);  // first contributor of the tile
+    const int slot = my_slice >= 0 ? my_slice : (int)blockIdx.x - w0;
     const int blk = t * NF + f;  // 128-row block
     auto vsel = [&](int i) -> f32x16& { return i == 0 ? v0 : v1; };
     if (p.epi == 2) {
@@ -594,7 +546,7 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       }
       V3_TL(58)
       pend_ctr = ctr;
-      pend_val = c_hi - c_lo + 1 + (p.oc_nc ? 0x10000 : 0);
+      pend_val = c_hi - c_lo + 1;
       pend_n = NM;
       pending = 1;
       return;
@@ -602,25 +554,14 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     if (c_lo != 0) {
       // owner: chunks [0, c_lo) were summed by the `slot` lower-numbered contributors
       bool arrived = false;
-      if (pf_a >= 0) {  // (owner / contributor split) the counter words were requested two units ago: no round trip here
-        int seen = pf_a;
-        if constexpr (NM == 2) seen = (pf_b & 0xffff) < (seen & 0xffff) ? pf_b : seen;
-        seen = __builtin_amdgcn_readfirstlane(seen);
-        if ((seen & 0xffff) >= c_lo) {
-          arrived = true;
-          slot = seen >> 16;
-        }
-      }
-      for (int spin = 0; !arrived && spin < V3_SPIN_LIMIT; ++spin) {
+      for (int spin = 0; spin < V3_SPIN_LIMIT; ++spin) {
         int seen = __hip_atomic_load(ctr, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
         if constexpr (NM == 2) {
           const int s1 = __hip_atomic_load(ctr + 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
           seen = seen < s1 ? seen : s1;
         }
-        seen = __builtin_amdgcn_readfirstlane(seen);
-        if ((seen & 0xffff) >= c_lo) {
+        if (__builtin_amdgcn_readfirstlane(seen) >= c_lo) {
           arrived = true;
-          if (p.oc_nc) slot = seen >> 16;
           break;
         }
         __builtin_amdgcn_s_sleep(4);
@@ -904,7 +845,6 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 #define V3_STEP(CUR, NXT)                                                                   \
   {                                                                                         \
     if (done == 5) { V3_TLC(44) }                                                           \
-    if (pf_ctr && done + 2 == cnt) pf_request();                                            \
     read_ops(RG::RA ? NXT : CUR, wnext, xnext);                                             \
     __builtin_amdgcn_sched_barrier(0); /* keep the reads up here (hipcc sinks them to their use otherwise) */ \
     if (done == 5) { V3_TLC(45) }                                                           \
@@ -1057,16 +997,13 @@ struct V3Plan {
   int nblocks, chunks, total_units, upw, grid, slots;
   int gt, gbase, grem, glead;
   int xcd_shift = -1;  // V3Params::xcd_shift
-  int oc_nc = 0, oc_cown = 0, oc_cbase = 0, oc_crem = 0;  // V3Params::oc_*
 };
 
 struct V3Knobs {
   int wgs = 0, lead = 4, gt_cap_div = 5, gt_cap = -1, nf = 0;
   int xcd = 8;  // split-K partial launches take a power-of-two split <= this and the XCD-aware map (LL_GEMM3_XCD=0: off)
   int fill = 85;  // ... when the launch still fills this percentage of the CUs (LL_GEMM3_FILL)
-  int oc_lead = 4;  // owner / contributor split: units an owner runs longer than a contributor (LL_GEMM3_OC=-1: stream-K as before)
   V3Knobs() {
-    if (const char* e = getenv("LL_GEMM3_OC")) oc_lead = atoi(e);
     if (const char* e = getenv("LL_GEMM3_XCD")) xcd = atoi(e);
     if (const char* e = getenv("LL_GEMM3_FILL")) fill = atoi(e);
     if (const char* e = getenv("LL_GEMM3_WGS")) wgs = atoi(e);
@@ -1140,28 +1077,6 @@ static V3Plan v3_plan(int64_t n, int64_t k, int nf_force = 0, bool partials = fa
     pl.slots = gt;
     return pl;
   }
-  // Owner / contributor split (V3Params::oc_*): between one and two workgroups per tile.  Owners (one per tile) sum the last
-  // a = chunks - cown chunks, the target - tiles contributors share the first cown chunks of every tile in equal ranges of
-  // b = tiles * cown / contributors units; cown is chosen so that a - b ~ lead.  (Qwen2.5-7B gate|up, 148 tiles x 28 chunks on
-  // 256 CUs: lead 4 -> cown 10, a = 18, b = 13.7; lead 2 -> cown 11, a = 17, b = 15.1.)
-  if (!partials && kn.oc_lead >= 0 && pl.nblocks < target && 2 * pl.nblocks >= target && pl.chunks >= 4) {
-    const int nc = target - pl.nblocks;
-    int cown = (int)((((int64_t)pl.chunks - kn.oc_lead) * nc + target / 2) / target);
-    if (cown > pl.chunks - 1) cown = pl.chunks - 1;
-    if (cown < 1) cown = 1;
-    const int64_t total_c = (int64_t)pl.nblocks * cown;
-    // a contributor's range is at least one region long (every region is cut at most once) and never longer than an owner's
-    if (total_c / nc >= cown && (total_c + nc - 1) / nc <= pl.chunks - cown) {
-      pl.oc_nc = nc;
-      pl.oc_cown = cown;
-      pl.oc_cbase = (int)(total_c / nc);
-      pl.oc_crem = (int)(total_c % nc);
-      pl.upw = pl.chunks - cown;
-      pl.grid = target;
-      pl.slots = 2;
-      return pl;
-    }
-  }
   int upw = (pl.total_units + target - 1) / target;
   // a tile has at most (chunks - 2) / upw + 2 contributors
   const int min_upw = (pl.chunks + (V3_MAX_SLOTS - 2) - 1) / (V3_MAX_SLOTS - 2);
@@ -1196,7 +1111,7 @@ extern "C" int ll_w4a16_partials_count(int64_t m, int64_t n, int64_t k, int grou
 
 // The launch plan of ll_w4a16_matmul_prepacked for (n, k, epilogue) as 16 ints -- host-side introspection for tests and
 // DESIGN.md (no device work): [0] grid, [1] 128-row blocks per tile, [2] tiles, [3] chunks, [4] slab slots, [5] gt, [6] gbase,
-// [7] grem, [8] glead, [9] xcd_shift, [10] upw, [11] oc_nc, [12] oc_cown, [13] oc_cbase, [14] oc_crem, [15] compute units assumed.
+// [7] grem, [8] glead, [9] xcd_shift, [10] upw, [11..14] 0 (reserved), [15] compute units assumed.
 extern "C" int ll_w4a16_v3_plan(int64_t m, int64_t n, int64_t k, int group_size, int epilogue, int32_t* out16) {
   if (!out16) return LL_ERR_ARG;
   if (!ll_w4a16_prepacked_supported(m, n, k, group_size)) return LL_ERR_SHAPE;
@@ -1204,8 +1119,8 @@ extern "C" int ll_w4a16_v3_plan(int64_t m, int64_t n, int64_t k, int group_size,
   if (partials && !ll_w4a16_partials_count(m, n, k, group_size)) return LL_ERR_SHAPE;
   const V3Plan pl = v3_plan(n, k, (epilogue >> 8) & 3, partials);
   const int v[16] = {pl.grid, pl.nf, pl.nblocks, pl.chunks, pl.slots, pl.gt, pl.gbase, pl.grem, pl.glead,
-                     (partials && pl.gt >= 1 && pl.grid == pl.nblocks * pl.gt) ? pl.xcd_shift : -1, pl.upw, pl.oc_nc, pl.oc_cown,
-                     pl.oc_cbase, pl.oc_crem, v3_knobs().wgs > 0 ? v3_knobs().wgs : v3_num_cus()};
+                     (partials && pl.gt >= 1 && pl.grid == pl.nblocks * pl.gt) ? pl.xcd_shift : -1, pl.upw, 0, 0,
+                     0, 0, v3_knobs().wgs > 0 ? v3_knobs().wgs : v3_num_cus()};
   for (int i = 0; i < 16; ++i) out16[i] = v[i];
   return LL_OK;
 }
@@ -1247,7 +1162,6 @@ static int v3_launch(void* out, const void* x, const void* wpacked, const void* 
   p.x_bytes = (uint32_t)((m - 1) * x_stride_m * 2 + k * 2);
   p.nblocks = pl.nblocks; p.chunks = pl.chunks; p.total_units = pl.total_units; p.upw = pl.upw; p.slots = pl.slots;
   p.gt = pl.gt; p.gbase = pl.gbase; p.grem = pl.grem; p.glead = pl.glead;
-  p.oc_nc = pl.oc_nc; p.oc_cown = pl.oc_cown; p.oc_cbase = pl.oc_cbase; p.oc_crem = pl.oc_crem;
   p.epi = epilogue;
   auto magic = [](int d) { return d > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)d - 1) / (uint64_t)d) : 0u; };
   // umulhi(x, ceil(2^32 / d)) == x / d for x * d < 2^32 (x: unit / workgroup indices); d == 1 is handled by the guard below
@@ -1257,7 +1171,6 @@ static int v3_launch(void* out, const void* x, const void* wpacked, const void* 
   p.chunks_magic = magic(pl.chunks);
   p.gt_magic = magic(pl.gt);
   p.upw_magic = magic(pl.upw);
-  p.oc_cown_magic = magic(pl.oc_cown);
 #ifdef V3_TIMELINE
   p.tlwave = getenv("LL_GEMM3_TL_WAVE") ? atoi(getenv("LL_GEMM3_TL_WAVE")) : 0;
   p.tl = getenv("LL_GEMM3_TIMELINE") ? (unsigned long long*)strtoull(getenv("LL_GEMM3_TIMELINE"), nullptr, 16) : nullptr;

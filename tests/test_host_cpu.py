@@ -191,15 +191,14 @@ def _v3_plan(lib, n, k, epilogue):
 
     out = (ctypes.c_int32 * 16)()
     assert lib.ll_w4a16_v3_plan(64, n, k, 128, epilogue, out) == 0
-    keys = ["grid", "nf", "tiles", "chunks", "slots", "gt", "gbase", "grem", "glead", "xcd_shift", "upw", "oc_nc", "oc_cown",
-            "oc_cbase", "oc_crem", "cus"]
+    keys = ["grid", "nf", "tiles", "chunks", "slots", "gt", "gbase", "grem", "glead", "xcd_shift", "upw", "r0", "r1", "r2", "r3", "cus"]
     return dict(zip(keys, list(out)))
 
 
 def _v3_segments(pl, b):
     """Restatement of wgemm3_kernel's range decode (gemm_w4_v3.hip): the (tile, first chunk, last chunk) segments workgroup b
     walks, in execution order (tail of the last tile, whole tiles, head of the first tile)."""
-    chunks, wrap = pl["chunks"], pl["chunks"]
+    chunks = pl["chunks"]
     if pl["gt"]:
         if pl["xcd_shift"] >= 0:
             x, q = b & 7, b >> 3
@@ -209,78 +208,52 @@ def _v3_segments(pl, b):
         lo = j * pl["gbase"] + min(j, pl["grem"])
         ub = gtile * chunks + lo
         ue = (gtile + 1) * chunks if j == pl["gt"] - 1 else ub + pl["gbase"] + (1 if j < pl["grem"] else 0)
-    elif pl["oc_nc"]:
-        if b < pl["oc_nc"]:
-            ub = b * pl["oc_cbase"] + min(b, pl["oc_crem"])
-            ue = ub + pl["oc_cbase"] + (1 if b < pl["oc_crem"] else 0)
-            wrap = pl["oc_cown"]
-        else:
-            ub, ue = (b - pl["oc_nc"]) * chunks + pl["oc_cown"], (b - pl["oc_nc"] + 1) * chunks
     else:
         ub, ue = b * pl["upw"], min((b + 1) * pl["upw"], pl["tiles"] * chunks)
     if ub >= ue:
         return []
-    (tA, cA), (tZ, cZ) = divmod(ub, wrap), divmod(ue - 1, wrap)
+    (tA, cA), (tZ, cZ) = divmod(ub, chunks), divmod(ue - 1, chunks)
     if tA == tZ:
         return [(tA, cA, cZ)]
     segs = []
-    if cZ != wrap - 1:
+    if cZ != chunks - 1:
         segs.append((tZ, 0, cZ))
     tF = tA + (1 if cA != 0 else 0)
-    tL = tZ - (1 if cZ != wrap - 1 else 0)
-    segs += [(t, 0, wrap - 1) for t in range(tF, tL + 1)]
+    tL = tZ - (1 if cZ != chunks - 1 else 0)
+    segs += [(t, 0, chunks - 1) for t in range(tF, tL + 1)]
     if cA != 0:
-        segs.append((tA, cA, wrap - 1))
+        segs.append((tA, cA, chunks - 1))
     return segs
 
 
-def test_w4a16_plans_cover_every_unit_once_and_the_owner_contributor_split_keeps_its_promises():
-    """Every launch plan of the pre-packed engine -- tile groups, the XCD-aware slice map, stream-K and the owner / contributor
-    split of round 4 -- hands every (tile, chunk) unit to exactly one workgroup.  For the owner / contributor split
-    (V3Params::oc_*) additionally, per tile: the contributors' pieces are the chunks [0, cown) cut at most once, the piece that
-    starts at chunk 0 is slab 0 and the other slab 1 (the kernel's rule), the counter word the owner polls ends at
-    (pieces << 16) + cown, every contributor has a lower workgroup number than every owner (waits point downwards), and an
-    owner runs at least as long as any contributor."""
+def test_w4a16_plans_cover_every_unit_once():
+    """Every launch plan of the pre-packed engine -- tile groups with an owner lead, the XCD-aware slice map of the split-K
+    partial launches, stream-K -- hands every (tile, chunk) unit to exactly one workgroup (the kernel's per-workgroup range
+    decode restated on the host plan, ``ll_w4a16_v3_plan``); a tile has at most ``slots`` contributing workgroups and every
+    contributor of a tile has a lower workgroup number than its owner (the merge waits point downwards only)."""
     from lite_llama_amd import _lib
 
     lib = _lib.lib()
     shapes = [(4608, 3584, 2), (3584, 3584, 2), (3584, 18944, 2), (37888, 3584, 1), (37888, 3584, 0), (4608, 3584, 0),
               (152064, 3584, 0), (2048, 1536, 0), (17920, 1536, 1)]
-    shapes += [(128 * t, 128 * c, 0) for t in (128, 131, 160, 200, 255) for c in (4, 7, 28, 37)]
+    shapes += [(128 * t, 128 * c, 0) for t in (1, 3, 28, 131, 160, 255, 300) for c in (1, 4, 7, 28, 37, 148)]
     shapes += [(256 * t, 128 * c, 1) for t in (128, 148, 191, 255) for c in (5, 28, 33)]
-    n_oc = 0
     for n, k, ep in shapes:
         pl = _v3_plan(lib, n, k, ep)
         assert pl["tiles"] * pl["nf"] * 128 == n and pl["chunks"] * 128 == k
         seen = {}
-        per_wg = {}
         for b in range(pl["grid"]):
-            segs = _v3_segments(pl, b)
-            per_wg[b] = sum(hi - lo + 1 for _, lo, hi in segs)
-            for t, lo, hi in segs:
+            for t, lo, hi in _v3_segments(pl, b):
                 assert 0 <= t < pl["tiles"] and 0 <= lo <= hi < pl["chunks"], (n, k, ep, b, t, lo, hi)
                 for c in range(lo, hi + 1):
                     assert (t, c) not in seen, (n, k, ep, b, t, c)
                     seen[(t, c)] = b
         assert len(seen) == pl["tiles"] * pl["chunks"], (n, k, ep, pl)
-        if not pl["oc_nc"]:
-            continue
-        n_oc += 1
-        nc, cown = pl["oc_nc"], pl["oc_cown"]
-        assert pl["grid"] == pl["cus"] == nc + pl["tiles"] and pl["slots"] == 2 and 1 <= cown < pl["chunks"]
         for t in range(pl["tiles"]):
-            pieces = sorted({(seen[(t, c)]) for c in range(cown)})
-            assert 1 <= len(pieces) <= 2 and all(b < nc for b in pieces)
-            counter, slots = 0, []
-            for b in pieces:
-                for tt, lo, hi in _v3_segments(pl, b):
-                    if tt == t:
-                        slots.append(0 if lo == 0 else 1)         # the kernel's slab rule
-                        counter += (hi - lo + 1) + 0x10000
-            assert sorted(slots) == list(range(len(pieces))) and counter == (len(pieces) << 16) + cown
-            assert {seen[(t, c)] for c in range(cown, pl["chunks"])} == {nc + t}
-        owner_units = pl["chunks"] - cown
-        assert max(per_wg[b] for b in range(nc)) <= owner_units, (n, k, pl)
-    assert n_oc >= 10
-    pl = _v3_plan(lib, 37888, 3584, 1)   # the headline gate|up launch: 148 owners + 108 contributors
-    assert (pl["oc_nc"], pl["oc_cown"], pl["nf"], pl["grid"]) == (108, 10, 2, 256), pl
+            owners = {seen[(t, pl["chunks"] - 1)]}
+            wgs = sorted({seen[(t, c)] for c in range(pl["chunks"])})
+            assert len(wgs) <= max(pl["slots"], 1), (n, k, ep, t, wgs, pl)
+            if ep != 2 and pl["xcd_shift"] < 0:
+                assert max(wgs) in owners, (n, k, ep, t, wgs)   # the owner is the highest-numbered workgroup of its tile
+    pl = _v3_plan(lib, 37888, 3584, 1)   # the headline gate|up launch: stream-K over 256-row tiles
+    assert (pl["nf"], pl["tiles"], pl["chunks"], pl["upw"], pl["grid"]) == (2, 148, 28, 17, 244), pl
