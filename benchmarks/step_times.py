@@ -8,13 +8,15 @@ from lite_llama_amd.quantization import QuantConfig
 
 steps = int(os.environ.get("STEPS", 60))
 geo = GEOMETRY[os.environ.get("MODEL", "qwen2.5-7b")]
-quant = QuantConfig.for_runtime_scheme("int4")
+quant = QuantConfig.for_runtime_scheme(os.environ.get("QUANT", "int4"))
+B = int(os.environ.get("BATCH", 64))
 with torch.device("cuda"):
     model = CausalLM(geo, quant)
 model.init_synthetic(seed=0, quant=quant, device="cuda")
-model.compact_weights()
-eng = DecodeEngine(model, max_batch=64, max_seq_len=512 + steps + 8, device="cuda")
-first = eng.synthetic_context(64, 512, seed=1)
+if hasattr(model, "compact_weights"):
+    model.compact_weights()
+eng = DecodeEngine(model, max_batch=B, max_seq_len=512 + steps + 8, device="cuda")
+first = eng.synthetic_context(B, 512, seed=1)
 if os.environ.get("IDLE"):
     torch.cuda.synchronize(); time.sleep(float(os.environ["IDLE"]))
 evs, host = [], []

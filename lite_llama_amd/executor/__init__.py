@@ -284,10 +284,6 @@ class DecodeEngine:
         """
         self._sampling = sampling  # None = greedy; else an object with temperature / top_p / repetition_penalty
         self._begin_decode(first_tokens, max_new_tokens)
-        # (the sticky device-side error words are also read BEFORE the first step: a stale error of an earlier run surfaces
-        # here, and the small reduction kernels the check launches are loaded outside anybody's timed region -- their
-        # first-use code-object load cost 5 - 20 ms at the end of a 20-step bench run once the check really ran, round 4)
-        self._check_device_errors()
         info = self.info
         final_len = info.max_actual_seq_len + max_new_tokens
         if final_len > self.max_seq_len:
@@ -305,6 +301,11 @@ class DecodeEngine:
                 self._step_body()
             torch.cuda.current_stream().wait_stream(s)
             self._restore(snap)
+            # The sticky device-side error words are read here once too, right after the eager warm-up step created the
+            # scratch they live in: a stale error of an earlier run surfaces before the run starts, and the check's first-use
+            # costs in a process (first device-to-host copy: several ms) are paid outside anybody's timed region -- at the end
+            # of a 32-step run they read as +0.2 ms per step (round 4).
+            self._check_device_errors()
             graph = torch.cuda.CUDAGraph()
             try:
                 with torch.cuda.graph(graph):
