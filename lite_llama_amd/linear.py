@@ -165,6 +165,11 @@ class MergedColumnLinear:
         first = self.layers[0]
         if not first.weight.is_cuda or torch.cuda.is_current_stream_capturing():
             return False
+        if any(getattr(l, "_w4_compact_member", None) is not None for l in self.layers):
+            # the members' `weight` parameters are views of the decode engine's layout, not reference rows: merging them again
+            # would permute garbage.  Somebody replaced a parameter of a compacted model.
+            raise RuntimeError("a parameter of a compacted merged projection was replaced: call model.expand_weights() before "
+                               "loading or assigning weights (CausalLM.compact_weights keeps only the decode engine's layout)")
         for l in self.layers:  # a member compacted on its own holds permuted words: merge reference-format rows only
             if getattr(l, "_w4_compact", False):
                 l.quant_method.expand(l)

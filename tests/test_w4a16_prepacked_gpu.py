@@ -362,6 +362,15 @@ def test_compacted_model_keeps_one_copy_of_the_int4_weights_and_the_same_numbers
         assert torch.equal(first1, first0) and torch.equal(toks1, toks0)
     again = eng_before.decode(eng_before.prefill(ids, lens), 6, use_graph=True)   # the engine whose graph was captured BEFORE
     assert torch.equal(again, toks0)
+    # replacing a parameter of a compacted model is refused loudly (its merged storage holds permuted words) ...
+    layer0 = model.layers[0].self_attn
+    keep = layer0.q_proj.weight
+    layer0.q_proj.weight = torch.nn.Parameter(ref_params["layers.0.self_attn.q_proj.weight"].clone(), requires_grad=False)
+    with pytest.raises(RuntimeError, match="expand_weights"):
+        prefill_logits()
+    layer0.q_proj._parameters["weight"] = keep
+    layer0._qkv._key = layer0._qkv._snapshot()
+    # ... after expand_weights() everything is the reference format again
     model.expand_weights()
     for k, v in model.named_parameters():
         assert torch.equal(v, ref_params[k]), k
