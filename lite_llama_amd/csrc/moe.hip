@@ -291,6 +291,9 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(const MoeParams p) {
 // row at a 2-KB stride (64 cache lines per load instruction, 2.3 TB/s on the Qwen3-30B-A3B expert stack).  The expert
 // stack is read exactly once per step whatever the routing, so this is the kernel's whole cost.  Same arithmetic, same
 // epilogue as the form above.
+#ifndef MOE_NT_W
+#define MOE_NT_W 1
+#endif
 template <int WFMT, int MT>
 __global__ __launch_bounds__(256) void moe_gemm_kernel2(const MoeParams p) {
   constexpr int EB = (WFMT == LL_W_F16) ? 2 : 1;        // bytes per weight element
@@ -351,7 +354,11 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel2(const MoeParams p) {
   i32x4 wreg[WPASS], areg[APASS];
   auto fetch = [&](int c) {
 #pragma unroll
-    for (int ps = 0; ps < WPASS; ++ps) wreg[ps] = *reinterpret_cast<const i32x4*>(wsrc[ps] + (int64_t)c * (128 * EB));
+    for (int ps = 0; ps < WPASS; ++ps) {
+      // the expert stack is read exactly once per step: non-temporal (MOE_NT_W; round 4, as the dense engines' big streams)
+      if constexpr (MOE_NT_W != 0) wreg[ps] = __builtin_nontemporal_load(reinterpret_cast<const i32x4*>(wsrc[ps] + (int64_t)c * (128 * EB)));
+      else wreg[ps] = *reinterpret_cast<const i32x4*>(wsrc[ps] + (int64_t)c * (128 * EB));
+    }
 #pragma unroll
     for (int ps = 0; ps < APASS; ++ps)  // rows without a token all re-read ONE piece (no traffic): their LDS rows are zeroed
       areg[ps] = *reinterpret_cast<const i32x4*>(aok[ps] ? asrc[ps] + c * 128 : p.a);
