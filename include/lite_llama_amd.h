@@ -127,7 +127,10 @@ int ll_flash_decoding(void* out, const void* q, const void* k_cache, const void*
  * tables [max_pos, >= d/2] of the q dtype (row stride given); positions int64 [batch].  k_cache /
  * v_cache are the (writable) pool views.  counters / mid_lse as for ll_flash_decoding's one-launch
  * form (required).  d >= 64 and hq/hkv <= 16, else LL_ERR_SHAPE; the select rows must be distinct
- * and already named by the table at position b_seq_len[b]-1. */
+ * and already named by the table at position b_seq_len[b]-1.
+ * q_norm_weight / k_norm_weight ([d], q dtype; both or both NULL; d == 128): Qwen3's per-head RMSNorm of q and of the new
+ * K heads (models/qwen3.py q_norm / k_norm; eps = norm_eps) applied in front of the rotation, with the values
+ * ll_skip_rmsnorm gives on the [.., d] views. */
 int ll_decode_attention(void* out, const void* q, const void* kv_new, int64_t kv_row_stride,
                         const void* cos_t, const void* sin_t, int64_t cs_row_stride,
                         const int64_t* positions, const void* select_index, int sel_width,
@@ -136,7 +139,8 @@ int ll_decode_attention(void* out, const void* q, const void* kv_new, int64_t kv
                         int d, int64_t max_len, float qk_scale, int64_t q_stride_b, int64_t q_stride_h,
                         int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
                         int64_t o_stride_b, int64_t o_stride_h, int64_t table_stride_b, int dtype,
-                        int req_width, int seq_width, int32_t* counters, void* stream);
+                        int req_width, int seq_width, int32_t* counters, const void* q_norm_weight,
+                        const void* k_norm_weight, float norm_eps, void* stream);
 
 /* ll_decode_attention whose q / k_new / v_new arrive as the fp32 split-K partials [s_count][batch][(hq + 2 hkv) * d] of the
  * fused q|k|v projection (ll_w4a16_matmul_prepacked epilogue 2) plus the projection bias (or NULL): every workgroup adds
@@ -148,7 +152,8 @@ int ll_decode_attention_partials(void* out, const float* qkv_partials, int s_cou
                                  const int32_t* table, const void* b_req_idx, const void* b_seq_len, int batch, int hq,
                                  int hkv, int d, int64_t max_len, float qk_scale, int64_t k_stride_t, int64_t k_stride_h,
                                  int64_t v_stride_t, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
-                                 int64_t table_stride_b, int dtype, int req_width, int seq_width, void* stream);
+                                 int64_t table_stride_b, int dtype, int req_width, int seq_width,
+                                 const void* q_norm_weight, const void* k_norm_weight, float norm_eps, void* stream);
 
 /* ---- a6: flash_attention2_no_pad  (kernels/flashattention2_nopad.py:175-231) --
  * Varlen causal prefill over freshly projected q/k/v (exp2 softmax; sm_scale

@@ -76,6 +76,10 @@ struct FdRope {
   int64_t qp_plane, qp_row;   // elements per partial, per batch row
   const uint16_t* qbias;      // [row_w] or nullptr
   float k_scale, v_scale;     // fp8 KV cache (KV8): stored value * scale = K / V value
+  // QKN (Qwen3): per-head RMSNorm of q and of the new K row BEFORE the rotation -- weights [D] of the q dtype
+  const uint16_t* qnw;
+  const uint16_t* knw;
+  float nrm_eps;
 };
 #define FD_QS_MAX 8
 
@@ -171,7 +175,49 @@ __device__ __forceinline__ void fd_fix_fragments(Q4 (&r)[4], bool hi) {
   r[3] = fd_sel(hi, k1, v1);
 }
 
-template <int DT, int D, bool FUSE, bool ROPE, int GS, bool GROUPED, bool KV8 = false>
+// QKN: the per-head RMSNorm Qwen3 applies to q (and to the new K row) between the projection and the rotation --
+// reference lite_llama/models/qwen3.py q_norm / k_norm -> kernels/skip_rmsnorm.py.  Same values as ll_skip_rmsnorm on the
+// [rows * heads, 128] view, bit for bit: thread tr of skip_rmsnorm_cached<TPR = 16> owns elements tr * 8 .. + 8, which is
+// fragment s, piece c of this lane (tr = 4 s + c); its xor butterfly over tr (8, 4, 2, 1) is fragments s ^ 2, s ^ 1, then
+// lanes ^ 32, ^ 16 -- reproduced in that order.  Head size 128 only.
+template <int DT>
+__device__ __forceinline__ float fd_ssq8(const Q4& v) {
+  const uint32_t w[4] = {v.x, v.y, v.z, v.w};
+  float p = 0.f;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const float lo = to_f32<DT>((uint16_t)w[i]), hi = to_f32<DT>((uint16_t)(w[i] >> 16));
+    p += lo * lo / 128.f;
+    p += hi * hi / 128.f;
+  }
+  return p;
+}
+template <int DT>
+__device__ __forceinline__ Q4 fd_scale8(const Q4& v, const Q4& wt, float rr) {
+  const uint32_t x[4] = {v.x, v.y, v.z, v.w}, w[4] = {wt.x, wt.y, wt.z, wt.w};
+  uint32_t o[4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    const uint16_t lo = mul_storage<DT>(from_f32<DT>(to_f32<DT>((uint16_t)x[i]) * rr), (uint16_t)w[i]);
+    const uint16_t hi = mul_storage<DT>(from_f32<DT>(to_f32<DT>((uint16_t)(x[i] >> 16)) * rr), (uint16_t)(w[i] >> 16));
+    o[i] = (uint32_t)lo | ((uint32_t)hi << 16);
+  }
+  return Q4{o[0], o[1], o[2], o[3]};
+}
+template <int DT>
+__device__ __forceinline__ void fd_head_norm(Q4 (&qf)[4], const Q4 (&wf)[4], float eps) {
+  const float p0 = fd_ssq8<DT>(qf[0]), p1 = fd_ssq8<DT>(qf[1]), p2 = fd_ssq8<DT>(qf[2]), p3 = fd_ssq8<DT>(qf[3]);
+  float v = (p0 + p2) + (p1 + p3);
+  auto a = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  const float rr = 1.0f / sqrtf(v + eps);
+#pragma unroll
+  for (int s = 0; s < 4; ++s) qf[s] = fd_scale8<DT>(qf[s], wf[s], rr);
+}
+
+template <int DT, int D, bool FUSE, bool ROPE, int GS, bool GROUPED, bool KV8 = false, bool QKN = false>
 __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     const int32_t* __restrict__ table, const void* __restrict__ b_req_idx,
@@ -184,6 +230,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
   constexpr int NT = D / 16;      // output d-tiles
   constexpr int VSTR = D + 8;     // padded LDS row stride (elements)
   static_assert(!KV8 || (DT == LL_F16 && !ROPE), "fp8 KV: fp16 queries, rope and the KV write happen before the launch");
+  static_assert(!QKN || (ROPE && D == 128), "q / k head norm: part of the one-launch decode form, head size 128");
   using KVR = typename FdKv<KV8>::Reg;
   using KVE = typename FdKv<KV8>::Elem;
   const KVE* kcE = reinterpret_cast<const KVE*>(kc);
@@ -311,6 +358,11 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
 
   constexpr int HS = ROPE ? NS / 2 : 1;
   Q4 cf[HS], sf[HS];
+  Q4 nwf[QKN ? NS : 1];
+  if constexpr (QKN) {
+#pragma unroll
+    for (int s = 0; s < NS; ++s) nwf[s] = *reinterpret_cast<const Q4*>(rp.qnw + s * 32 + c * 8);
+  }
   if constexpr (ROPE) {
     static_assert(!ROPE || NS >= 2, "the rotation partner must be another fragment of the same lane");
     const int64_t crow = rp.positions[b] * rp.cs_rs;
@@ -326,6 +378,44 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
       const int64_t dstrow = fd_load_idx(rp.sel, b, rp.sel_w);
       const uint16_t* kn = qpart ? q_lds + groups * D : rp.kv_new + b * rp.kv_rs + (int64_t)kvh * D;
       const uint16_t* vn = qpart ? q_lds + groups * D + D : rp.kv_new + b * rp.kv_rs + (int64_t)(hkv + kvh) * D;
+      if constexpr (QKN) {
+        // every lane takes part (the butterfly needs whole groups of 8 lanes); lanes >= D / 16 repeat lane & 7's work
+        const int j = (lane & (D / 16 - 1)) * 8;
+        U16x8 k1 = *reinterpret_cast<const U16x8*>(kn + j), k2 = *reinterpret_cast<const U16x8*>(kn + D / 2 + j);
+        const U16x8 cv = *reinterpret_cast<const U16x8*>(rp.cos_t + crow + j);
+        const U16x8 sv = *reinterpret_cast<const U16x8*>(rp.sin_t + crow + j);
+        const U16x8 w1 = *reinterpret_cast<const U16x8*>(rp.knw + j), w2 = *reinterpret_cast<const U16x8*>(rp.knw + D / 2 + j);
+        float pa = 0.f, pb = 0.f;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = to_f32<DT>(k1.v[e]), bb = to_f32<DT>(k2.v[e]);
+          pa += a * a / 128.f;
+          pb += bb * bb / 128.f;
+        }
+        float var = pa + pb;  // skip_rmsnorm_cached's butterfly: thread tr ^ 8 is this lane's other half, then lanes ^ 4, ^ 2, ^ 1
+        var += __shfl_xor(var, 4, 64);
+        var += __shfl_xor(var, 2, 64);
+        var += __shfl_xor(var, 1, 64);
+        const float rr = 1.0f / sqrtf(var + rp.nrm_eps);
+        U16x8 o1, o2;
+#pragma unroll
+        for (int e = 0; e < 8; ++e) {
+          const float a = to_f32<DT>(mul_storage<DT>(from_f32<DT>(to_f32<DT>(k1.v[e]) * rr), w1.v[e]));
+          const float bb = to_f32<DT>(mul_storage<DT>(from_f32<DT>(to_f32<DT>(k2.v[e]) * rr), w2.v[e]));
+          const float cc = to_f32<DT>(cv.v[e]), ss = to_f32<DT>(sv.v[e]);
+          o1.v[e] = from_f32<DT>(a * cc - bb * ss);
+          o2.v[e] = from_f32<DT>(bb * cc + a * ss);
+        }
+        if (lane < D / 16) {
+          uint16_t* pk = rp.pool_k + dstrow * k_st + (int64_t)kvh * k_sh;
+          *reinterpret_cast<U16x8*>(pk + j) = o1;
+          *reinterpret_cast<U16x8*>(pk + D / 2 + j) = o2;
+        } else if (lane < D / 16 + D / 8) {
+          const int jv = (lane - D / 16) * 8;
+          *reinterpret_cast<U16x8*>(rp.pool_v + dstrow * v_st + (int64_t)kvh * v_sh + jv) =
+              *reinterpret_cast<const U16x8*>(vn + jv);
+        }
+      } else
       if (lane < D / 16) {
         const int j = lane * 8;
         const U16x8 k1 = *reinterpret_cast<const U16x8*>(kn + j), k2 = *reinterpret_cast<const U16x8*>(kn + D / 2 + j);
@@ -516,6 +606,13 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
   KVR kaA[NS], kbA[NS], vaA[NS], vbA[NS], kaB[NS], kbB[NS], vaB[NS], vbB[NS];
   FD_LOAD(A, 0)
   FD_LOAD(B, 1)
+  if constexpr (QKN) {
+    fd_head_norm<DT>(qf, nwf, rp.nrm_eps);
+    if (!head_ok) {
+#pragma unroll
+      for (int s = 0; s < NS; ++s) qf[s] = Q4{0, 0, 0, 0};
+    }
+  }
   if constexpr (ROPE) {
     // (after the first gathers are in flight: the rotation only has to precede the first S^T)
 #pragma unroll
@@ -816,6 +913,8 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
   FdRope rp = rope ? *rope : FdRope{};
   rp.k_scale = k_scale;
   rp.v_scale = v_scale;
+  const bool qkn = rope && (rp.qnw || rp.knw);
+  if (qkn && (!rp.qnw || !rp.knw || d != 128 || kv8 || !(rp.nrm_eps >= 0.f))) return LL_ERR_SHAPE;
   const bool grouped_ok = fuse && nparts >= 2 && nparts <= FD_GROUP_MAX;
   // split-K partial inputs need the grouped form and two float4 slots per lane: (groups + 2) * d / 4 <= 2 * 64 * nparts
   static const bool ungrouped_env = getenv("LL_FD_UNGROUPED") != nullptr;  // A/B knob, read once
@@ -823,19 +922,19 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
     return LL_ERR_SHAPE;
   // one workgroup per (row, KV head group) with a wave per partition while the context fits FD_GROUP_MAX partitions
   const bool grouped = grouped_ok && !ungrouped_env;
-#define LL_FD1X(DD, FU, RO, GG, GR) LL_FD1XK(DD, FU, RO, GG, GR, false)
-#define LL_FD1XK(DD, FU, RO, GG, GR, K8)                                                             \
+#define LL_FD1X(DD, FU, RO, GG, GR) LL_FD1XK(DD, FU, RO, GG, GR, false, false)
+#define LL_FD1XK(DD, FU, RO, GG, GR, K8, QN)                                                            \
   {                                                                                                  \
     constexpr int tile_bytes_ = 32 * (DD + 8) * 2;                                                   \
     if (GR) {                                                                                        \
       static bool attr_ = false;                                                                     \
       if (!attr_) {                                                                                  \
-        (void)hipFuncSetAttribute((const void*)fd_stage1<DT, DD, FU, RO, GG, GR, K8>,                \
+        (void)hipFuncSetAttribute((const void*)fd_stage1<DT, DD, FU, RO, GG, GR, K8, QN>,             \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, FD_GROUP_MAX * tile_bytes_ + 18 * DD * 2); \
         attr_ = true;                                                                                \
       }                                                                                              \
     }                                                                                                \
-    fd_stage1<DT, DD, FU, RO, GG, GR, K8><<<(GR) ? dim3(1, grid.y, grid.z) : grid, (GR) ? 64 * nparts : 64, \
+    fd_stage1<DT, DD, FU, RO, GG, GR, K8, QN><<<(GR) ? dim3(1, grid.y, grid.z) : grid, (GR) ? 64 * nparts : 64, \
                                         ((GR) ? nparts : 1) * tile_bytes_ + ((GR) ? 18 * DD * 2 : 0), st>>>( \
         (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, table, req, seq, mid_o, mid_lse, hq, hkv, nparts, \
         scale, q_sb, q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w, (uint16_t*)out, o_sb, o_sh, counters, rp); \
@@ -857,8 +956,8 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
     if constexpr (DT == LL_F16) {
       if (rope || !fuse || (d != 64 && d != 128)) return LL_ERR_SHAPE;
 #define LL_FD8(DD, GG)                                   \
-  if (grouped) LL_FD1XK(DD, true, false, GG, true, true) \
-  else LL_FD1XK(DD, true, false, GG, false, true)
+  if (grouped) LL_FD1XK(DD, true, false, GG, true, true, false) \
+  else LL_FD1XK(DD, true, false, GG, false, true, false)
 #define LL_FD8G(DD)                  \
   if (groups <= 4) { LL_FD8(DD, 4) } \
   else if (groups <= 8) { LL_FD8(DD, 8) } \
@@ -870,6 +969,17 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
     } else {
       return LL_ERR_DTYPE;
     }
+  }
+  if (qkn) {
+    // one-launch decode form with the q / k head norm in front of the rotation (checked above: rope, d == 128)
+#define LL_FD1Q(GG)                                                      \
+  if (grouped) LL_FD1XK(128, true, true, GG, true, false, true)          \
+  else LL_FD1XK(128, true, true, GG, false, false, true)
+    if (groups <= 4) { LL_FD1Q(4) }
+    else if (groups <= 8) { LL_FD1Q(8) }
+    else { LL_FD1Q(16) }
+#undef LL_FD1Q
+    return LL_LAUNCH_CHECK();
   }
   switch (d) {
     case 32: LL_FD1D(32); break;
@@ -954,6 +1064,8 @@ extern "C" int ll_flash_decoding_fp8kv(void* out, const void* q, const void* k_c
 // k_cache / v_cache are written at row select_index[b].  Requires: counters (see ll_flash_decoding),
 // d >= 64, hq/hkv <= 16, cos/sin of the q dtype, distinct select rows, and
 // table[b_req_idx[b], b_seq_len[b]-1] == select_index[b].
+// q_norm_weight / k_norm_weight ([d], q dtype; both or neither, d == 128): Qwen3's per-head RMSNorm of q and of the
+// new K heads (eps = norm_eps) runs in front of the rotation -- the values of ll_skip_rmsnorm on the [.., d] views.
 extern "C" int ll_decode_attention(void* out, const void* q, const void* kv_new, int64_t kv_row_stride,
                                    const void* cos_t, const void* sin_t, int64_t cs_row_stride,
                                    const int64_t* positions, const void* select_index, int sel_width,
@@ -962,13 +1074,19 @@ extern "C" int ll_decode_attention(void* out, const void* q, const void* kv_new,
                                    int d, int64_t max_len, float qk_scale, int64_t q_stride_b, int64_t q_stride_h,
                                    int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t, int64_t v_stride_h,
                                    int64_t o_stride_b, int64_t o_stride_h, int64_t table_stride_b, int dtype,
-                                   int req_width, int seq_width, int32_t* counters, void* stream) {
+                                   int req_width, int seq_width, int32_t* counters, const void* q_norm_weight,
+                                   const void* k_norm_weight, float norm_eps, void* stream) {
   if (!kv_new || !cos_t || !sin_t || !positions || !select_index || !counters) return LL_ERR_ARG;
+  if ((q_norm_weight != nullptr) != (k_norm_weight != nullptr) || !ll_aligned16(q_norm_weight) || !ll_aligned16(k_norm_weight))
+    return LL_ERR_ARG;
   if (sel_width != LL_I32 && sel_width != LL_I64) return LL_ERR_DTYPE;
   if ((kv_row_stride | cs_row_stride) % 8 != 0 || !ll_aligned16(kv_new) || !ll_aligned16(cos_t) || !ll_aligned16(sin_t))
     return LL_ERR_ARG;
-  const FdRope rp{(const uint16_t*)kv_new, kv_row_stride, (const uint16_t*)cos_t, (const uint16_t*)sin_t, cs_row_stride,
-                  positions, select_index, sel_width, (uint16_t*)k_cache, (uint16_t*)v_cache, nullptr, 0, 0, 0, nullptr};
+  FdRope rp{(const uint16_t*)kv_new, kv_row_stride, (const uint16_t*)cos_t, (const uint16_t*)sin_t, cs_row_stride,
+            positions, select_index, sel_width, (uint16_t*)k_cache, (uint16_t*)v_cache, nullptr, 0, 0, 0, nullptr};
+  rp.qnw = (const uint16_t*)q_norm_weight;
+  rp.knw = (const uint16_t*)k_norm_weight;
+  rp.nrm_eps = norm_eps;
   return fd_entry(out, q, k_cache, v_cache, table, b_req_idx, b_seq_len, mid_o, mid_lse, batch, hq, hkv, d, max_len,
                   qk_scale, q_stride_b, q_stride_h, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_b,
                   o_stride_h, table_stride_b, dtype, req_width, seq_width, counters, &rp, stream);
@@ -986,16 +1104,23 @@ extern "C" int ll_decode_attention_partials(void* out, const float* qkv_partials
                                             const void* b_seq_len, int batch, int hq, int hkv, int d, int64_t max_len,
                                             float qk_scale, int64_t k_stride_t, int64_t k_stride_h, int64_t v_stride_t,
                                             int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
-                                            int64_t table_stride_b, int dtype, int req_width, int seq_width, void* stream) {
+                                            int64_t table_stride_b, int dtype, int req_width, int seq_width,
+                                            const void* q_norm_weight, const void* k_norm_weight, float norm_eps,
+                                            void* stream) {
   if (!qkv_partials || !cos_t || !sin_t || !positions || !select_index) return LL_ERR_ARG;
+  if ((q_norm_weight != nullptr) != (k_norm_weight != nullptr) || !ll_aligned16(q_norm_weight) || !ll_aligned16(k_norm_weight))
+    return LL_ERR_ARG;
   if (sel_width != LL_I32 && sel_width != LL_I64) return LL_ERR_DTYPE;
   if (cs_row_stride % 8 != 0 || !ll_aligned16(qkv_partials) || !ll_aligned16(cos_t) || !ll_aligned16(sin_t) || d % 4 != 0)
     return LL_ERR_ARG;
   const int64_t row_w = (int64_t)(hq + 2 * hkv) * d;
   static int32_t dummy_counters = 0;  // the grouped form never touches the counters; fd_entry only wants a non-null pointer
-  const FdRope rp{nullptr, 0, (const uint16_t*)cos_t, (const uint16_t*)sin_t, cs_row_stride, positions, select_index,
-                  sel_width, (uint16_t*)k_cache, (uint16_t*)v_cache, qkv_partials, s_count, (int64_t)batch * row_w, row_w,
-                  (const uint16_t*)qkv_bias};
+  FdRope rp{nullptr, 0, (const uint16_t*)cos_t, (const uint16_t*)sin_t, cs_row_stride, positions, select_index,
+            sel_width, (uint16_t*)k_cache, (uint16_t*)v_cache, qkv_partials, s_count, (int64_t)batch * row_w, row_w,
+            (const uint16_t*)qkv_bias};
+  rp.qnw = (const uint16_t*)q_norm_weight;
+  rp.knw = (const uint16_t*)k_norm_weight;
+  rp.nrm_eps = norm_eps;
   // q pointer / strides are unused in this mode; pass the pool (aligned, non-null) to satisfy the argument checks
   return fd_entry(out, k_cache, k_cache, v_cache, table, b_req_idx, b_seq_len, nullptr, nullptr, batch, hq, hkv, d, max_len,
                   qk_scale, 8, 8, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_b, o_stride_h, table_stride_b,

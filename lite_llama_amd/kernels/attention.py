@@ -133,18 +133,29 @@ def decode_attention_supported(q, kv, cos, n_kv_heads: int) -> bool:
 
 
 @torch.no_grad()
+def _head_norm_ok(qk_norm, head_dim: int, dtype) -> bool:
+    if qk_norm is None:
+        return True
+    qw, kw, _ = qk_norm
+    return (head_dim == 128 and all(w.dtype == dtype and w.is_contiguous() and w.numel() == head_dim and w.is_cuda
+                                    for w in (qw, kw)))
+
+
+@torch.no_grad()
 def decode_attention(q, kv, cos_table, sin_table, positions, select_index, kv_buffer, qk_scale, b_req_tokens_table,
-                     b_req_idx, b_seq_len, max_actual_seq_len):
+                     b_req_idx, b_seq_len, max_actual_seq_len, qk_norm=None):
     """Extension: ``rope_and_cache(q, kv, tables, positions)`` + ``flash_decoding(...)`` in ONE launch
     (same values).  ``q [B, Hq, D]`` un-rotated (left untouched), ``kv [B, 2*Hkv, D]`` this step's K
     heads then V heads (left untouched), ``kv_buffer [max_tokens, 2*Hkv, D]`` the layer's pool: row
-    ``select_index[b]`` receives the rotated K and the V.  Returns ``None`` when the shape is not
+    ``select_index[b]`` receives the rotated K and the V.  ``qk_norm = (q_weight, k_weight, eps)`` (Qwen3, head_dim 128):
+    the per-head RMSNorm of q and of the new K heads runs inside the launch, in front of the rotation, with the values
+    of ``skip_rmsnorm`` on the ``[.., D]`` views.  Returns ``None`` when the shape is not
     served or the merge counters cannot be set up (caller runs the two-call form)."""
     L.require_cuda(q, kv, cos_table, sin_table, positions, select_index, kv_buffer, b_req_tokens_table, b_req_idx,
                    b_seq_len)
     batchs, num_heads, head_dim = q.shape
     n_kv = kv.shape[1] // 2
-    if not decode_attention_supported(q, kv, cos_table, n_kv):
+    if not decode_attention_supported(q, kv, cos_table, n_kv) or not _head_norm_ok(qk_norm, head_dim, q.dtype):
         return None
     counters = _merge_counters(q.device, batchs * n_kv)
     positions = positions.reshape(-1)
@@ -167,7 +178,9 @@ def decode_attention(q, kv, cos_table, sin_table, positions, select_index, kv_bu
             b_seq_len.data_ptr(), mid_o.data_ptr(), mid_lse.data_ptr(), batchs, num_heads, n_kv, head_dim, max_len,
             float(qk_scale), q.stride(0), q.stride(1), k_cache.stride(0), k_cache.stride(1), v_cache.stride(0),
             v_cache.stride(1), out.stride(0), out.stride(1), b_req_tokens_table.stride(0), L.dtype_code(q.dtype),
-            L.index_width(b_req_idx), L.index_width(b_seq_len), counters.data_ptr(), L.stream_ptr(),
+            L.index_width(b_req_idx), L.index_width(b_seq_len), counters.data_ptr(),
+            L.ptr(None if qk_norm is None else qk_norm[0]), L.ptr(None if qk_norm is None else qk_norm[1]),
+            0.0 if qk_norm is None else float(qk_norm[2]), L.stream_ptr(),
         ),
         "decode_attention",
     )
@@ -184,11 +197,11 @@ def decode_attention_partials_supported(max_actual_seq_len, num_heads: int, num_
 @torch.no_grad()
 def decode_attention_partials(parts, bias, num_heads: int, num_kv_heads: int, head_dim: int, cos_table, sin_table,
                               positions, select_index, kv_buffer, qk_scale, b_req_tokens_table, b_req_idx, b_seq_len,
-                              max_actual_seq_len):
+                              max_actual_seq_len, qk_norm=None):
     """:func:`decode_attention` whose ``q | k | v`` come as the fp32 split-K partials of the fused projection
     (``PartialSums`` ``[S, B, (Hq + 2 Hkv) D]``, ``bias`` the projection bias or ``None``): every workgroup adds the
     partials of its (row, KV head) -- plus bias, one rounding to the pool dtype: the value the projection itself would
-    have stored -- and continues as ``decode_attention``.  Returns ``None`` when the shape is not served (contexts of
+    have stored -- and continues as ``decode_attention`` (``qk_norm`` as there).  Returns ``None`` when the shape is not served (contexts of
     129..1024 tokens, head_dim >= 64, <= 16 query heads per KV head): finish the sums and call ``decode_attention``."""
     p = parts.parts
     L.require_cuda(p, bias, cos_table, sin_table, positions, select_index, kv_buffer, b_req_tokens_table, b_req_idx, b_seq_len)
@@ -202,7 +215,8 @@ def decode_attention_partials(parts, bias, num_heads: int, num_kv_heads: int, he
             or cos_table.stride(0) != sin_table.stride(0) or cos_table.stride(0) % 8 != 0
             or positions.dtype != torch.int64 or not positions.is_contiguous() or positions.shape[0] != batchs
             or kv_buffer.stride(2) != 1 or b_req_tokens_table.dtype != torch.int32 or b_req_tokens_table.stride(1) != 1
-            or (bias is not None and (bias.dtype != dt or not bias.is_contiguous() or bias.numel() != row_w))):
+            or (bias is not None and (bias.dtype != dt or not bias.is_contiguous() or bias.numel() != row_w))
+            or not _head_norm_ok(qk_norm, head_dim, dt)):
         return None
     max_len = int(max_actual_seq_len)
     nparts = L.lib().ll_flash_decoding_num_partitions(max_len)
@@ -218,7 +232,8 @@ def decode_attention_partials(parts, bias, num_heads: int, num_kv_heads: int, he
             b_seq_len.data_ptr(), batchs, num_heads, num_kv_heads, head_dim, max_len, float(qk_scale),
             k_cache.stride(0), k_cache.stride(1), v_cache.stride(0), v_cache.stride(1), out.stride(0), out.stride(1),
             b_req_tokens_table.stride(0), L.dtype_code(dt), L.index_width(b_req_idx), L.index_width(b_seq_len),
-            L.stream_ptr(),
+            L.ptr(None if qk_norm is None else qk_norm[0]), L.ptr(None if qk_norm is None else qk_norm[1]),
+            0.0 if qk_norm is None else float(qk_norm[2]), L.stream_ptr(),
         ),
         "decode_attention_partials",
     )

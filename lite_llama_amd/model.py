@@ -261,7 +261,10 @@ class Attention(nn.Module):
         batch, seq_len, _ = x.shape
         x2 = x.view(-1, self.hidden_size)
         fp8_pool = atten_info.kv_buffer[layer_index].element_size() == 1  # extension: e4m3 KV cache, unfused route
-        if (seq_len == 1 and not self.use_qk_norm and not _TWO_CALL_ATTENTION and isinstance(position_embeddings, RopeTables)
+        # Qwen3: the per-head q / k RMSNorm rides inside the one-launch decode attention (head size 128)
+        qk_norm = (self.q_norm_weight, self.k_norm_weight, self.eps) if self.use_qk_norm else None
+        norm_fused = qk_norm is None or (self.head_dim == 128 and not os.environ.get("LL_NO_FUSED_QK_NORM"))
+        if (seq_len == 1 and norm_fused and not _TWO_CALL_ATTENTION and isinstance(position_embeddings, RopeTables)
                 and not fp8_pool and self._qkv.refresh() and not os.environ.get("LL_NO_QKV_PARTIALS")
                 and decode_attention_partials_supported(atten_info.max_actual_seq_len, self.num_heads, self.num_kv_heads,
                                                         self.head_dim)):
@@ -274,7 +277,7 @@ class Attention(nn.Module):
                                                 tables[1], tables[2], atten_info.cur_select_index,
                                                 atten_info.kv_buffer[layer_index], self.attn.scale,
                                                 atten_info.b_req_tokens_table, atten_info.b_req_idx, atten_info.b_seq_len,
-                                                atten_info.max_actual_seq_len)
+                                                atten_info.max_actual_seq_len, qk_norm=qk_norm)
                 if out is not None:
                     return self.o_proj(out.view(batch, seq_len, self.q_size), partials_ok)
                 # not served (context outside 129..1024 tokens, ...): finish the sums and take the ordinary route
@@ -291,21 +294,22 @@ class Attention(nn.Module):
         xq = xq.view(n, self.num_heads, self.head_dim)
         xkv = xkv.view(n, 2 * self.num_kv_heads, self.head_dim)
         xk, xv = xkv[:, : self.num_kv_heads], xkv[:, self.num_kv_heads :]
+        tables = position_embeddings if isinstance(position_embeddings, RopeTables) else None
+        dense_rows = xkv.stride(1) == self.head_dim and xq.stride(1) == self.head_dim and not fp8_pool
+        if dense_rows and norm_fused and tables is not None and seq_len == 1 and not _TWO_CALL_ATTENTION:
+            # decode: (q / k head norm +) rope + KV scatter + attention + partition merge in ONE launch
+            out = decode_attention(xq, xkv, tables[0], tables[1], tables[2], atten_info.cur_select_index,
+                                   atten_info.kv_buffer[layer_index], self.attn.scale, atten_info.b_req_tokens_table,
+                                   atten_info.b_req_idx, atten_info.b_seq_len, atten_info.max_actual_seq_len,
+                                   qk_norm=qk_norm)
+            if out is not None:
+                return self.o_proj(out.view(batch, seq_len, self.q_size), partials_ok)
         if self.use_qk_norm:
             xq, _ = skip_rmsnorm(xq, None, self.q_norm_weight, self.eps)
             xk, _ = skip_rmsnorm(xk, None, self.k_norm_weight, self.eps)
-        tables = position_embeddings if isinstance(position_embeddings, RopeTables) else None
-        fused = (not self.use_qk_norm and xkv.stride(1) == self.head_dim and xq.stride(1) == self.head_dim
-                 and not fp8_pool)
+        fused = not self.use_qk_norm and dense_rows
         if tables is not None and not fused:
             position_embeddings = tables.materialise()
-        if fused and tables is not None and seq_len == 1 and not _TWO_CALL_ATTENTION:
-            # decode: rope + KV scatter + attention + partition merge in ONE launch
-            out = decode_attention(xq, xkv, tables[0], tables[1], tables[2], atten_info.cur_select_index,
-                                   atten_info.kv_buffer[layer_index], self.attn.scale, atten_info.b_req_tokens_table,
-                                   atten_info.b_req_idx, atten_info.b_seq_len, atten_info.max_actual_seq_len)
-            if out is not None:
-                return self.o_proj(out.view(batch, seq_len, self.q_size), partials_ok)
         if fused and tables is not None:
             # rope (position-indexed tables) + KV scatter in one launch, in place
             rope_and_cache(xq, xkv, tables[0], tables[1], batch, seq_len, atten_info.cur_select_index,

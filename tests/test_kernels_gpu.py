@@ -406,6 +406,74 @@ def test_decode_attention_one_launch_equals_rope_cache_then_flash_decoding(hq, h
                             pool[:, :, :32].contiguous(), 0.2, table, req, seq, max(lens)) is None
 
 
+@pytest.mark.parametrize("hq,hkv,dtype", [(32, 4, torch.float16), (32, 8, torch.bfloat16), (16, 1, torch.float16)])
+@pytest.mark.parametrize("lens", [[1, 128, 129, 600, 333, 64, 2], [1030, 2049, 700, 5]], ids=["grouped", "counter-merge"])
+def test_decode_attention_with_head_norm_equals_skip_rmsnorm_then_the_launch(hq, hkv, dtype, lens):
+    """Qwen3 (models/qwen3.py q_norm / k_norm): the per-head RMSNorm of q and of the new K heads inside the one-launch decode
+    attention == skip_rmsnorm on the [.., 128] views, then the launch without it -- bit for bit, output AND pool rows; also
+    with q | k | v arriving as split-K partials."""
+    from lite_llama_amd.kernels.attention import decode_attention, decode_attention_partials
+    from lite_llama_amd.kernels.norm_act import PartialSums
+
+    torch.manual_seed(11)
+    d, b, eps = 128, len(lens), 1e-6
+    total = sum(lens)
+    pool = torch.randn(total + 64, 2 * hkv, d, device=DEV).to(dtype)
+    perm = torch.randperm(total, device=DEV).to(torch.int32)
+    table = torch.zeros(b, max(lens), dtype=torch.int32, device=DEV)
+    off = 0
+    for i, n in enumerate(lens):
+        table[i, :n] = perm[off:off + n]
+        off += n
+    seq = torch.tensor(lens, dtype=torch.int64, device=DEV)
+    req = torch.arange(b, dtype=torch.int64, device=DEV)
+    sel = table[req, seq - 1].contiguous()
+    pos = (seq - 1).clone()
+    inv = 1.0 / (1e6 ** (torch.arange(0, d, 2, device=DEV, dtype=torch.float32) / d))
+    fr = torch.arange(max(lens) + 8, device=DEV, dtype=torch.float32)[:, None] * inv[None, :]
+    emb = torch.cat([fr, fr], dim=-1)
+    cos, sin = emb.cos().to(dtype), emb.sin().to(dtype)
+    row_w = (hq + 2 * hkv) * d
+    # three planes whose sum is the projection output (+ bias): rows of very different magnitude exercise the statistic
+    planes = torch.randn(3, b, row_w, device=DEV) * torch.logspace(-2, 1, b, device=DEV)[None, :, None]
+    bias = (torch.randn(row_w, device=DEV) * 0.1).to(dtype)
+    proj = (planes[0] + planes[1] + planes[2] + bias.float()).to(dtype)
+    q, kv = proj[:, : hq * d].view(b, hq, d), proj[:, hq * d:].view(b, 2 * hkv, d)
+    qw = (1.0 + 0.3 * torch.randn(d, device=DEV)).to(dtype)
+    kw = (1.0 + 0.3 * torch.randn(d, device=DEV)).to(dtype)
+    scale = 1.0 / d ** 0.5
+
+    # reference route: two norm launches, then the one-launch attention without the norm
+    qn, _ = K().skip_rmsnorm(q.contiguous(), None, qw, eps)
+    kn, _ = K().skip_rmsnorm(kv[:, :hkv].contiguous(), None, kw, eps)
+    kvn = torch.cat([kn, kv[:, hkv:]], dim=1).contiguous()
+    pool_ref = pool.clone()
+    want = decode_attention(qn, kvn, cos, sin, pos, sel, pool_ref, scale, table, req, seq, max(lens))
+    assert want is not None
+
+    pool_one = pool.clone()
+    got = decode_attention(q, kv, cos, sin, pos, sel, pool_one, scale, table, req, seq, max(lens), qk_norm=(qw, kw, eps))
+    assert got is not None
+    assert torch.equal(pool_one, pool_ref)
+    assert torch.equal(got.view(torch.int16), want.view(torch.int16))
+    # it is the norm that ran (not the plain launch)
+    plain = decode_attention(q, kv, cos, sin, pos, sel, pool.clone(), scale, table, req, seq, max(lens))
+    assert not torch.equal(plain.view(torch.int16), want.view(torch.int16))
+
+    pool_p = pool.clone()
+    parts = PartialSums(planes.contiguous(), (b, row_w), dtype)
+    gp = decode_attention_partials(parts, bias, hq, hkv, d, cos, sin, pos, sel, pool_p, scale, table, req, seq, max(lens),
+                                   qk_norm=(qw, kw, eps))
+    if 2 <= -(-max(lens) // 128) <= 8:
+        assert gp is not None and torch.equal(pool_p, pool_ref)
+        assert torch.equal(gp.view(torch.int16), want.view(torch.int16))
+    else:
+        assert gp is None      # contexts beyond eight partitions: the caller finishes the sums
+    # head sizes other than 128 and mismatched weights are declined, not mis-served
+    assert decode_attention(q, kv, cos, sin, pos, sel, pool.clone(), scale, table, req, seq, max(lens),
+                            qk_norm=(qw.float(), kw.float(), eps)) is None
+
+
 # ------------------------------------------------------------------------------------- #
 # w4a16 (tol 5e-2; nibble unpack bit-exact)
 # ------------------------------------------------------------------------------------- #

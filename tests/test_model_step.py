@@ -389,6 +389,92 @@ def test_headline_shape_decode_layer_matches_oracle(B, CTX, expect_partials, mon
 
 
 @pytest.mark.gpu
+@pytest.mark.parametrize("quant,CTX,via_partials", [("fp8", 300, True), (None, 300, True), ("int4", 300, True), ("fp8", 1500, False)])
+def test_qwen3_shape_decode_layer_fuses_the_head_norm_and_matches_oracle(quant, CTX, via_partials, monkeypatch):
+    """Qwen3 attention geometry (32 / 4 heads of 128, q_norm / k_norm, no projection bias -- models/qwen3.py) at decode: the
+    per-head norms run INSIDE the one-launch attention (no norm / rope / cat / scatter launches), fed by the q|k|v split-K
+    partials while the context fits eight partitions -- against oracle/model.py with qk_norm on identical weights, and
+    against the unfused route (LL_NO_FUSED_QK_NORM: two norm launches, rope, KV scatter, flash_decoding)."""
+    from lite_llama_amd.model import CausalLM, tiny_geometry
+    from lite_llama_amd.quantization import QuantConfig
+    from oracle.model import OracleModel
+    import lite_llama_amd.model as M
+
+    H, I, L, HQ, HKV, D, V = 2048, 2048, 1, 32, 4, 128, 1024
+    B = 8
+    g = torch.Generator().manual_seed(99 + CTX)
+    geo = tiny_geometry(hidden_size=H, intermediate_size=I, num_layers=L, num_heads=HQ, num_kv_heads=HKV, head_dim=D,
+                        vocab_size=V, rope_theta=1000000.0, rms_norm_eps=1e-6, qkv_bias=False, use_qk_norm=True)
+    m = CausalLM(geo)
+    params = {}
+    for name, t in m.state_dict().items():
+        if name.endswith("norm_weight") or name.endswith("layernorm_weight"):
+            params[name] = (1 + 0.2 * torch.randn(t.shape, generator=g)).half()
+        else:
+            params[name] = (0.02 * torch.randn(t.shape, generator=g)).half()
+    m.load_state_dict(params, strict=True)
+    m = m.to("cuda")
+    if quant:
+        m.quantize_({"int4": QuantConfig.int4_groupwise(128), "fp8": QuantConfig.fp8_per_channel()}[quant])
+    m.rotary_emb.ensure(CTX + 8, "cuda")
+
+    rows = B * (CTX + 1)
+    kv_cpu = [(torch.randn(rows, 2 * HKV, D, generator=g) * 0.5).half() for _ in range(L)]
+    table = torch.arange(rows, dtype=torch.int32).view(B, CTX + 1)
+    ids = torch.randint(0, V, (B, 1), generator=g)
+    pos = torch.full((B, 1), CTX)
+
+    def info_on(dev, kv):
+        return types.SimpleNamespace(
+            kv_buffer=kv, cur_select_index=table[:, CTX].contiguous().to(dev), b_req_tokens_table=table.clone().to(dev),
+            b_start_loc=None, b_req_idx=torch.arange(B, dtype=torch.int32, device=dev),
+            b_seq_len=torch.full((B,), CTX + 1, dtype=torch.int32, device=dev), max_actual_seq_len=CTX + 1)
+
+    calls = {"attn_partials": 0, "attn": 0, "norm": 0}
+
+    def count(key, fn, need_norm):
+        def wrapped(*a, **k):
+            out = fn(*a, **k)
+            if out is not None and (not need_norm or k.get("qk_norm") is not None):
+                calls[key] += 1
+            return out
+        return wrapped
+
+    monkeypatch.setattr(M, "decode_attention_partials", count("attn_partials", M.decode_attention_partials, True))
+    monkeypatch.setattr(M, "decode_attention", count("attn", M.decode_attention, True))
+    real_norm = M.skip_rmsnorm
+
+    def norm_counted(x, r, w, eps):
+        calls["norm"] += int(w.numel() == D)     # the head norms (weights of one head's width)
+        return real_norm(x, r, w, eps)
+
+    monkeypatch.setattr(M, "skip_rmsnorm", norm_counted)
+    kv_gpu = [k.clone().cuda() for k in kv_cpu]
+    with torch.no_grad():
+        got = m(ids.cuda(), pos.cuda(), info_on("cuda", kv_gpu))
+    assert calls == {"attn_partials": int(via_partials), "attn": int(not via_partials), "norm": 0}, calls
+
+    monkeypatch.setenv("LL_NO_FUSED_QK_NORM", "1")
+    monkeypatch.setenv("LL_NO_QKV_PARTIALS", "1")
+    kv_two = [k.clone().cuda() for k in kv_cpu]
+    with torch.no_grad():
+        two = m(ids.cuda(), pos.cuda(), info_on("cuda", kv_two))
+    assert calls["norm"] == 2
+    new_rows = table[:, CTX].long()
+    # (the two routes add the projection's split-K planes in different orders: close, not equal -- the bit-for-bit statement
+    # on identical q | k | v is tests/test_kernels_gpu.py::test_decode_attention_with_head_norm_equals_...)
+    torch.testing.assert_close(kv_gpu[0][new_rows.cuda()].float(), kv_two[0][new_rows.cuda()].float(), rtol=1e-2, atol=1e-2)
+    torch.testing.assert_close(got.float(), two.float(), rtol=2e-2, atol=2e-2)
+
+    om = OracleModel({k: v.clone() for k, v in params.items()}, H, I, L, HQ, HKV, D, V, eps=geo.rms_norm_eps,
+                     rope_theta=geo.rope_theta, quant=quant, qk_norm=True)
+    kv_ref = [k.clone() for k in kv_cpu]
+    ref = om.forward(ids, pos, info_on("cpu", kv_ref))
+    torch.testing.assert_close(kv_gpu[0][new_rows.cuda()].float().cpu(), kv_ref[0][new_rows].float(), rtol=2e-2, atol=2e-2)
+    torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=3e-2, atol=3e-2)
+
+
+@pytest.mark.gpu
 def test_engine_sampling_path_graph_equals_eager():
     """Non-greedy decode through the sampler kernels inside the captured step: with a vanishing top_p the
     nucleus is the single most probable token, so the stochastic path must reproduce greedy decoding
