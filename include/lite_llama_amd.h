@@ -242,12 +242,31 @@ int ll_w8a8_matmul(void* out, const int8_t* qa, const float* a_scale, const int8
  * the other formats): partials [S][M][N] fp32 with the block scales applied, summed by the projection's consumer
  * (ll_skip_rmsnorm_partials, ll_decode_attention_partials) -- no finish launch.  wfmt: 1 fp8 e4m3 / 2 int8 (fp16
  * activations; scales as in ll_w8a16_matmul) / 4 fp16 / 5 bf16 weights (activations of the weight's type, scales NULL;
- * w_stride in elements).  ll_dense_partials_count: S for (shape, format, cap) -- 0 = not served; ll_dense_partials returns
+ * w_stride in elements) / 3 = smoothquant (x int8 rows quantised by the caller, w int8, scales NULL: the planes are exact
+ * int32 sums, consumed with the per-token / per-channel scales by ll_skip_rmsnorm_q8 / ll_w8a8_finish_swiglu).
+ * ll_dense_partials_count: S for (shape, format, cap) -- 0 = not served; ll_dense_partials returns
  * the S it wrote (the same number), 0 when alignment rules decline the call, < 0 on error. */
 int ll_dense_partials_count(int64_t m, int64_t n, int64_t k, int wfmt, int max_splits);
 int ll_dense_partials(float* partials, const void* x, const void* w, const float* scales, int64_t m, int64_t n, int64_t k,
                       int group_n, int64_t group_k, int wfmt, int64_t x_stride, int64_t w_stride, int64_t s_stride_n,
                       int64_t s_stride_k, int max_splits, void* stream);
+
+/* Decode-step fusions around smoothquant_matmul (csrc/w8a8_fused.hip; reference kernels/quantization/w8a8.py:28-217 + the
+ * skip_rmsnorm / swiglu launches between two W8A8 projections).
+ * ll_skip_rmsnorm_q8: skip_rmsnorm (fp16) whose input is EITHER x [rows][n] (planes NULL) OR the int32 planes
+ * [s_count][rows][n] of ll_dense_partials(wfmt 3) with a_scale [rows], w_scale [n], optional bias [n] (x NULL): the
+ * normalised input is then fp16(((float)sum * a_scale[m]) * w_scale[n] (+ bias)) -- what ll_w8a8_matmul stores.
+ * residual (updated in place) or NULL.  Outputs, each optional (not both NULL): y fp16 [rows][n]; q int8 [rows][n] +
+ * q_scale [rows] = ll_quantize_activations_int8(y).  Bit-identical to the separate launches.  n % 8 == 0, n <= 8192.
+ * ll_w8a8_finish_swiglu: out [m][n/2] = silu(gate) * up over the planes of a fused gate|up projection with interleaved
+ * rows (gate_j, up_j), gate / up finished as above. */
+int ll_skip_rmsnorm_q8(void* y, int8_t* q, float* q_scale, const void* x, const int32_t* planes, int s_count,
+                       const float* a_scale, const float* w_scale, const void* bias, void* residual, const void* weight,
+                       int64_t rows, int64_t n, float eps, void* stream);
+int ll_w8a8_finish_swiglu(void* out, const int32_t* planes, int s_count, const float* a_scale, const float* w_scale,
+                          int64_t m, int64_t n, void* stream);
+/* (internal dispatch target of ll_quantize_activations_int8: the row-in-registers quantiser; 1 launched / 0 declined) */
+int ll_quant_act_cached_try(int8_t* q, float* a_scale, const void* x, int64_t m, int64_t k, int64_t x_stride_m, void* stream);
 
 /* ---- unquantised 16-bit linears at decode shapes (models/quantization/methods/unquantized.py:21-22 and the lm_head of
  * models/base.py:486-489: torch F.linear, i.e. a vendor GEMM, in the reference) -------------------------------------------

@@ -53,6 +53,9 @@ SIGNATURES = {
     "ll_dense16_matmul": [P, P, P, P, L, L, L, L, L, I, P, P],
     "ll_dense_partials_count": [L, L, L, I, I],
     "ll_dense_partials": [P, P, P, P, L, L, L, I, L, I, L, L, L, L, I, P],
+    "ll_skip_rmsnorm_q8": [P, P, P, P, P, I, P, P, P, P, P, L, L, F, P],
+    "ll_w8a8_finish_swiglu": [P, P, I, P, P, L, L, P],
+    "ll_quant_act_cached_try": [P, P, P, L, L, L, P],
     "ll_w8a8_matmul": [P, P, P, P, P, P, L, L, L, L, P, P, P, P],
     "ll_moe_align_block_size": [P, I, L, I, I, P, P, P, P],
     "ll_moe_gemm": [P, P, P, P, P, P, P, P, L, L, I, L, L, I, I, I, I, L, L, L, L, L, L, L, I, P],

@@ -407,12 +407,14 @@ extern "C" int ll_dense16_matmul(void* out, const void* x, const void* w, const 
 // leaves its fp32 partial planes [S][M][N] -- block scales already applied (a9) / plain products (16-bit) -- for the
 // consumer of the projection to add up: ll_skip_rmsnorm_partials after a row-parallel projection, ll_decode_attention_partials
 // after the fused q|k|v one.  No dense8_finish launch, no second pass over the output.  wfmt: 1 fp8 e4m3, 2 int8 (fp16
-// activations, block scales), 4 fp16, 5 bf16 weights (activations of the same type).  Not for a10 (int32 planes need the
-// per-token scales first).  Returns the number of planes written (>= 1), 0 when the shape is not served, < 0 on error.
+// activations, block scales), 4 fp16, 5 bf16 weights (activations of the same type); 3 = a10 (int8 activations, quantised by
+// the caller, x int8 weights): the planes are then EXACT int32 sums that still need a_scale[m] * w_scale[n] -- consumers:
+// ll_skip_rmsnorm_q8, ll_w8a8_finish_swiglu (w8a8_fused.hip).  Returns the number of planes written (>= 1), 0 when the
+// shape is not served, < 0 on error.
 // ---------------------------------------------------------------------------------------------------------------- //
 extern "C" int ll_dense_partials_count(int64_t m, int64_t n, int64_t k, int wfmt, int max_splits) {
   const bool w16 = wfmt == D8_F16 || wfmt == D8_BF16;
-  if (wfmt != D8_FP8 && wfmt != D8_I8 && !w16) return 0;
+  if (wfmt != D8_FP8 && wfmt != D8_I8 && wfmt != D8_I8I8 && !w16) return 0;
   const int kch = w16 ? 64 : 128;
   if (m < 1 || m > 64 || n < 4 || n % 4 != 0 || k < kch || k % kch != 0 || max_splits < 1) return 0;
   const int chunks = (int)(k / kch);
@@ -427,10 +429,12 @@ extern "C" int ll_dense_partials(float* partials, const void* x, const void* w, 
   const bool w16 = wfmt == D8_F16 || wfmt == D8_BF16;
   const int used = ll_dense_partials_count(m, n, k, wfmt, max_splits);
   if (used == 0) return 0;
-  if (!partials || !x || !w || (!w16 && !scales)) return LL_ERR_ARG;
+  const bool i8a = wfmt == D8_I8I8;
+  if (!partials || !x || !w || (!w16 && !i8a && !scales)) return LL_ERR_ARG;
   const int eb = w16 ? 2 : 1;
-  if ((w_stride * eb) % 16 != 0 || x_stride % 8 != 0 || !ll_aligned16(w) || !ll_aligned16(x) || !ll_aligned16(partials)) return 0;
-  if (!w16 && group_k < k && group_k % 64 != 0) return 0;
+  if ((w_stride * eb) % 16 != 0 || x_stride % (i8a ? 16 : 8) != 0 || !ll_aligned16(w) || !ll_aligned16(x) || !ll_aligned16(partials))
+    return 0;
+  if (!w16 && !i8a && group_k < k && group_k % 64 != 0) return 0;
   D8Params p{};
   p.part = partials; p.x = x; p.w = (const unsigned char*)w; p.scales = scales;
   p.m = m; p.n = n; p.k = k; p.x_stride = x_stride; p.w_stride = w_stride * eb;
@@ -448,6 +452,7 @@ extern "C" int ll_dense_partials(float* partials, const void* x, const void* w, 
   else dense8_kernel<WF, 1><<<grid, 256, 0, st>>>(p)
   if (wfmt == D8_FP8) { LL_D8P(D8_FP8); }
   else if (wfmt == D8_I8) { LL_D8P(D8_I8); }
+  else if (wfmt == D8_I8I8) { LL_D8P(D8_I8I8); }
   else if (wfmt == D8_F16) { LL_D8P(D8_F16); }
   else { LL_D8P(D8_BF16); }
 #undef LL_D8P

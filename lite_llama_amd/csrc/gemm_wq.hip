@@ -787,10 +787,14 @@ __global__ __launch_bounds__(256) void quant_act_kernel(int8_t* __restrict__ q, 
   if (threadIdx.x == 0) a_scale[row] = scale;
 }
 
+extern "C" int ll_quant_act_cached_try(int8_t* q, float* a_scale, const void* x, int64_t m, int64_t k, int64_t x_stride_m,
+                                       void* stream);
 extern "C" int ll_quantize_activations_int8(int8_t* q, float* a_scale, const void* x, int64_t m, int64_t k,
                                             int64_t x_stride_m, void* stream) {
   if (m < 0 || k <= 0) return LL_ERR_SHAPE;
   if (m == 0) return LL_OK;
+  // decode-sized rows: one pass with the row in registers (w8a8_fused.hip); anything else: the two-pass kernel above
+  if (const int rc = ll_quant_act_cached_try(q, a_scale, x, m, k, x_stride_m, stream)) return rc < 0 ? rc : LL_OK;
   quant_act_kernel<<<dim3((unsigned)m), 256, 0, (hipStream_t)stream>>>(q, a_scale, (const uint16_t*)x, k,
                                                                         x_stride_m);
   return LL_LAUNCH_CHECK();

@@ -208,7 +208,7 @@ def decode_attention_partials(parts, bias, num_heads: int, num_kv_heads: int, he
     s_count, batchs, row_w = p.shape
     dt = kv_buffer.dtype
     positions = positions.reshape(-1)
-    if (row_w != (num_heads + 2 * num_kv_heads) * head_dim or head_dim < 64 or head_dim % 32 or num_heads % num_kv_heads
+    if (p.dtype != torch.float32 or row_w != (num_heads + 2 * num_kv_heads) * head_dim or head_dim < 64 or head_dim % 32 or num_heads % num_kv_heads
             or num_heads // num_kv_heads > 16 or s_count > 8 or not p.is_contiguous() or parts.dtype != dt
             or dt not in (torch.float16, torch.bfloat16) or cos_table.dtype != dt or sin_table.dtype != dt
             or cos_table.dim() != 2 or cos_table.stride(1) != 1 or sin_table.stride(1) != 1

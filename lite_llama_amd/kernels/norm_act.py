@@ -70,6 +70,109 @@ class PartialSums:
         return out
 
 
+class Int8Rows:
+    """Activations already through smoothquant's per-token quantiser (``quantize_activations_int8``): ``q`` int8
+    ``[rows, k]``, ``scale`` fp32 ``[rows]``; ``shape`` is the logical (fp16) tensor's.  Produced by
+    :func:`skip_rmsnorm_q8` (the quantiser fused into the norm launch) and accepted by ``smoothquant_matmul`` and the
+    W8A8 linear method in place of the fp16 tensor (decode-step extension; reference w8a8.py:34-68 runs the quantiser as a
+    launch of its own in front of every projection)."""
+
+    __slots__ = ("q", "scale", "shape")
+    dtype = torch.float16
+    is_cuda = True
+
+    def __init__(self, q: torch.Tensor, scale: torch.Tensor, shape):
+        self.q, self.scale, self.shape = q, scale, tuple(shape)
+
+    @property
+    def device(self):
+        return self.q.device
+
+    def view(self, *shape):
+        """Only re-groupings of the leading dimensions (the rows stay rows)."""
+        shape = tuple(shape[0]) if len(shape) == 1 and isinstance(shape[0], (tuple, list, torch.Size)) else tuple(shape)
+        if shape[-1] != self.shape[-1]:
+            raise ValueError("Int8Rows.view keeps the last dimension")
+        lead = shape[:-1]
+        if -1 in lead:
+            known = 1
+            for d in lead:
+                known *= d if d != -1 else 1
+            lead = tuple(self.q.shape[0] // known if d == -1 else d for d in lead)
+        return Int8Rows(self.q, self.scale, (*lead, shape[-1]))
+
+    def numel(self):
+        return self.q.numel()
+
+
+class ScaledInt32Partials(PartialSums):
+    """:class:`PartialSums` of a smoothquant projection: ``parts`` are EXACT int32 split-K sums ``[S, rows, n]`` that still
+    need ``* a_scale[m] * w_scale[n] (+ bias)`` -- consumed by :func:`skip_rmsnorm_q8`."""
+
+    __slots__ = ("a_scale", "w_scale", "bias")
+
+    def __init__(self, parts, shape, a_scale, w_scale, bias=None):
+        super().__init__(parts, shape, torch.float16)
+        self.a_scale, self.w_scale, self.bias = a_scale, w_scale, bias
+
+    def materialise(self) -> torch.Tensor:
+        acc = self.parts.sum(0, dtype=torch.int32).float()
+        out = (acc * self.a_scale[:, None]) * self.w_scale[None, :]
+        if self.bias is not None:
+            out = out + self.bias.float()
+        return out.to(self.dtype).view(self.shape)
+
+
+@torch.no_grad()
+def skip_rmsnorm_q8(X, residual, weight, eps=1e-5, *, quantize: bool = True, keep_y: bool = False):
+    """:func:`skip_rmsnorm` of a smoothquant block in ONE launch (csrc/w8a8_fused.hip): ``X`` is an fp16 tensor or the
+    :class:`ScaledInt32Partials` of the previous W8A8 projection (its scale epilogue runs here); with ``quantize`` the
+    normalised rows leave as :class:`Int8Rows` for the next W8A8 projection -- the values of ``dense8_finish`` ->
+    ``skip_rmsnorm`` -> ``quantize_activations_int8``, bit for bit.  Returns ``(Int8Rows | Y, residual)``; ``keep_y`` also
+    stores the fp16 ``Y`` and returns ``((Int8Rows, Y), residual)``."""
+    planes = X if isinstance(X, ScaledInt32Partials) else None
+    if planes is not None:
+        s, m, n = X.parts.shape
+        shape = X.shape
+        dev = X.parts.device
+        if residual is None:
+            raise ValueError("skip_rmsnorm_q8 over partials needs a residual")
+    else:
+        if X.dtype != torch.float16:
+            raise ValueError("skip_rmsnorm_q8 is the fp16 smoothquant route")
+        shape = X.shape
+        X = X.contiguous().view(-1, shape[-1])
+        m, n = X.shape
+        s, dev = 0, X.device
+    _check_row(n)
+    if n % 8 or n > 8192:
+        raise ValueError(f"skip_rmsnorm_q8: row width {n} outside the fused launch (n % 8 == 0, n <= 8192)")
+    if residual is not None:
+        residual = residual.contiguous().view(-1, n)
+        if residual.shape[0] != m or residual.dtype != torch.float16:
+            raise ValueError("residual must be fp16 [rows, n]")
+    weight = weight.to(torch.float16).contiguous()
+    L.require_cuda(weight, residual)
+    want_y = keep_y or not quantize
+    Y = torch.empty((m, n), dtype=torch.float16, device=dev) if want_y else None
+    q = torch.empty((m, n), dtype=torch.int8, device=dev) if quantize else None
+    qs = torch.empty((m,), dtype=torch.float32, device=dev) if quantize else None
+    L.check(
+        L.lib().ll_skip_rmsnorm_q8(L.ptr(Y), L.ptr(q), L.ptr(qs), 0 if planes is not None else X.data_ptr(),
+                                   planes.parts.data_ptr() if planes is not None else 0, s,
+                                   planes.a_scale.data_ptr() if planes is not None else 0,
+                                   planes.w_scale.data_ptr() if planes is not None else 0,
+                                   L.ptr(planes.bias) if planes is not None else 0, L.ptr(residual), weight.data_ptr(), m, n,
+                                   float(eps), L.stream_ptr()),
+        "skip_rmsnorm_q8",
+    )
+    res_out = residual.view(shape) if residual is not None else X.view(shape)
+    rows = Int8Rows(q, qs, shape) if quantize else None
+    if quantize and keep_y:
+        return (rows, Y.view(shape)), res_out
+    return (rows if quantize else Y.view(shape)), res_out
+
+
 @torch.no_grad()
 def skip_rmsnorm_partials(X: PartialSums, residual, weight, eps=1e-5):
     """:func:`skip_rmsnorm` over a :class:`PartialSums` input: ``x = fp16(sum of the partials)`` -- the value the

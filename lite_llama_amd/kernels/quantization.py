@@ -281,21 +281,29 @@ def smoothquant_matmul(
     bias: torch.Tensor | None = None,
     _return_int32: bool = False,
 ) -> torch.Tensor:
-    """Dynamic per-token W8A8: int8 x int8 -> int32 (exact) -> ``* a_scale[m] * w_scale[n]``."""
-    if x.dtype != torch.float16:
+    """Dynamic per-token W8A8: int8 x int8 -> int32 (exact) -> ``* a_scale[m] * w_scale[n]``.  ``x``: fp16, or rows already
+    through the quantiser (``kernels.norm_act.Int8Rows``)."""
+    from .norm_act import Int8Rows
+    pre = x if isinstance(x, Int8Rows) else None
+    if pre is None and x.dtype != torch.float16:
         raise ValueError(f"smoothquant activations must be fp16, got {x.dtype}")
     if qweight.dtype != torch.int8:
         raise ValueError(f"qweight must be int8, got {qweight.dtype}")
     n, k = qweight.shape
     if x.shape[-1] != k:
         raise ValueError(f"x has {x.shape[-1]} cols but weight expects {k}")
-    L.require_cuda(x, qweight, weight_scales, bias)
+    L.require_cuda(qweight, weight_scales, bias)
     leading = x.shape[:-1]
-    a = x.reshape(-1, k)
-    if a.stride(-1) != 1:
-        a = a.contiguous()
-    m = a.shape[0]
-    qa, a_scale = quantize_activations_int8(a)
+    if pre is not None:
+        qa, a_scale = pre.q, pre.scale
+        m = qa.shape[0]
+    else:
+        L.require_cuda(x)
+        a = x.reshape(-1, k)
+        if a.stride(-1) != 1:
+            a = a.contiguous()
+        m = a.shape[0]
+        qa, a_scale = quantize_activations_int8(a)
     if weight_scales.dim() > 1:
         weight_scales = weight_scales.squeeze(-1)
     weight_scales = weight_scales.float().contiguous()
@@ -303,9 +311,9 @@ def smoothquant_matmul(
         qweight = qweight.contiguous()
     if bias is not None and bias.dtype != torch.float16:
         bias = bias.half()
-    out = torch.empty((m, n), dtype=x.dtype, device=x.device)
-    acc = torch.empty((m, n), dtype=torch.int32, device=x.device) if _return_int32 else None
-    ws, cnt = L.gemm_workspace(x.device, m, n, k)
+    out = torch.empty((m, n), dtype=torch.float16, device=qa.device)
+    acc = torch.empty((m, n), dtype=torch.int32, device=qa.device) if _return_int32 else None
+    ws, cnt = L.gemm_workspace(qa.device, m, n, k)
     L.check(
         L.lib().ll_w8a8_matmul(
             out.data_ptr(), qa.data_ptr(), a_scale.data_ptr(), qweight.data_ptr(),
@@ -318,6 +326,79 @@ def smoothquant_matmul(
     if _return_int32:
         return out, acc, qa, a_scale
     return out
+
+
+def _w8a8_planes(x, qweight, max_splits: int):
+    """int32 split-K planes of ``x @ qweight.T`` at decode shapes (``ll_dense_partials`` wfmt 3) + the activation scales;
+    ``None`` when the engine does not take the call."""
+    from .norm_act import Int8Rows
+    n, k = qweight.shape
+    if qweight.dtype != torch.int8 or qweight.stride(1) != 1 or x.shape[-1] != k or os.environ.get("LL_W8A8_NO_PARTIALS", "0") == "1":
+        return None
+    if isinstance(x, Int8Rows):
+        qa, a_scale = x.q, x.scale
+    else:
+        if not x.is_cuda or x.dtype != torch.float16:
+            return None
+        a = x.reshape(-1, k)
+        if a.stride(-1) != 1:
+            a = a.contiguous()
+        if a.shape[0] < 1 or a.shape[0] > 64:
+            return None
+        qa, a_scale = quantize_activations_int8(a)
+    m = qa.shape[0]
+    if m < 1 or m > 64:
+        return None
+    s = L.lib().ll_dense_partials_count(m, n, k, 3, int(max_splits))
+    if s < 1:
+        return None
+    parts = torch.empty((s, m, n), dtype=torch.int32, device=qa.device)
+    rc = L.lib().ll_dense_partials(parts.data_ptr(), qa.data_ptr(), qweight.data_ptr(), 0, m, n, k, 1, k, 3, qa.stride(0),
+                                   qweight.stride(0), 0, 0, int(max_splits), L.stream_ptr())
+    if rc == 0:
+        return None
+    if rc != s:
+        L.check(rc if rc < 0 else -1, "smoothquant_matmul_partials")
+    return parts, a_scale
+
+
+def _w8a8_scales(weight_scales):
+    if weight_scales.dim() > 1:
+        weight_scales = weight_scales.squeeze(-1)
+    return weight_scales.float().contiguous()
+
+
+def smoothquant_matmul_partials(x, qweight, weight_scales, *, bias=None, max_splits: int = 12):
+    """Decode-step extension: :func:`smoothquant_matmul` left as exact int32 split-K planes + scales
+    (``ScaledInt32Partials``) for ``skip_rmsnorm_q8`` -- no finish launch.  ``x``: fp16 or ``Int8Rows``.  ``None`` when
+    not served (more than 64 rows, shapes off the engine's grid)."""
+    from .norm_act import ScaledInt32Partials
+    got = _w8a8_planes(x, qweight, min(max_splits, int(os.environ.get("LL_W8A8_SPLITS", max_splits))))
+    if got is None:
+        return None
+    if bias is not None and bias.dtype != torch.float16:
+        bias = bias.half()
+    return ScaledInt32Partials(got[0], (*x.shape[:-1], qweight.shape[0]), got[1], _w8a8_scales(weight_scales), bias)
+
+
+def smoothquant_gate_up_swiglu(x, qweight, weight_scales, *, max_splits: int = 16):
+    """``silu(gate) * up`` of a fused gate|up smoothquant projection whose rows are interleaved ``(gate_j, up_j)``: the int8
+    GEMM leaves int32 planes and ONE element-wise launch applies the scale epilogue and the activation (instead of finish +
+    swiglu).  Same values as ``swiglu_forward(*smoothquant_matmul(x, ...).unflatten(-1, (-1, 2)).unbind(-1))``.  ``None``
+    when not served."""
+    n = qweight.shape[0]
+    if n % 4:
+        return None
+    got = _w8a8_planes(x, qweight, max_splits)
+    if got is None:
+        return None
+    parts, a_scale = got
+    s, m, _ = parts.shape
+    out = torch.empty((m, n // 2), dtype=torch.float16, device=parts.device)
+    L.check(L.lib().ll_w8a8_finish_swiglu(out.data_ptr(), parts.data_ptr(), s, a_scale.data_ptr(),
+                                          _w8a8_scales(weight_scales).data_ptr(), m, n, L.stream_ptr()),
+            "smoothquant_gate_up_swiglu")
+    return out.view(*x.shape[:-1], n // 2)
 
 
 def dense_matmul_partials(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor | None = None, *, group_n: int = 1,

@@ -25,7 +25,7 @@ import torch.nn.functional as F
 from .distributed.parallel_state import all_reduce_tp, divide, get_tp_rank, get_tp_world_size
 from .distributed.partition import ShardPlan, make_plan, scale_unit, set_active_plan
 from .kernels.attention import decode_attention, decode_attention_partials, decode_attention_partials_supported
-from .kernels.norm_act import PartialSums, rope_and_cache, skip_rmsnorm_partials
+from .kernels.norm_act import Int8Rows, PartialSums, ScaledInt32Partials, rope_and_cache, skip_rmsnorm_partials, skip_rmsnorm_q8
 from .kernels import (
     flash_attention2_no_pad,
     flash_decoding,
@@ -186,6 +186,7 @@ class RotaryEmbedding(nn.Module):
 # ------------------------------------------------------------------------------------- #
 # A/B knob for measurements: keep rope + KV scatter and flash_decoding as two launches
 _TWO_CALL_ATTENTION = os.environ.get("LL_TWO_CALL_ATTENTION", "0") == "1"
+_Q8_FUSION = os.environ.get("LL_NO_Q8_FUSION", "0") != "1"  # smoothquant: quantiser inside the norm launch (A/B knob)
 
 
 class PagedAttention(nn.Module):
@@ -330,8 +331,23 @@ class Attention(nn.Module):
         return self.o_proj(out.view(batch, seq_len, self.q_size))
 
 
-def add_norm(hidden_states, residual, weight, eps):
-    """``skip_rmsnorm`` that also accepts a projection left as split-K partials (kernels/norm_act.py::PartialSums)."""
+def _takes_int8_rows(*linears) -> bool:
+    """Whether every one of these projections reads smoothquant-quantised rows (so the norm in front of them can run the
+    per-token quantiser itself and hand over ``Int8Rows``)."""
+    return _Q8_FUSION and all(getattr(l.quant_method, "takes_int8_rows", False) for l in linears)
+
+
+def add_norm(hidden_states, residual, weight, eps, q8: bool = False):
+    """``skip_rmsnorm`` that also accepts a projection left as split-K partials (kernels/norm_act.py::PartialSums).
+    ``q8`` (smoothquant blocks): the consumer reads per-token int8 rows -- the quantiser runs inside the norm launch and the
+    result is an ``Int8Rows``."""
+    if isinstance(hidden_states, ScaledInt32Partials):
+        if hidden_states.parts.shape[2] % 8 == 0 and hidden_states.parts.shape[2] <= 8192:
+            return skip_rmsnorm_q8(hidden_states, residual, weight, eps, quantize=q8)
+        hidden_states = hidden_states.materialise()
+    if (q8 and torch.is_tensor(hidden_states) and hidden_states.is_cuda and hidden_states.dtype == torch.float16
+            and hidden_states.shape[-1] % 8 == 0 and hidden_states.shape[-1] <= 8192):
+        return skip_rmsnorm_q8(hidden_states, residual, weight, eps)
     if isinstance(hidden_states, PartialSums):
         return skip_rmsnorm_partials(hidden_states, residual, weight, eps)
     return skip_rmsnorm(hidden_states, residual, weight, eps)
@@ -431,9 +447,12 @@ class DecoderLayer(nn.Module):
     def forward(self, hidden_states, atten_info, layer_index, position_embeddings, residual=None):
         """``hidden_states`` in and out may be a :class:`PartialSums` (decode, int4, TP = 1): the row-parallel
         projections leave fp32 split-K partials and the add-and-normalise that follows adds them up."""
-        hidden_states, residual = add_norm(hidden_states, residual, self.input_layernorm_weight, self.eps)
+        hidden_states, residual = add_norm(hidden_states, residual, self.input_layernorm_weight, self.eps,
+                                           q8=_takes_int8_rows(self.self_attn.q_proj, self.self_attn.kv_proj))
         hidden_states = self.self_attn(hidden_states, atten_info, layer_index, position_embeddings, partials_ok=True)
-        hidden_states, residual = add_norm(hidden_states, residual, self.post_attention_layernorm_weight, self.eps)
+        hidden_states, residual = add_norm(hidden_states, residual, self.post_attention_layernorm_weight, self.eps,
+                                           q8=isinstance(self.mlp, FusedMLP)
+                                           and _takes_int8_rows(self.mlp.gate_proj, self.mlp.up_proj))
         if isinstance(self.mlp, FusedMLP):
             hidden_states = self.mlp(hidden_states, partials_ok=True)
         else:

@@ -15,6 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..kernels import fused_moe, smoothquant_matmul, w4a16_matmul, w8a16_matmul
+from ..kernels.quantization import smoothquant_gate_up_swiglu, smoothquant_matmul_partials
 from ..kernels.quantization import (dense16_linear, dense_matmul_partials, pack_w4a16_scales, pack_w4a16_weights, unpack_w4a16_weights, w4a16_matmul_partials,
                                     w4a16_matmul_prepacked, w4a16_prepacked_supported)
 from .config import FP8, INT4, INT8, SMOOTHQUANT, QuantConfig
@@ -265,8 +266,23 @@ class SmoothQuantLinearMethod(LinearQuantMethod):
         layer.weight = RawParameter(torch.empty(output_size, input_size, dtype=q.storage_dtype))
         layer.weight_scale_inv = RawParameter(torch.empty(*q.scale_shape(output_size, input_size), dtype=torch.float32))
 
+    takes_int8_rows = True  # ``apply`` accepts kernels.norm_act.Int8Rows (the quantiser fused into the producing launch)
+
     def apply(self, layer, x):
         return smoothquant_matmul(x, layer.weight, layer.weight_scale_inv, bias=layer.bias)
+
+    def apply_partials(self, layer, x, allow_bias: bool = False, max_splits: int = 12):
+        """Decode-shaped projection left as exact int32 split-K planes + scales for ``skip_rmsnorm_q8`` (extension);
+        ``None`` -> the caller runs :meth:`apply`."""
+        if layer.bias is not None and not allow_bias:
+            return None
+        return smoothquant_matmul_partials(x, layer.weight, layer.weight_scale_inv, bias=layer.bias, max_splits=max_splits)
+
+    def apply_gate_up_swiglu(self, layer, x):
+        """``layer`` holds gate/up row-interleaved: the int8 GEMM + ONE launch for the scale epilogue and the activation."""
+        if layer.bias is not None:
+            return None
+        return smoothquant_gate_up_swiglu(x, layer.weight, layer.weight_scale_inv)
 
     def convert_from_fp16(self, layer, quant):
         qw, sc = quantize_int8_per_channel(layer.weight.data)

@@ -628,6 +628,72 @@ def test_smoothquant_oracle(M, N, K_):
     close(y, ref, 2e-3)
 
 
+@pytest.mark.parametrize("M,K_", [(1, 4096), (32, 4096), (7, 14336), (64, 3584), (3, 100), (5, 20000)])
+def test_activation_quantiser_row_in_registers_equals_oracle(M, K_):
+    """w8a8.py:34-68 (absmax / 127, truncation): the decode-sized rows take the one-pass kernel (row cached in registers),
+    odd widths / long rows the two-pass one -- both bit-equal to the oracle, zero rows included."""
+    from lite_llama_amd.kernels.quantization import quantize_activations_int8
+    torch.manual_seed(M + K_)
+    x = (torch.randn(M, K_) * torch.logspace(-3, 1, M)[:, None]).half()
+    x[M // 2] = 0
+    q_ref, s_ref = O.quantize_activations_int8(x)
+    q, s = quantize_activations_int8(x.to(DEV))
+    assert torch.equal(q.cpu(), q_ref) and torch.equal(s.cpu(), s_ref)
+
+
+@pytest.mark.parametrize("M,N,K_", [(32, 4096, 4096), (32, 4096, 14336), (64, 2048, 1024), (5, 1024, 512)])
+def test_smoothquant_block_fusions_equal_the_separate_launches(M, N, K_):
+    """Decode-step fusions of a smoothquant block (csrc/w8a8_fused.hip), bit for bit against the launch sequence of the
+    reference (w8a8.py GEMM + scale epilogue -> skip_rmsnorm -> per-token quantiser; ... -> swiglu):
+    (a) int32 planes of a row-parallel projection -> scale epilogue + add-and-normalise + the next projection's quantiser;
+    (b) the same launch over a finished fp16 tensor, with and without a residual;
+    (c) fused gate|up planes -> scale epilogue + silu-mul."""
+    from lite_llama_amd.kernels.norm_act import Int8Rows, ScaledInt32Partials, skip_rmsnorm_q8
+    from lite_llama_amd.kernels.quantization import (quantize_activations_int8, smoothquant_gate_up_swiglu,
+                                                     smoothquant_matmul_partials)
+    torch.manual_seed(N + K_ + M)
+    x = (torch.randn(M, K_, device=DEV) * 0.5).half()
+    qw, sc = O.quantize_int8_per_channel(torch.randn(N, K_) * 0.05)
+    qw, sc = qw.to(DEV), sc.to(DEV)
+    res = (torch.randn(M, N, device=DEV) * 0.3).half()
+    wn = (1 + 0.1 * torch.randn(N, device=DEV)).half()
+    eps = 1e-5
+    # the separate launches
+    y_proj = K().smoothquant_matmul(x, qw, sc)
+    r_ref = res.clone()
+    y_ref, r_ref = K().skip_rmsnorm(y_proj, r_ref, wn, eps)
+    q_ref, s_ref = quantize_activations_int8(y_ref)
+    # (a)
+    parts = smoothquant_matmul_partials(x, qw, sc)
+    assert isinstance(parts, ScaledInt32Partials) and parts.parts.dtype == torch.int32 and parts.parts.shape[0] <= 12
+    assert torch.equal(parts.materialise(), y_proj)
+    r_a = res.clone()
+    (rows, y_a), r_a = skip_rmsnorm_q8(parts, r_a, wn, eps, keep_y=True)
+    assert isinstance(rows, Int8Rows) and rows.shape == (M, N)
+    assert torch.equal(r_a, r_ref) and torch.equal(y_a, y_ref)
+    assert torch.equal(rows.q, q_ref) and torch.equal(rows.scale, s_ref)
+    y_only, _ = skip_rmsnorm_q8(parts, res.clone(), wn, eps, quantize=False)
+    assert torch.equal(y_only, y_ref)
+    # the quantised rows feed the next projection without another quantiser launch: same output
+    qw2, sc2 = O.quantize_int8_per_channel(torch.randn(256, N) * 0.05)
+    assert torch.equal(K().smoothquant_matmul(rows, qw2.to(DEV), sc2.to(DEV)), K().smoothquant_matmul(y_ref, qw2.to(DEV), sc2.to(DEV)))
+    # (b)
+    r_b = res.clone()
+    rows_b, r_b = skip_rmsnorm_q8(y_proj, r_b, wn, eps)
+    assert torch.equal(r_b, r_ref) and torch.equal(rows_b.q, q_ref) and torch.equal(rows_b.scale, s_ref)
+    y_nr, _ = K().skip_rmsnorm(y_proj, None, wn, eps)
+    q_nr, s_nr = quantize_activations_int8(y_nr)
+    rows_nr, same = skip_rmsnorm_q8(y_proj, None, wn, eps)
+    assert torch.equal(rows_nr.q, q_nr) and torch.equal(rows_nr.scale, s_nr) and torch.equal(same, y_proj)
+    # (c) rows interleaved (gate_j, up_j)
+    g, u = y_proj[:, 0::2], y_proj[:, 1::2]
+    want = K().swiglu_forward(g.contiguous(), u.contiguous())
+    got = smoothquant_gate_up_swiglu(x, qw, sc)
+    assert got is not None and torch.equal(got, want)
+    got8 = smoothquant_gate_up_swiglu(Int8Rows(*quantize_activations_int8(x), x.shape), qw, sc)
+    assert torch.equal(got8, want)
+
+
 # ------------------------------------------------------------------------------------- #
 # greedy argmax (exact)
 # ------------------------------------------------------------------------------------- #
