@@ -171,6 +171,11 @@ int ll_flash_attention_nopad(void* out, const void* q, const void* k, const void
  * with that x (residual required, updated in place). */
 int ll_skip_rmsnorm_partials(void* y, const float* partials, int s_count, void* residual, const void* weight,
                              int64_t rows, int64_t n, float eps, int dtype, void* stream);
+/* skip_rmsnorm over the fused-MoE block's per-slot rows [rows][k_count][n] (16-bit, router weights folded in): x = the value
+ * ll_moe_sum gives (fp32 sum over the k slots in order, one rounding; fused_moe.py:318-335), then exactly ll_skip_rmsnorm
+ * (residual required, updated in place) -- the moe_sum launch and the norm launch as one.  k_count <= 8, n % 8 == 0, n <= 8192. */
+int ll_skip_rmsnorm_slots(void* y, const void* slots, int k_count, void* residual, const void* weight, int64_t rows, int64_t n,
+                          float eps, int dtype, void* stream);
 
 /* ---- a8: w4a16_matmul  (kernels/quantization/w4a16.py:152-207) ---------------
  * out[m,n] = sum_k x[m,k] * ((nib(qweight[n,k/8],k%8) - zeros[n,k/g]) * scales[n,k/g]) (+bias)

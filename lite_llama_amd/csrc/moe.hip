@@ -469,30 +469,69 @@ extern "C" int ll_moe_gemm(void* c, const void* a, const void* w, const float* w
 // probabilities are positive floats, so their bit patterns order like the values, and equal values resolve to the LOWER
 // expert index (torch.topk leaves the order among equal values unspecified; this kernel is deterministic).
 // ---------------------------------------------------------------------------------- //
-template <int DT>
-__global__ __launch_bounds__(256) void moe_route_topk_kernel(uint16_t* __restrict__ w_out, int64_t* __restrict__ ids_out,
-                                                             const uint16_t* __restrict__ logits, int64_t tokens, int experts,
-                                                             int64_t l_stride, int top_k, int norm) {
-  constexpr int PER = 16;  // experts <= 1024
-  const int lane = threadIdx.x & 63;
-  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);
-  if (tok >= tokens) return;
+
+// (Round 4 also built the WHOLE router -- gate GEMM + this tail -- as one launch, twice: every lane streaming half a gate row
+// with v_dot2 (64 cache lines per load instruction), then MFMA with the contraction split over the four waves of a 16-token
+// workgroup and wave-private LDS pipelines.  22 us per call against 9.4 us for the library GEMM + the tail below at batch 64
+// x 128 experts x 2048: a workgroup cannot pull the 0.5 MB gate matrix through one CU faster than ~12 us, and the four
+// sequential tails per wave cost another 5.  benchmarks/probes/moe_router_one_launch.patch.)
+// Wave reductions on DPP / permlane moves (a handful of cycles per step) instead of __shfl_xor (ds_bpermute: ~100 cycles each,
+// six dependent ones per reduction): the k selection rounds of the router tail are nothing but reductions -- with shuffles a
+// token's tail took ~5 us (eight rounds of twelve dependent shuffles on a 64-bit key).
+template <int CTRL>
+__device__ __forceinline__ uint32_t rt_dpp(uint32_t v) {
+  return (uint32_t)__builtin_amdgcn_mov_dpp((int)v, CTRL, 0xf, 0xf, true);
+}
+// OP over the 16 lanes of a row (quad swaps, then rotations by 4 and 8), then across the four rows
+// (every moved value lands in a temporary BEFORE it is combined, and the combiners are branch-free: a DPP move under a
+// partial EXEC mask -- what a `a > b ? a : b` on the moved value compiles to -- reads disabled lanes)
+#define RT_WAVE_REDUCE(NAME, T, OP, TO_U, FROM_U)                                                              \
+  __device__ __forceinline__ T NAME(T x) {                                                                     \
+    T y;                                                                                                       \
+    y = FROM_U(rt_dpp<0xB1>(TO_U(x)));  x = OP(x, y);  /* quad_perm [1,0,3,2] */                                \
+    y = FROM_U(rt_dpp<0x4E>(TO_U(x)));  x = OP(x, y);  /* quad_perm [2,3,0,1] */                                \
+    y = FROM_U(rt_dpp<0x124>(TO_U(x))); x = OP(x, y);  /* row_ror:4 */                                          \
+    y = FROM_U(rt_dpp<0x128>(TO_U(x))); x = OP(x, y);  /* row_ror:8 */                                          \
+    auto a = __builtin_amdgcn_permlane16_swap(TO_U(x), TO_U(x), false, false);                                 \
+    x = OP(FROM_U(a[0]), FROM_U(a[1]));                                                                        \
+    auto b = __builtin_amdgcn_permlane32_swap(TO_U(x), TO_U(x), false, false);                                 \
+    x = OP(FROM_U(b[0]), FROM_U(b[1]));                                                                        \
+    return FROM_U((uint32_t)__builtin_amdgcn_readfirstlane((int)TO_U(x))); /* one value for the whole wave */  \
+  }
+#define RT_ID(x) (x)
+__device__ __forceinline__ uint32_t rt_umax(uint32_t a, uint32_t b) { return __builtin_elementwise_max(a, b); }
+__device__ __forceinline__ uint32_t rt_umin(uint32_t a, uint32_t b) { return __builtin_elementwise_min(a, b); }
+__device__ __forceinline__ float rt_fadd(float a, float b) { return a + b; }
+#define RT_UMAX rt_umax
+#define RT_UMIN rt_umin
+#define RT_FADD rt_fadd
+RT_WAVE_REDUCE(rt_wave_umax, uint32_t, RT_UMAX, RT_ID, RT_ID)
+RT_WAVE_REDUCE(rt_wave_umin, uint32_t, RT_UMIN, RT_ID, RT_ID)
+RT_WAVE_REDUCE(rt_wave_fmax, float, fmaxf, __float_as_uint, __uint_as_float)
+RT_WAVE_REDUCE(rt_wave_fsum, float, RT_FADD, __float_as_uint, __uint_as_float)
+
+// The router tail for ONE token on one wave: fp32 softmax over the row, k rounds of (largest remaining probability, lowest
+// expert index among equals), optional renormalisation, cast.  Probabilities are non-negative floats: their bit patterns
+// order like the values; a NaN orders above every finite value (as torch.topk orders it) and still yields a valid index.
+template <int DT, int PER>  // PER = ceil(experts / 64)
+__device__ __forceinline__ void moe_topk_wave(uint16_t* __restrict__ w_out, int64_t* __restrict__ ids_out,
+                                              const uint16_t* __restrict__ logits, int experts, int top_k, int norm, int lane) {
   float v[PER];
   float mx = -INFINITY;
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     const int e = j * 64 + lane;
-    v[j] = e < experts ? to_f32<DT>(logits[tok * l_stride + e]) : -INFINITY;
+    v[j] = e < experts ? to_f32<DT>(logits[e]) : -INFINITY;
     mx = fmaxf(mx, v[j]);
   }
-  mx = wave_max(mx);
+  mx = rt_wave_fmax(mx);
   float sum = 0.f;
 #pragma unroll
   for (int j = 0; j < PER; ++j) {
     v[j] = j * 64 + lane < experts ? expf(v[j] - mx) : 0.f;
     sum += v[j];
   }
-  sum = wave_sum(sum);
+  sum = rt_wave_fsum(sum);
 #pragma unroll
   for (int j = 0; j < PER; ++j) v[j] = v[j] / sum;  // the probabilities torch.softmax(dtype=float32) hands to topk
   float picked_w = 0.f;   // lane r keeps selection r
@@ -500,36 +539,40 @@ __global__ __launch_bounds__(256) void moe_route_topk_kernel(uint16_t* __restric
   float top_sum = 0.f;
   unsigned taken = 0u;    // bit j: this lane's expert j * 64 + lane is already selected
   for (int r = 0; r < top_k; ++r) {
-    unsigned long long best = 0ull;
+    uint32_t lb = 0u, le = 0xffffffffu;  // this lane's best remaining (bits, expert); lower j wins a tie
 #pragma unroll
     for (int j = 0; j < PER; ++j) {
       const int e = j * 64 + lane;
-      // (no test of the VALUE: a NaN probability -- NaN logits, e.g. a poisoned activation -- orders above every finite one by
-      // its bit pattern, as torch.topk orders it, and still yields a valid expert index)
-      if (e < experts && !((taken >> j) & 1u)) {
-        const unsigned long long key = ((unsigned long long)__float_as_uint(v[j]) << 32) | (unsigned)(0xffffffffu - (unsigned)e);
-        best = key > best ? key : best;
+      const uint32_t bits = __float_as_uint(v[j]);
+      if (e < experts && !((taken >> j) & 1u) && (le == 0xffffffffu || bits > lb)) {
+        lb = bits;
+        le = (uint32_t)e;
       }
     }
-#pragma unroll
-    for (int off = 32; off > 0; off >>= 1) {
-      const unsigned long long o = __shfl_xor(best, off, 64);
-      best = o > best ? o : best;
-    }
-    const int e = (int)(0xffffffffu - (unsigned)(best & 0xffffffffull));
-    const float pw = __uint_as_float((unsigned)(best >> 32));
+    const uint32_t best = rt_wave_umax(le == 0xffffffffu ? 0u : lb);
+    const uint32_t e = rt_wave_umin((le != 0xffffffffu && lb == best) ? le : 0xffffffffu);
+    const float pw = __uint_as_float(best);
     top_sum += pw;
     if (lane == r) {
       picked_w = pw;
-      picked_e = e;
+      picked_e = (int)e;
     }
-    if ((e & 63) == lane) taken |= 1u << (e >> 6);
+    if ((int)(e & 63u) == lane) taken |= 1u << (e >> 6);
   }
   if (lane < top_k) {
-    const float wv = norm ? picked_w / top_sum : picked_w;
-    w_out[tok * top_k + lane] = from_f32<DT>(wv);
-    ids_out[tok * top_k + lane] = picked_e;
+    w_out[lane] = from_f32<DT>(norm ? picked_w / top_sum : picked_w);
+    ids_out[lane] = picked_e;
   }
+}
+
+template <int DT, int PER>
+__global__ __launch_bounds__(256) void moe_route_topk_kernel(uint16_t* __restrict__ w_out, int64_t* __restrict__ ids_out,
+                                                             const uint16_t* __restrict__ logits, int64_t tokens, int experts,
+                                                             int64_t l_stride, int top_k, int norm) {
+  const int64_t tok = (int64_t)blockIdx.x * 4 + (threadIdx.x >> 6);  // one wave per token
+  if (tok >= tokens) return;
+  moe_topk_wave<DT, PER>(w_out + tok * top_k, ids_out + tok * top_k, logits + tok * l_stride, experts, top_k, norm,
+                         (int)(threadIdx.x & 63));
 }
 
 extern "C" int ll_moe_route_topk(void* weights_out, int64_t* ids_out, const void* logits, int64_t tokens, int experts,
@@ -540,11 +583,15 @@ extern "C" int ll_moe_route_topk(void* weights_out, int64_t* ids_out, const void
   if (tokens == 0) return LL_OK;
   if (!weights_out || !ids_out || !logits) return LL_ERR_ARG;
   const dim3 grid((unsigned)((tokens + 3) / 4));
-  if (dtype == LL_F16)
-    moe_route_topk_kernel<LL_F16><<<grid, 256, 0, (hipStream_t)stream>>>((uint16_t*)weights_out, ids_out, (const uint16_t*)logits,
-                                                                          tokens, experts, logits_stride, top_k, norm_topk_prob);
-  else
-    moe_route_topk_kernel<LL_BF16><<<grid, 256, 0, (hipStream_t)stream>>>((uint16_t*)weights_out, ids_out, (const uint16_t*)logits,
-                                                                           tokens, experts, logits_stride, top_k, norm_topk_prob);
+#define LL_TK(DT, PER)                                                                                             \
+  moe_route_topk_kernel<DT, PER><<<grid, 256, 0, (hipStream_t)stream>>>((uint16_t*)weights_out, ids_out, (const uint16_t*)logits, \
+                                                                        tokens, experts, logits_stride, top_k, norm_topk_prob)
+#define LL_TK_P(DT)                                                                   \
+  if (experts <= 64) LL_TK(DT, 1); else if (experts <= 128) LL_TK(DT, 2);             \
+  else if (experts <= 256) LL_TK(DT, 4); else if (experts <= 512) LL_TK(DT, 8); else LL_TK(DT, 16)
+  if (dtype == LL_F16) { LL_TK_P(LL_F16); } else { LL_TK_P(LL_BF16); }
+#undef LL_TK_P
+#undef LL_TK
   return LL_LAUNCH_CHECK();
 }
+

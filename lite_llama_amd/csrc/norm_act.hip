@@ -254,6 +254,84 @@ extern "C" int ll_skip_rmsnorm_partials(void* y, const float* partials, int s_co
   return LL_LAUNCH_CHECK();
 }
 
+// skip_rmsnorm whose input is the fused-MoE block's per-slot output [rows][k][n] (16-bit: the down projection's rows with the
+// router weight folded in): x = moe_sum's value -- fp32 sum over the k slots in order, one rounding (fused_moe.py:318-335) --
+// then the arithmetic of skip_rmsnorm_cached.  Replaces the moe_sum launch + the norm launch.  One row per block.
+template <int DT, int VPT, int KMAX>
+__global__ __launch_bounds__(256) void skip_rmsnorm_slots_kernel(uint16_t* __restrict__ y, const uint16_t* __restrict__ slots,
+                                                                 int k_count, uint16_t* __restrict__ r,
+                                                                 const uint16_t* __restrict__ w, int64_t rows, int n, float eps) {
+  __shared__ float lds[4];
+  const int tr = threadIdx.x;
+  const int64_t row = blockIdx.x;
+  const float nf = (float)n;
+  U16x8 rv[VPT], wv[VPT], hv[VPT][KMAX];
+  bool ok[VPT];
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    const int col = (v * 256 + tr) * 8;
+    ok[v] = col < n;
+    const int c0 = ok[v] ? col : 0;
+    rv[v] = *reinterpret_cast<const U16x8*>(r + row * n + c0);
+    wv[v] = *reinterpret_cast<const U16x8*>(w + c0);
+#pragma unroll
+    for (int s = 0; s < KMAX; ++s)  // slots >= k_count re-read slot 0 and are dropped below
+      hv[v][s] = *reinterpret_cast<const U16x8*>(slots + (row * k_count + (s < k_count ? s : 0)) * (int64_t)n + c0);
+  }
+  float sv[VPT][8];
+  float ssq = 0.f;
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+#pragma unroll
+    for (int i = 0; i < 8; ++i) {
+      float a = 0.f;
+#pragma unroll
+      for (int s = 0; s < KMAX; ++s) a += s < k_count ? to_f32<DT>(hv[v][s].v[i]) : 0.f;
+      float x = to_f32<DT>(from_f32<DT>(a)) + to_f32<DT>(rv[v].v[i]);
+      rv[v].v[i] = from_f32<DT>(x);
+      sv[v][i] = ok[v] ? x : 0.f;
+    }
+    if (ok[v]) *reinterpret_cast<U16x8*>(r + row * n + (v * 256 + tr) * 8) = rv[v];
+#pragma unroll
+    for (int i = 0; i < 8; ++i) ssq += sv[v][i] * sv[v][i] / nf;
+  }
+  const float var = row_sum<256>(ssq, lds);
+  const float rrms = 1.0f / sqrtf(var + eps);
+#pragma unroll
+  for (int v = 0; v < VPT; ++v) {
+    if (ok[v]) {
+      U16x8 yv;
+#pragma unroll
+      for (int i = 0; i < 8; ++i) yv.v[i] = mul_storage<DT>(from_f32<DT>(sv[v][i] * rrms), wv[v].v[i]);
+      *reinterpret_cast<U16x8*>(y + row * n + (v * 256 + tr) * 8) = yv;
+    }
+  }
+}
+
+extern "C" int ll_skip_rmsnorm_slots(void* y, const void* slots, int k_count, void* residual, const void* weight, int64_t rows,
+                                     int64_t n, float eps, int dtype, void* stream) {
+  if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (rows < 0 || n <= 0 || n % 8 != 0 || n > 8192 || k_count < 1 || k_count > 8) return LL_ERR_SHAPE;
+  if (!y || !slots || !residual || !weight || !ll_aligned16(y) || !ll_aligned16(slots) || !ll_aligned16(residual) ||
+      !ll_aligned16(weight))
+    return LL_ERR_ARG;
+  if (rows == 0) return LL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const int nv = (int)(n / 8);
+#define LL_SLOT_CASE(DT, VPT, KMAX)                                                                          \
+  skip_rmsnorm_slots_kernel<DT, VPT, KMAX><<<dim3((unsigned)rows), 256, 0, st>>>(                            \
+      (uint16_t*)y, (const uint16_t*)slots, k_count, (uint16_t*)residual, (const uint16_t*)weight, rows, (int)n, eps)
+#define LL_SLOT_K(DT, VPT) \
+  if (k_count <= 2) LL_SLOT_CASE(DT, VPT, 2); else if (k_count <= 4) LL_SLOT_CASE(DT, VPT, 4); else LL_SLOT_CASE(DT, VPT, 8)
+#define LL_SLOT_DT(DT) \
+  if (nv <= 256) { LL_SLOT_K(DT, 1); } else if (nv <= 512) { LL_SLOT_K(DT, 2); } else { LL_SLOT_K(DT, 4); }
+  if (dtype == LL_F16) { LL_SLOT_DT(LL_F16) } else { LL_SLOT_DT(LL_BF16) }
+#undef LL_SLOT_DT
+#undef LL_SLOT_K
+#undef LL_SLOT_CASE
+  return LL_LAUNCH_CHECK();
+}
+
 // --------------------------------------------------------------------------- //
 // swiglu_forward -- reference lite_llama/kernels/swiglu.py:24-65
 // silu_and_mul   -- reference lite_llama/kernels/fused_moe.py:298-315

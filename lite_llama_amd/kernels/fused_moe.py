@@ -89,12 +89,16 @@ def fused_moe(
     group_k: int = 0,
     w1_group: tuple | None = None,
     w2_group: tuple | None = None,
+    slots_ok: bool = False,
 ) -> torch.Tensor:
     """``sum_k w_k * (silu(x W1g^T) * (x W1u^T)) W2^T`` over each token's top-k experts.
 
     ``w1_group`` / ``w2_group`` (extension, ``(group_n, group_k)`` per matrix): a tensor-parallel shard whose cut does
     not end on the checkpoint's scale blocks carries its scales re-expressed on a finer grid -- gate|up along N, down
     along K (model.py::SparseMoeBlock); multiples of 8 along K.
+
+    ``slots_ok`` (extension): return the per-slot rows as a ``SlotSums`` for ``skip_rmsnorm_partials`` instead of running
+    ``moe_sum`` (the same values, one launch less).
 
     Pipeline and intermediate dtypes as the reference: align -> GEMM1 (``[T*k, 2I]`` in x's
     dtype) -> silu*up -> GEMM2 with the router weight folded in fp32 -> fp32 sum over top_k."""
@@ -118,7 +122,8 @@ def fused_moe(
     if hidden_states.stride(-1) != 1:
         hidden_states = hidden_states.contiguous()
 
-    topk_ids = topk_ids.to(torch.int32)
+    if topk_ids.dtype not in (torch.int32, torch.int64):  # (the align kernel reads either width: no cast launch)
+        topk_ids = topk_ids.to(torch.int32)
     flat_weights = topk_weights.reshape(-1).to(dtype).contiguous()
 
     block_m = _block_m(num_tokens)
@@ -141,6 +146,10 @@ def fused_moe(
     _moe_gemm(act, w2, expanded, w2_scale, flat_weights, sorted_ids, expert_ids, num_post,
               1, True, wfmt, g2[0], g2[1], block_m)
 
+    if slots_ok and top_k <= 8 and hidden % 8 == 0 and hidden <= 8192:
+        # (extension) the caller's add-and-normalise adds the k slots up itself: no moe_sum launch
+        from .norm_act import SlotSums
+        return SlotSums(expanded.view(num_tokens, top_k, hidden), (num_tokens, hidden))
     out = torch.empty((num_tokens, hidden), device=device, dtype=dtype)
     L.check(
         L.lib().ll_moe_sum(out.data_ptr(), expanded.data_ptr(), num_tokens, top_k, hidden,
@@ -167,3 +176,4 @@ def moe_route_topk(router_logits: torch.Tensor, top_k: int, norm_topk_prob: bool
                                       int(top_k), 1 if norm_topk_prob else 0, L.dtype_code(router_logits.dtype),
                                       L.stream_ptr()), "moe_route_topk")
     return w, ids
+

@@ -70,6 +70,24 @@ class PartialSums:
         return out
 
 
+class SlotSums(PartialSums):
+    """:class:`PartialSums` of a fused-MoE block: ``parts`` are the down projection's per-slot rows ``[rows, k, n]`` in the
+    activation dtype (router weights folded in); their fp32 sum over ``k``, rounded once, is the block's output (``moe_sum``).
+    Consumed by :func:`skip_rmsnorm_partials` (one launch instead of moe_sum + norm)."""
+
+    __slots__ = ()
+
+    def __init__(self, parts: torch.Tensor, shape):
+        super().__init__(parts, shape, parts.dtype)
+
+    def materialise(self) -> torch.Tensor:
+        rows, k, n = self.parts.shape
+        out = torch.empty((rows, n), dtype=self.dtype, device=self.parts.device)
+        L.check(L.lib().ll_moe_sum(out.data_ptr(), self.parts.data_ptr(), rows, k, n, L.dtype_code(self.dtype), L.stream_ptr()),
+                "moe_sum")
+        return out.view(self.shape)
+
+
 class Int8Rows:
     """Activations already through smoothquant's per-token quantiser (``quantize_activations_int8``): ``q`` int8
     ``[rows, k]``, ``scale`` fp32 ``[rows]``; ``shape`` is the logical (fp16) tensor's.  Produced by
@@ -182,7 +200,10 @@ def skip_rmsnorm_partials(X: PartialSums, residual, weight, eps=1e-5):
     if residual is None:
         raise ValueError("skip_rmsnorm_partials needs a residual (the projection follows a normalised block)")
     L.require_cuda(X.parts, residual, weight)
-    s, m, n = X.parts.shape
+    if isinstance(X, SlotSums):
+        m, s, n = X.parts.shape
+    else:
+        s, m, n = X.parts.shape
     _check_row(n)
     residual = residual.contiguous().view(-1, n)
     if residual.shape[0] != m or residual.dtype != X.dtype:
@@ -190,6 +211,11 @@ def skip_rmsnorm_partials(X: PartialSums, residual, weight, eps=1e-5):
     if weight.dtype != X.dtype:
         weight = weight.to(X.dtype)
     Y = torch.empty((m, n), dtype=X.dtype, device=residual.device)
+    if isinstance(X, SlotSums):
+        L.check(L.lib().ll_skip_rmsnorm_slots(Y.data_ptr(), X.parts.data_ptr(), s, residual.data_ptr(),
+                                              weight.contiguous().data_ptr(), m, n, float(eps), L.dtype_code(X.dtype),
+                                              L.stream_ptr()), "skip_rmsnorm_slots")
+        return Y.view(X.shape), residual.view(X.shape)
     if X.tp_reduce:
         # tensor parallelism: the partials are this rank's share; one launch adds them, exchanges the fp16 sums with the
         # peers (one-shot all-reduce over peer-mapped buffers, fp32 adds in rank order) and normalises

@@ -416,11 +416,17 @@ class SparseMoeBlock(nn.Module):
             w = w / w.sum(dim=-1, keepdim=True)
         return w, ids
 
-    def forward(self, x):
+    def forward(self, x, partials_ok: bool = False):
+        """``partials_ok`` (extension, TP = 1): the caller's add-and-normalise adds the top-k slots up itself -- the result is a
+        ``SlotSums`` and the ``moe_sum`` launch is skipped."""
         shape = x.shape
         x2 = x.reshape(-1, self.hidden_size)
         w, ids = self._route(x2)
-        out = self.quant_method.apply(self, x2, w, ids)
+        slots = (partials_ok and get_tp_world_size() == 1 and x2.is_cuda and not os.environ.get("LL_MOE_NO_SLOTS"))
+        out = self.quant_method.apply(self, x2, w, ids, slots_ok=True) if slots else self.quant_method.apply(self, x2, w, ids)
+        if isinstance(out, PartialSums):
+            out.shape = tuple(shape)
+            return out
         return all_reduce_tp(out).view(shape)
 
     @torch.no_grad()
@@ -453,10 +459,7 @@ class DecoderLayer(nn.Module):
         hidden_states, residual = add_norm(hidden_states, residual, self.post_attention_layernorm_weight, self.eps,
                                            q8=isinstance(self.mlp, FusedMLP)
                                            and _takes_int8_rows(self.mlp.gate_proj, self.mlp.up_proj))
-        if isinstance(self.mlp, FusedMLP):
-            hidden_states = self.mlp(hidden_states, partials_ok=True)
-        else:
-            hidden_states = self.mlp(hidden_states)
+        hidden_states = self.mlp(hidden_states, partials_ok=True)
         return hidden_states, residual
 
 

@@ -48,7 +48,7 @@ class MoeQuantMethod(ABC):
     def create_weights(self, block: nn.Module) -> dict: ...
 
     @abstractmethod
-    def apply(self, block, x, topk_weights, topk_ids) -> torch.Tensor: ...
+    def apply(self, block, x, topk_weights, topk_ids, slots_ok: bool = False) -> torch.Tensor: ...
 
     def convert_from_fp16(self, block: nn.Module, quant: QuantConfig) -> None:
         raise NotImplementedError(f"{type(self).__name__} cannot be computed from fp16 weights at load time")
@@ -301,8 +301,9 @@ class UnquantizedMoeMethod(MoeQuantMethod):
                                                   block.moe_intermediate_size, dtype=torch.float16), requires_grad=False),
         }
 
-    def apply(self, block, x, topk_weights, topk_ids):
-        return fused_moe(x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids)
+    def apply(self, block, x, topk_weights, topk_ids, slots_ok: bool = False):
+        return fused_moe(x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids,
+                         slots_ok=slots_ok)
 
 
 class W8A16MoeMethod(MoeQuantMethod):
@@ -332,7 +333,7 @@ class W8A16MoeMethod(MoeQuantMethod):
             "down_proj_scale_inv": RawParameter(torch.empty(e, cdiv(d_n, g2n), cdiv(d_k, g2k), dtype=torch.float32)),
         }
 
-    def apply(self, block, x, topk_weights, topk_ids):
+    def apply(self, block, x, topk_weights, topk_ids, slots_ok: bool = False):
         q = block.quant
         if getattr(block, "scale_cut", 0):
             g1, g2 = self.groups(block)
@@ -340,11 +341,12 @@ class W8A16MoeMethod(MoeQuantMethod):
                 x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids,
                 w1_scale=block.experts["gate_up_proj_scale_inv"], w2_scale=block.experts["down_proj_scale_inv"],
                 group_n=q.group_n, group_k=q.group_k, w1_group=(g1[0], min(g1[1], block.hidden_size)), w2_group=g2,
+                slots_ok=slots_ok,
             )
         return fused_moe(
             x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids,
             w1_scale=block.experts["gate_up_proj_scale_inv"], w2_scale=block.experts["down_proj_scale_inv"],
-            group_n=q.group_n, group_k=min(q.group_k, block.hidden_size),
+            group_n=q.group_n, group_k=min(q.group_k, block.hidden_size), slots_ok=slots_ok,
         )
 
     def convert_from_fp16(self, block, quant):

@@ -694,6 +694,26 @@ def test_smoothquant_block_fusions_equal_the_separate_launches(M, N, K_):
     assert torch.equal(got8, want)
 
 
+@pytest.mark.parametrize("T,k,H,dtype", [(64, 8, 2048, torch.float16), (5, 2, 512, torch.float16), (33, 6, 4096, torch.bfloat16),
+                                         (1, 1, 8192, torch.float16)])
+def test_skip_rmsnorm_over_moe_slots_equals_moe_sum_then_skip_rmsnorm(T, k, H, dtype):
+    """The fused-MoE block's per-slot rows [T, k, H] consumed by the add-and-normalise (fused_moe.py:318-335 moe_sum, then
+    skip_rmsnorm.py:126-234) in one launch: bit-equal output AND residual; fused_moe(slots_ok=True) hands over those rows."""
+    from lite_llama_amd.kernels.norm_act import SlotSums, skip_rmsnorm_partials
+    torch.manual_seed(T + k)
+    rows = (torch.randn(T, k, H, device=DEV) * 0.4).to(dtype)
+    res = (torch.randn(T, H, device=DEV) * 0.3).to(dtype)
+    wn = (1 + 0.1 * torch.randn(H, device=DEV)).to(dtype)
+    slots = SlotSums(rows, (T, H))
+    summed = slots.materialise()
+    assert torch.equal(summed, rows.float().sum(1).to(dtype)) or k > 2   # (k <= 2: one fp32 add, any order)
+    r_ref = res.clone()
+    y_ref, r_ref = K().skip_rmsnorm(summed, r_ref, wn, 1e-6)
+    r = res.clone()
+    y, r = skip_rmsnorm_partials(slots, r, wn, 1e-6)
+    assert torch.equal(y, y_ref) and torch.equal(r, r_ref)
+
+
 # ------------------------------------------------------------------------------------- #
 # greedy argmax (exact)
 # ------------------------------------------------------------------------------------- #
