@@ -80,15 +80,37 @@ struct VecIO<1> {
   __device__ static __forceinline__ void store(uint16_t* p, const uint16_t (&o)[1]) { p[0] = o[0]; }
 };
 
+// Wave reductions on DPP row moves + permlane swaps (a few cycles per step) -- NOT __shfl_xor, which hipcc lowers to
+// ds_bpermute_b32 (~100 cycles each; six dependent ones per reduction: ~0.3 us of every row-per-workgroup norm launch, ~5 us
+// of a router tail's eight selection rounds, round 4).  Every lane of the wave must be active (DPP reads disabled lanes as
+// garbage): all callers reduce right before a workgroup barrier.  The result is lane 0's value in every lane.
+template <int CTRL>
+__device__ __forceinline__ float ll_dpp_f32(float v) {
+  return __uint_as_float((uint32_t)__builtin_amdgcn_mov_dpp((int)__float_as_uint(v), CTRL, 0xf, 0xf, true));
+}
 __device__ __forceinline__ float wave_sum(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v += __shfl_xor(v, off, 64);
-  return v;
+  float t;
+  t = ll_dpp_f32<0xB1>(v); v += t;   // quad_perm [1,0,3,2]
+  t = ll_dpp_f32<0x4E>(v); v += t;   // quad_perm [2,3,0,1]
+  t = ll_dpp_f32<0x124>(v); v += t;  // row_ror:4
+  t = ll_dpp_f32<0x128>(v); v += t;  // row_ror:8
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(a[0]) + __uint_as_float(a[1]);
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = __uint_as_float(b[0]) + __uint_as_float(b[1]);
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
 }
 __device__ __forceinline__ float wave_max(float v) {
-#pragma unroll
-  for (int off = 32; off > 0; off >>= 1) v = fmaxf(v, __shfl_xor(v, off, 64));
-  return v;
+  float t;
+  t = ll_dpp_f32<0xB1>(v); v = fmaxf(v, t);
+  t = ll_dpp_f32<0x4E>(v); v = fmaxf(v, t);
+  t = ll_dpp_f32<0x124>(v); v = fmaxf(v, t);
+  t = ll_dpp_f32<0x128>(v); v = fmaxf(v, t);
+  auto a = __builtin_amdgcn_permlane16_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(a[0]), __uint_as_float(a[1]));
+  auto b = __builtin_amdgcn_permlane32_swap(__float_as_uint(v), __float_as_uint(v), false, false);
+  v = fmaxf(__uint_as_float(b[0]), __uint_as_float(b[1]));
+  return __uint_as_float((uint32_t)__builtin_amdgcn_readfirstlane((int)__float_as_uint(v)));
 }
 
 // shared by swiglu / silu_and_mul and the GEMM's fused gate-up epilogue (must stay ONE definition:
