@@ -174,9 +174,12 @@ def gemm_roofline(model, batch, quant, iters=6):
         "int4": "wgemm3_kernel (w4a16 dequant-GEMM over pre-packed weights, decode engine; gemm_w4_v3.hip)",
         "int8": "dense8_kernel + dense8_finish (w8a16 int8, split-K weight streaming; gemm_w8_skinny.hip)",
         "fp8": "dense8_kernel + dense8_finish (w8a16 fp8-e4m3, split-K weight streaming; gemm_w8_skinny.hip)",
-        "smoothquant": "quantize_activations_int8 + dense8_kernel (int8 x int8 MFMA) + dense8_finish (gemm_w8_skinny.hip)",
-        "none": "hipBLASLt 16-bit GEMM through torch F.linear (the reference's own unquantised path, methods/unquantized.py:21-22; "
-                "NOT a kernel of this repo -- see DESIGN.md on the dense 16-bit row)",
+        "smoothquant": "dense8_kernel (int8 x int8 MFMA, split-K planes; gemm_w8_skinny.hip) with the per-token quantiser / scale "
+                       "epilogue fused into the neighbouring launches where the step fuses them (w8a8_fused.hip): as timed here, "
+                       "q|k|v = quantiser + GEMM + finish, gate|up = quantiser + GEMM + finish-swiglu, o / down = quantiser + GEMM",
+        "none": "dense8_kernel 16-bit form in split-K partial mode for q|k|v, o, down (gemm_w8_skinny.hip; planes summed by the "
+                "consuming norm / attention launch) + hipBLASLt through torch F.linear for the fused gate|up GEMM (followed by the "
+                "in-tree swiglu launch) -- the mix the decode step runs; averaged over the launches",
     }[quant] if batch <= 64 or quant == "none" else "wgemm_kernel (generic engine, M > 64; gemm_wq.hip)"
     return {
         "bound": "hbm", "kernel": kernel,

@@ -22,6 +22,12 @@ timeout 400 python bench.py --model llama-3-8b --quant smoothquant --batch 32 --
 timeout 600 python bench.py --model qwen3-30b-a3b --quant fp8 --batch 64 --no-cpu-baseline --no-secondary --steps 16 --warmup 4 > $O/bench_cfg5_qwen3-30b-a3b_fp8_b64_$V.json 2>/dev/null
 cd /tmp && rm -rf /tmp/pk2 && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pk2 -o c -- python $ROOT/bench.py --model qwen2.5-1.5b --quant none --dtype bf16 --batch 32 --no-cpu-baseline --no-secondary --steps 16 --warmup 3 > /dev/null 2>&1; cd $ROOT
 python tools/rocpd.py stats /tmp/pk2/c_results.db --by-grid 2>&1 | head -40 > $O/cfg2_kernel_stats_bygrid_$V.txt
+cd /tmp && rm -rf /tmp/pk4 && timeout 600 rocprofv3 --kernel-trace --stats -d /tmp/pk4 -o c -- python $ROOT/bench.py --model llama-3-8b --quant smoothquant --batch 32 --no-cpu-baseline --no-secondary --steps 8 --warmup 2 > /dev/null 2>&1; cd $ROOT
+python tools/rocpd.py stats /tmp/pk4/c_results.db --by-grid 2>&1 | head -40 > $O/cfg4_kernel_stats_bygrid_$V.txt
+python tools/rocpd.py steps /tmp/pk4/c_results.db 2>&1 | head -3 >> $O/cfg4_kernel_stats_bygrid_$V.txt
+cd /tmp && rm -rf /tmp/pk5 && timeout 900 rocprofv3 --kernel-trace --stats -d /tmp/pk5 -o c -- python $ROOT/bench.py --model qwen3-30b-a3b --quant fp8 --batch 64 --no-cpu-baseline --no-secondary --steps 8 --warmup 2 > /dev/null 2>&1; cd $ROOT
+python tools/rocpd.py stats /tmp/pk5/c_results.db --by-grid 2>&1 | head -40 > $O/cfg5_kernel_stats_bygrid_$V.txt
+python tools/rocpd.py steps /tmp/pk5/c_results.db 2>&1 | head -3 >> $O/cfg5_kernel_stats_bygrid_$V.txt
 ls -la $O | tail -20
 python - <<PY
 import json
