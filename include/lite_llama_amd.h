@@ -145,7 +145,10 @@ int ll_decode_attention(void* out, const void* q, const void* kv_new, int64_t kv
 /* ll_decode_attention whose q / k_new / v_new arrive as the fp32 split-K partials [s_count][batch][(hq + 2 hkv) * d] of the
  * fused q|k|v projection (ll_w4a16_matmul_prepacked epilogue 2) plus the projection bias (or NULL): every workgroup adds
  * the partials of its (row, KV head), rounds once to the pool dtype -- the value the projection would have stored -- and
- * continues as ll_decode_attention.  Contexts of 2..8 partitions (129..1024 tokens); LL_ERR_SHAPE otherwise. */
+ * continues as ll_decode_attention.  Contexts of 2..8 partitions (129..1024 tokens); LL_ERR_SHAPE otherwise.
+ * int32_a_scale [batch] / int32_w_scale [row width] (both or both NULL; fp16, d == 128): the planes are the exact int32 sums
+ * of a smoothquant projection (ll_dense_partials wfmt 3); the value summed is fp16(((float)sum * a_scale[row]) * w_scale[col]
+ * (+ bias)), what ll_w8a8_matmul stores. */
 int ll_decode_attention_partials(void* out, const float* qkv_partials, int s_count, const void* qkv_bias,
                                  const void* cos_t, const void* sin_t, int64_t cs_row_stride, const int64_t* positions,
                                  const void* select_index, int sel_width, void* k_cache, void* v_cache,
@@ -153,7 +156,8 @@ int ll_decode_attention_partials(void* out, const float* qkv_partials, int s_cou
                                  int hkv, int d, int64_t max_len, float qk_scale, int64_t k_stride_t, int64_t k_stride_h,
                                  int64_t v_stride_t, int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
                                  int64_t table_stride_b, int dtype, int req_width, int seq_width,
-                                 const void* q_norm_weight, const void* k_norm_weight, float norm_eps, void* stream);
+                                 const void* q_norm_weight, const void* k_norm_weight, float norm_eps,
+                                 const float* int32_a_scale, const float* int32_w_scale, void* stream);
 
 /* ---- a6: flash_attention2_no_pad  (kernels/flashattention2_nopad.py:175-231) --
  * Varlen causal prefill over freshly projected q/k/v (exp2 softmax; sm_scale

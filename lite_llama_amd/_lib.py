@@ -36,7 +36,7 @@ SIGNATURES = {
     "ll_decode_attention": [P, P, P, L, P, P, L, P, P, I, P, P, P, P, P, P, P, I, I, I, I, L, F, L, L, L, L, L, L, L, L, L,
                             I, I, I, P, P, P, F, P],
     "ll_decode_attention_partials": [P, P, I, P, P, P, L, P, P, I, P, P, P, P, P, I, I, I, I, L, F, L, L, L, L, L, L, L, I, I, I,
-                                     P, P, F, P],
+                                     P, P, F, P, P, P],
     "ll_flash_attention_nopad": [P, P, P, P, P, P, I, I, I, I, L, F, L, L, L, L, L, L, L, L, I, I, I, P],
     "ll_gemm_workspace": [L, L, L, P, P],
     "ll_w4a16_matmul": [P, P, P, P, P, P, L, L, L, I, L, L, L, P, P, P],

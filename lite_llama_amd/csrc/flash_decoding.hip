@@ -80,6 +80,9 @@ struct FdRope {
   const uint16_t* qnw;
   const uint16_t* knw;
   float nrm_eps;
+  // QI32 (smoothquant q|k|v): the planes at qp are EXACT int32 sums; value = fp16(((float)sum * q_as[row]) * q_ws[col] (+ bias))
+  const float* q_as;          // [batch] per-token activation scales
+  const float* q_ws;          // [row_w] per-channel weight scales
 };
 #define FD_QS_MAX 8
 
@@ -217,7 +220,7 @@ __device__ __forceinline__ void fd_head_norm(Q4 (&qf)[4], const Q4 (&wf)[4], flo
   for (int s = 0; s < 4; ++s) qf[s] = fd_scale8<DT>(qf[s], wf[s], rr);
 }
 
-template <int DT, int D, bool FUSE, bool ROPE, int GS, bool GROUPED, bool KV8 = false, bool QKN = false>
+template <int DT, int D, bool FUSE, bool ROPE, int GS, bool GROUPED, bool KV8 = false, bool QKN = false, bool QI32 = false>
 __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     const uint16_t* __restrict__ q, const uint16_t* __restrict__ kc, const uint16_t* __restrict__ vc,
     const int32_t* __restrict__ table, const void* __restrict__ b_req_idx,
@@ -231,6 +234,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
   constexpr int VSTR = D + 8;     // padded LDS row stride (elements)
   static_assert(!KV8 || (DT == LL_F16 && !ROPE), "fp8 KV: fp16 queries, rope and the KV write happen before the launch");
   static_assert(!QKN || (ROPE && D == 128), "q / k head norm: part of the one-launch decode form, head size 128");
+  static_assert(!QI32 || (GROUPED && ROPE && DT == LL_F16), "int32 q|k|v planes (smoothquant): the grouped partial-input form, fp16");
   using KVR = typename FdKv<KV8>::Reg;
   using KVE = typename FdKv<KV8>::Elem;
   const KVE* kcE = reinterpret_cast<const KVE*>(kc);
@@ -260,6 +264,9 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
   int64_t qcol[2] = {0, 0};
   bool qok[2] = {false, false};
   uint2 qbv[2] = {uint2{0, 0}, uint2{0, 0}};  // the 4 bias values of a slot, fetched with the partials (one 8-byte load)
+  f32x4 qws[QI32 ? 2 : 1];                     // QI32: the slot's 4 weight scales
+  float qas = 0.f;                             // QI32: this row's activation scale
+  if constexpr (QI32) qas = rp.q_as[b];
   if constexpr (QPART_OK) {
     if (qpart) {
       const int nq = groups * D;                // this KV head's query values, then its new K row, then its new V row
@@ -282,6 +289,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
         // per-element form of this cost eight dependent round trips in the launch's ramp)
         const uint16_t* bsrc = rp.qbias ? rp.qbias + qcol[it] : reinterpret_cast<const uint16_t*>(rp.qp);
         qbv[it] = *reinterpret_cast<const uint2*>(bsrc);
+        if constexpr (QI32) qws[it] = *reinterpret_cast<const f32x4*>(rp.q_ws + qcol[it]);
       }
     }
   }
@@ -291,10 +299,29 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
 #pragma unroll
         for (int it = 0; it < 2; ++it) {
           f32x4 a = {0.f, 0.f, 0.f, 0.f};
+          if constexpr (QI32) {
+            // exact int32 sums, then (acc.f32 * a_scale[m]) * w_scale[n] (w8a8.py:118-120) -- the product pinned to fp32 before
+            // the narrowing below (see w8a8_fused.hip::q8_f32)
+            i32x4 ai = {0, 0, 0, 0};
+#pragma unroll
+            for (int sl = 0; sl < FD_QS_MAX; ++sl)
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                const float bits = qacc[sl][it][e];  // (a copy first: __builtin_bit_cast on a vector ELEMENT reads element 0)
+                ai[e] += sl < rp.qs ? __float_as_int(bits) : 0;
+              }
+#pragma unroll
+            for (int e = 0; e < 4; ++e) {
+              float v = ((float)ai[e] * qas) * qws[it][e];
+              asm volatile("" : "+v"(v));
+              a[e] = v;
+            }
+          } else {
 #pragma unroll
           for (int sl = 0; sl < FD_QS_MAX; ++sl)
 #pragma unroll
             for (int e = 0; e < 4; ++e) a[e] += sl < rp.qs ? qacc[sl][it][e] : 0.f;
+          }
           uint16_t o4[4];
 #pragma unroll
           for (int e = 0; e < 4; ++e) {
@@ -922,19 +949,19 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
     return LL_ERR_SHAPE;
   // one workgroup per (row, KV head group) with a wave per partition while the context fits FD_GROUP_MAX partitions
   const bool grouped = grouped_ok && !ungrouped_env;
-#define LL_FD1X(DD, FU, RO, GG, GR) LL_FD1XK(DD, FU, RO, GG, GR, false, false)
-#define LL_FD1XK(DD, FU, RO, GG, GR, K8, QN)                                                            \
+#define LL_FD1X(DD, FU, RO, GG, GR) LL_FD1XK(DD, FU, RO, GG, GR, false, false, false)
+#define LL_FD1XK(DD, FU, RO, GG, GR, K8, QN, QI)                                                            \
   {                                                                                                  \
     constexpr int tile_bytes_ = 32 * (DD + 8) * 2;                                                   \
     if (GR) {                                                                                        \
       static bool attr_ = false;                                                                     \
       if (!attr_) {                                                                                  \
-        (void)hipFuncSetAttribute((const void*)fd_stage1<DT, DD, FU, RO, GG, GR, K8, QN>,             \
+        (void)hipFuncSetAttribute((const void*)fd_stage1<DT, DD, FU, RO, GG, GR, K8, QN, QI>,             \
                                   hipFuncAttributeMaxDynamicSharedMemorySize, FD_GROUP_MAX * tile_bytes_ + 18 * DD * 2); \
         attr_ = true;                                                                                \
       }                                                                                              \
     }                                                                                                \
-    fd_stage1<DT, DD, FU, RO, GG, GR, K8, QN><<<(GR) ? dim3(1, grid.y, grid.z) : grid, (GR) ? 64 * nparts : 64, \
+    fd_stage1<DT, DD, FU, RO, GG, GR, K8, QN, QI><<<(GR) ? dim3(1, grid.y, grid.z) : grid, (GR) ? 64 * nparts : 64, \
                                         ((GR) ? nparts : 1) * tile_bytes_ + ((GR) ? 18 * DD * 2 : 0), st>>>( \
         (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, table, req, seq, mid_o, mid_lse, hq, hkv, nparts, \
         scale, q_sb, q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w, (uint16_t*)out, o_sb, o_sh, counters, rp); \
@@ -956,8 +983,8 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
     if constexpr (DT == LL_F16) {
       if (rope || !fuse || (d != 64 && d != 128)) return LL_ERR_SHAPE;
 #define LL_FD8(DD, GG)                                   \
-  if (grouped) LL_FD1XK(DD, true, false, GG, true, true, false) \
-  else LL_FD1XK(DD, true, false, GG, false, true, false)
+  if (grouped) LL_FD1XK(DD, true, false, GG, true, true, false, false) \
+  else LL_FD1XK(DD, true, false, GG, false, true, false, false)
 #define LL_FD8G(DD)                  \
   if (groups <= 4) { LL_FD8(DD, 4) } \
   else if (groups <= 8) { LL_FD8(DD, 8) } \
@@ -970,11 +997,23 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
       return LL_ERR_DTYPE;
     }
   }
+  if (rope && rp.qp && rp.q_as) {
+    // smoothquant q|k|v planes (int32 + scales): the grouped partial-input form (checked above), fp16, head size 128, no head norm
+    if constexpr (DT == LL_F16) {
+      if (!rp.q_ws || d != 128 || qkn) return LL_ERR_SHAPE;
+      if (groups <= 4) { LL_FD1XK(128, true, true, 4, true, false, false, true) }
+      else if (groups <= 8) { LL_FD1XK(128, true, true, 8, true, false, false, true) }
+      else { LL_FD1XK(128, true, true, 16, true, false, false, true) }
+      return LL_LAUNCH_CHECK();
+    } else {
+      return LL_ERR_DTYPE;
+    }
+  }
   if (qkn) {
     // one-launch decode form with the q / k head norm in front of the rotation (checked above: rope, d == 128)
 #define LL_FD1Q(GG)                                                      \
-  if (grouped) LL_FD1XK(128, true, true, GG, true, false, true)          \
-  else LL_FD1XK(128, true, true, GG, false, false, true)
+  if (grouped) LL_FD1XK(128, true, true, GG, true, false, true, false)   \
+  else LL_FD1XK(128, true, true, GG, false, false, true, false)
     if (groups <= 4) { LL_FD1Q(4) }
     else if (groups <= 8) { LL_FD1Q(8) }
     else { LL_FD1Q(16) }
@@ -1097,6 +1136,9 @@ extern "C" int ll_decode_attention(void* out, const void* q, const void* kv_new,
 // (q heads, K heads, V heads), qkv_bias [row_width] (projection bias, dtype of the pool) or NULL.  x = fp16(sum of the
 // partials + bias) -- the value the projection would have stored -- then exactly ll_decode_attention.  Served for
 // contexts of 2..8 partitions (129..1024 tokens); LL_ERR_SHAPE otherwise: finish the sums and call ll_decode_attention.
+// int32_a_scale [batch] / int32_w_scale [row_width] (both or neither; fp16, d == 128): the planes are the EXACT int32 sums of
+// a smoothquant projection (ll_dense_partials wfmt 3) and x = fp16(((float)sum * a_scale[row]) * w_scale[col] (+ bias)) --
+// what ll_w8a8_matmul stores.
 extern "C" int ll_decode_attention_partials(void* out, const float* qkv_partials, int s_count, const void* qkv_bias,
                                             const void* cos_t, const void* sin_t, int64_t cs_row_stride,
                                             const int64_t* positions, const void* select_index, int sel_width,
@@ -1106,8 +1148,9 @@ extern "C" int ll_decode_attention_partials(void* out, const float* qkv_partials
                                             int64_t v_stride_h, int64_t o_stride_b, int64_t o_stride_h,
                                             int64_t table_stride_b, int dtype, int req_width, int seq_width,
                                             const void* q_norm_weight, const void* k_norm_weight, float norm_eps,
-                                            void* stream) {
+                                            const float* int32_a_scale, const float* int32_w_scale, void* stream) {
   if (!qkv_partials || !cos_t || !sin_t || !positions || !select_index) return LL_ERR_ARG;
+  if ((int32_a_scale != nullptr) != (int32_w_scale != nullptr) || !ll_aligned16(int32_w_scale)) return LL_ERR_ARG;
   if ((q_norm_weight != nullptr) != (k_norm_weight != nullptr) || !ll_aligned16(q_norm_weight) || !ll_aligned16(k_norm_weight))
     return LL_ERR_ARG;
   if (sel_width != LL_I32 && sel_width != LL_I64) return LL_ERR_DTYPE;
@@ -1121,6 +1164,8 @@ extern "C" int ll_decode_attention_partials(void* out, const float* qkv_partials
   rp.qnw = (const uint16_t*)q_norm_weight;
   rp.knw = (const uint16_t*)k_norm_weight;
   rp.nrm_eps = norm_eps;
+  rp.q_as = int32_a_scale;
+  rp.q_ws = int32_w_scale;
   // q pointer / strides are unused in this mode; pass the pool (aligned, non-null) to satisfy the argument checks
   return fd_entry(out, k_cache, k_cache, v_cache, table, b_req_idx, b_seq_len, nullptr, nullptr, batch, hq, hkv, d, max_len,
                   qk_scale, 8, 8, k_stride_t, k_stride_h, v_stride_t, v_stride_h, o_stride_b, o_stride_h, table_stride_b,

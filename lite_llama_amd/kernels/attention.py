@@ -201,14 +201,19 @@ def decode_attention_partials(parts, bias, num_heads: int, num_kv_heads: int, he
     """:func:`decode_attention` whose ``q | k | v`` come as the fp32 split-K partials of the fused projection
     (``PartialSums`` ``[S, B, (Hq + 2 Hkv) D]``, ``bias`` the projection bias or ``None``): every workgroup adds the
     partials of its (row, KV head) -- plus bias, one rounding to the pool dtype: the value the projection itself would
-    have stored -- and continues as ``decode_attention`` (``qk_norm`` as there).  Returns ``None`` when the shape is not served (contexts of
+    have stored -- and continues as ``decode_attention`` (``qk_norm`` as there).  ``parts`` may also be the
+    ``ScaledInt32Partials`` of a smoothquant projection (fp16, head_dim 128): the launch applies the scale epilogue.  Returns ``None`` when the shape is not served (contexts of
     129..1024 tokens, head_dim >= 64, <= 16 query heads per KV head): finish the sums and call ``decode_attention``."""
     p = parts.parts
+    scaled = p.dtype == torch.int32  # smoothquant: exact int32 planes + per-token / per-channel scales (ScaledInt32Partials)
+    if scaled and (qk_norm is not None or head_dim != 128 or kv_buffer.dtype != torch.float16
+                   or getattr(parts, "a_scale", None) is None):
+        return None
     L.require_cuda(p, bias, cos_table, sin_table, positions, select_index, kv_buffer, b_req_tokens_table, b_req_idx, b_seq_len)
     s_count, batchs, row_w = p.shape
     dt = kv_buffer.dtype
     positions = positions.reshape(-1)
-    if (p.dtype != torch.float32 or row_w != (num_heads + 2 * num_kv_heads) * head_dim or head_dim < 64 or head_dim % 32 or num_heads % num_kv_heads
+    if ((p.dtype != torch.float32 and not scaled) or row_w != (num_heads + 2 * num_kv_heads) * head_dim or head_dim < 64 or head_dim % 32 or num_heads % num_kv_heads
             or num_heads // num_kv_heads > 16 or s_count > 8 or not p.is_contiguous() or parts.dtype != dt
             or dt not in (torch.float16, torch.bfloat16) or cos_table.dtype != dt or sin_table.dtype != dt
             or cos_table.dim() != 2 or cos_table.stride(1) != 1 or sin_table.stride(1) != 1
@@ -233,7 +238,8 @@ def decode_attention_partials(parts, bias, num_heads: int, num_kv_heads: int, he
             k_cache.stride(0), k_cache.stride(1), v_cache.stride(0), v_cache.stride(1), out.stride(0), out.stride(1),
             b_req_tokens_table.stride(0), L.dtype_code(dt), L.index_width(b_req_idx), L.index_width(b_seq_len),
             L.ptr(None if qk_norm is None else qk_norm[0]), L.ptr(None if qk_norm is None else qk_norm[1]),
-            0.0 if qk_norm is None else float(qk_norm[2]), L.stream_ptr(),
+            0.0 if qk_norm is None else float(qk_norm[2]), parts.a_scale.data_ptr() if scaled else 0,
+            parts.w_scale.data_ptr() if scaled else 0, L.stream_ptr(),
         ),
         "decode_attention_partials",
     )

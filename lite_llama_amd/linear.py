@@ -288,8 +288,8 @@ class MergedColumnLinear:
         to it) for a consumer that adds them up (``decode_attention_partials``); ``None`` when not served."""
         h = self._holder
         if h is None or h.interleaved or not hasattr(h.quant_method, "apply_partials") or get_tp_world_size() != 1 \
-                or collective_forced() or getattr(h.quant_method, "takes_int8_rows", False):
-            return None  # (smoothquant leaves int32 planes + scales: only the norm launch takes those)
+                or collective_forced():
+            return None
         parts = h.quant_method.apply_partials(h, x, allow_bias=True, max_splits=8)  # the attention kernel adds <= 8 planes
         return None if parts is None else (parts, h.bias)
 

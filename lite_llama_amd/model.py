@@ -282,7 +282,10 @@ class Attention(nn.Module):
                 if out is not None:
                     return self.o_proj(out.view(batch, seq_len, self.q_size), partials_ok)
                 # not served (context outside 129..1024 tokens, ...): finish the sums and take the ordinary route
-                qkv = pq[0].materialise() if pq[1] is None else (pq[0].parts.sum(0) + pq[1].float()).to(pq[0].dtype)
+                if isinstance(pq[0], ScaledInt32Partials):
+                    qkv = pq[0].materialise() if pq[1] is None else (pq[0].materialise().float() + pq[1].float()).to(pq[0].dtype)
+                else:
+                    qkv = pq[0].materialise() if pq[1] is None else (pq[0].parts.sum(0) + pq[1].float()).to(pq[0].dtype)
                 xq, xkv = torch.split(qkv.view(-1, self.q_size + 2 * self.kv_size), [self.q_size, 2 * self.kv_size], dim=-1)
             else:
                 xq, xkv = self._qkv(x2)

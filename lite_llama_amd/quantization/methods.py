@@ -276,7 +276,9 @@ class SmoothQuantLinearMethod(LinearQuantMethod):
         ``None`` -> the caller runs :meth:`apply`."""
         if layer.bias is not None and not allow_bias:
             return None
-        return smoothquant_matmul_partials(x, layer.weight, layer.weight_scale_inv, bias=layer.bias, max_splits=max_splits)
+        # (``allow_bias``: the consumer adds the bias itself -- the planes never carry it twice)
+        return smoothquant_matmul_partials(x, layer.weight, layer.weight_scale_inv, bias=None if allow_bias else layer.bias,
+                                           max_splits=max_splits)
 
     def apply_gate_up_swiglu(self, layer, x):
         """``layer`` holds gate/up row-interleaved: the int8 GEMM + ONE launch for the scale epilogue and the activation."""

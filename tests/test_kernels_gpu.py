@@ -474,6 +474,52 @@ def test_decode_attention_with_head_norm_equals_skip_rmsnorm_then_the_launch(hq,
                             qk_norm=(qw.float(), kw.float(), eps)) is None
 
 
+@pytest.mark.parametrize("hq,hkv", [(32, 8), (28, 4)])
+def test_decode_attention_over_smoothquant_planes_equals_the_finished_projection(hq, hkv):
+    """q | k | v left by a smoothquant projection as exact int32 split-K planes + scales (ll_dense_partials wfmt 3): the
+    one-launch decode attention applies (acc * a_scale[m]) * w_scale[n] (+ bias) itself -- bit-equal, output and pool rows, to
+    smoothquant_matmul followed by the launch over the finished tensor."""
+    from lite_llama_amd.kernels.attention import decode_attention, decode_attention_partials
+    from lite_llama_amd.kernels.quantization import smoothquant_matmul_partials
+    torch.manual_seed(hq)
+    d, H = 128, 1024
+    lens = [130, 600, 333, 1024, 257]
+    b = len(lens)
+    total = sum(lens)
+    pool = torch.randn(total + 8, 2 * hkv, d, device=DEV).half()
+    perm = torch.randperm(total, device=DEV).to(torch.int32)
+    table = torch.zeros(b, max(lens), dtype=torch.int32, device=DEV)
+    off = 0
+    for i, n in enumerate(lens):
+        table[i, :n] = perm[off:off + n]
+        off += n
+    seq = torch.tensor(lens, dtype=torch.int64, device=DEV)
+    req = torch.arange(b, dtype=torch.int64, device=DEV)
+    sel = table[req, seq - 1].contiguous()
+    pos = (seq - 1).clone()
+    inv = 1.0 / (5e5 ** (torch.arange(0, d, 2, device=DEV, dtype=torch.float32) / d))
+    fr = torch.arange(max(lens) + 8, device=DEV, dtype=torch.float32)[:, None] * inv[None, :]
+    emb = torch.cat([fr, fr], dim=-1)
+    cos, sin = emb.cos().half(), emb.sin().half()
+    row_w = (hq + 2 * hkv) * d
+    x = (torch.randn(b, H, device=DEV) * 0.5).half()
+    qw, sc = O.quantize_int8_per_channel(torch.randn(row_w, H) * 0.05)
+    qw, sc = qw.to(DEV), sc.to(DEV)
+    bias = (torch.randn(row_w, device=DEV) * 0.05).half()
+    scale = 1.0 / d ** 0.5
+    for bb in (None, bias):
+        proj = K().smoothquant_matmul(x, qw, sc, bias=bb)
+        q, kv = proj[:, : hq * d].view(b, hq, d), proj[:, hq * d:].view(b, 2 * hkv, d)
+        pool_ref = pool.clone()
+        want = decode_attention(q, kv, cos, sin, pos, sel, pool_ref, scale, table, req, seq, max(lens))
+        parts = smoothquant_matmul_partials(x, qw, sc, max_splits=8)
+        assert parts is not None and parts.parts.dtype == torch.int32 and parts.bias is None
+        pool_p = pool.clone()
+        got = decode_attention_partials(parts, bb, hq, hkv, d, cos, sin, pos, sel, pool_p, scale, table, req, seq, max(lens))
+        assert got is not None
+        assert torch.equal(pool_p, pool_ref) and torch.equal(got.view(torch.int16), want.view(torch.int16))
+
+
 # ------------------------------------------------------------------------------------- #
 # w4a16 (tol 5e-2; nibble unpack bit-exact)
 # ------------------------------------------------------------------------------------- #

@@ -475,6 +475,84 @@ def test_qwen3_shape_decode_layer_fuses_the_head_norm_and_matches_oracle(quant, 
 
 
 @pytest.mark.gpu
+def test_smoothquant_shape_decode_layer_route_and_oracle(monkeypatch):
+    """Llama-3 attention geometry (heads of 128, GQA 4, no bias), SmoothQuant W8A8, one decode step: the block runs
+    quantiser-in-norm -> int8 q|k|v planes -> one-launch attention over the int32 planes -> o planes -> norm + quantiser ->
+    gate|up planes -> finish + swiglu -> down planes (no finish launch anywhere) -- route asserted, logits against
+    oracle/model.py (smoothquant) and against the unfused route (LL_NO_Q8_FUSION / LL_W8A8_NO_PARTIALS)."""
+    from lite_llama_amd.model import CausalLM, tiny_geometry
+    from lite_llama_amd.quantization import QuantConfig
+    from lite_llama_amd.kernels.norm_act import Int8Rows, ScaledInt32Partials
+    from oracle.model import OracleModel
+    import lite_llama_amd.model as M
+
+    H, I, L, HQ, HKV, D, V = 2048, 4096, 1, 16, 4, 128, 1024
+    B, CTX = 8, 300
+    g = torch.Generator().manual_seed(77)
+    geo = tiny_geometry(hidden_size=H, intermediate_size=I, num_layers=L, num_heads=HQ, num_kv_heads=HKV, head_dim=D,
+                        vocab_size=V, rope_theta=500000.0, rms_norm_eps=1e-5, qkv_bias=False)
+    m = CausalLM(geo)
+    params = {}
+    for name, t in m.state_dict().items():
+        if name.endswith("norm_weight") or name.endswith("layernorm_weight"):
+            params[name] = (1 + 0.1 * torch.randn(t.shape, generator=g)).half()
+        else:
+            params[name] = (0.02 * torch.randn(t.shape, generator=g)).half()
+    m.load_state_dict(params, strict=True)
+    m = m.to("cuda")
+    m.quantize_(QuantConfig.smoothquant_per_channel())
+    m.rotary_emb.ensure(CTX + 8, "cuda")
+    rows = B * (CTX + 1)
+    kv_cpu = [(torch.randn(rows, 2 * HKV, D, generator=g) * 0.5).half() for _ in range(L)]
+    table = torch.arange(rows, dtype=torch.int32).view(B, CTX + 1)
+    ids = torch.randint(0, V, (B, 1), generator=g)
+    pos = torch.full((B, 1), CTX)
+
+    def info_on(dev, kv):
+        return types.SimpleNamespace(
+            kv_buffer=kv, cur_select_index=table[:, CTX].contiguous().to(dev), b_req_tokens_table=table.clone().to(dev),
+            b_start_loc=None, b_req_idx=torch.arange(B, dtype=torch.int32, device=dev),
+            b_seq_len=torch.full((B,), CTX + 1, dtype=torch.int32, device=dev), max_actual_seq_len=CTX + 1)
+
+    calls = {"attn_int32": 0, "norm_q8_planes": 0, "norm_q8_rows": 0}
+    real_attn, real_q8 = M.decode_attention_partials, M.skip_rmsnorm_q8
+
+    def attn(parts, *a, **k):
+        out = real_attn(parts, *a, **k)
+        calls["attn_int32"] += int(out is not None and isinstance(parts, ScaledInt32Partials))
+        return out
+
+    def q8(X, *a, **k):
+        out = real_q8(X, *a, **k)
+        calls["norm_q8_planes"] += int(isinstance(X, ScaledInt32Partials))
+        calls["norm_q8_rows"] += int(isinstance(out[0], Int8Rows))
+        return out
+
+    monkeypatch.setattr(M, "decode_attention_partials", attn)
+    monkeypatch.setattr(M, "skip_rmsnorm_q8", q8)
+    kv_gpu = [k.clone().cuda() for k in kv_cpu]
+    with torch.no_grad():
+        got = m(ids.cuda(), pos.cuda(), info_on("cuda", kv_gpu))
+    # input norm (fp16 in, int8 rows out), post-attention norm (o planes in, rows out), final norm (down planes in, fp16 out)
+    assert calls == {"attn_int32": 1, "norm_q8_planes": 2, "norm_q8_rows": 2}, calls
+
+    monkeypatch.setattr(M, "_Q8_FUSION", False)
+    monkeypatch.setenv("LL_W8A8_NO_PARTIALS", "1")
+    kv_two = [k.clone().cuda() for k in kv_cpu]
+    with torch.no_grad():
+        two = m(ids.cuda(), pos.cuda(), info_on("cuda", kv_two))
+    assert torch.equal(got, two) and torch.equal(kv_gpu[0], kv_two[0])   # integer sums are exact: the two routes agree bit for bit
+
+    om = OracleModel({k: v.clone() for k, v in params.items()}, H, I, L, HQ, HKV, D, V, eps=geo.rms_norm_eps,
+                     rope_theta=geo.rope_theta, quant="smoothquant")
+    kv_ref = [k.clone() for k in kv_cpu]
+    ref = om.forward(ids, pos, info_on("cpu", kv_ref))
+    new_rows = table[:, CTX].long()
+    torch.testing.assert_close(kv_gpu[0][new_rows.cuda()].float().cpu(), kv_ref[0][new_rows].float(), rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=1e-1, atol=1e-1)
+
+
+@pytest.mark.gpu
 def test_engine_sampling_path_graph_equals_eager():
     """Non-greedy decode through the sampler kernels inside the captured step: with a vanishing top_p the
     nucleus is the single most probable token, so the stochastic path must reproduce greedy decoding
