@@ -257,3 +257,20 @@ def test_w4a16_plans_cover_every_unit_once():
                 assert max(wgs) in owners, (n, k, ep, t, wgs)   # the owner is the highest-numbered workgroup of its tile
     pl = _v3_plan(lib, 37888, 3584, 1)   # the headline gate|up launch: stream-K over 256-row tiles
     assert (pl["nf"], pl["tiles"], pl["chunks"], pl["upw"], pl["grid"]) == (2, 148, 28, 17, 244), pl
+
+
+def test_int8_rows_regroup_only_their_leading_dimensions():
+    """kernels/norm_act.py::Int8Rows stands in for the fp16 activations of a smoothquant block (the quantiser ran inside the
+    norm launch): callers re-group its leading dimensions like a tensor's; the row width never changes."""
+    import pytest
+    from lite_llama_amd.kernels.norm_act import Int8Rows
+
+    q = torch.zeros(6, 32, dtype=torch.int8)
+    s = torch.ones(6)
+    r = Int8Rows(q, s, (2, 3, 32))
+    assert r.shape == (2, 3, 32) and r.dtype == torch.float16 and r.numel() == 6 * 32
+    flat = r.view(-1, 32)
+    assert flat.shape == (6, 32) and flat.q is q and flat.scale is s
+    assert r.view(3, -1, 32).shape == (3, 2, 32) and r.view((6, 32)).shape == (6, 32)
+    with pytest.raises(ValueError):
+        r.view(-1, 16)
