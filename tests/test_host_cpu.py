@@ -274,3 +274,25 @@ def test_int8_rows_regroup_only_their_leading_dimensions():
     assert r.view(3, -1, 32).shape == (3, 2, 32) and r.view((6, 32)).shape == (6, 32)
     with pytest.raises(ValueError):
         r.view(-1, 16)
+
+
+def test_scaled_int32_partials_materialise_is_the_reference_smoothquant_epilogue():
+    """kernels/norm_act.py::ScaledInt32Partials (what a smoothquant projection leaves for its consumer at decode shapes): summing
+    the exact int32 split-K planes and applying (acc.f32 * a_scale[m]) * w_scale[n] (+ bias) -- w8a8.py:118-120 -- gives the
+    oracle's smoothquant_matmul bit for bit, however the contraction was split."""
+    from lite_llama_amd.kernels.norm_act import ScaledInt32Partials
+    from oracle import oracle as O
+
+    torch.manual_seed(3)
+    M, N, K_ = 5, 48, 256
+    x = (torch.randn(M, K_) * 0.5).half()
+    qw, sc = O.quantize_int8_per_channel(torch.randn(N, K_) * 0.05)
+    bias = (torch.randn(N) * 0.1).half()
+    qa, a_scale = O.quantize_activations_int8(x)
+    cuts = [0, 64, 192, 256]
+    planes = torch.stack([(qa[:, a:b].int() @ qw[:, a:b].int().T) for a, b in zip(cuts[:-1], cuts[1:])]).to(torch.int32)
+    acc_ref, _, _ = O.smoothquant_int32_acc(x, qw)
+    assert torch.equal(planes.sum(0, dtype=torch.int32), acc_ref)
+    for b in (None, bias):
+        parts = ScaledInt32Partials(planes, (M, N), a_scale, sc.reshape(-1).float(), b)
+        assert torch.equal(parts.materialise(), O.smoothquant_matmul(x, qw, sc, bias=b))
