@@ -154,7 +154,7 @@ def gemm_roofline(model, batch, quant, iters=6):
     e1.record(stream)
     torch.cuda.synchronize()
     nl = len(launches_list)
-    launches = iters * nl * (2 if quant == "smoothquant" else 1)
+    launches = iters * nl  # projections timed (a format's quantiser / finish launches ride inside their projection's share)
     avg_s = e0.elapsed_time(e1) * 1e-3 / (iters * nl)
     bytes_per_launch = nbytes / nl
     achieved = bytes_per_launch / avg_s
