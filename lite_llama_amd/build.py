@@ -37,7 +37,8 @@ def sources() -> list[str]:
 
 def _digest(paths: list[str]) -> str:
     h = hashlib.sha256()
-    for p in sorted(paths) + [os.path.join(CSRC, "common.h"), os.path.join(HERE, "..", "include", "lite_llama_amd.h")]:
+    headers = sorted(os.path.join(CSRC, f) for f in os.listdir(CSRC) if f.endswith(".h"))
+    for p in sorted(paths) + headers + [os.path.join(HERE, "..", "include", "lite_llama_amd.h")]:
         with open(p, "rb") as f:
             h.update(f.read())
     h.update(" ".join(FLAGS).encode())

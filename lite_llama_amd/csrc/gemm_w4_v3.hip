@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_w4_common.h"
 
 #define V3_BN 128
 #define V3_BM 64
@@ -66,9 +67,6 @@ struct V3Lds {
 #else
 #define V3_ABL(B) false
 #endif
-
-typedef unsigned u32x2 __attribute__((ext_vector_type(2)));
-typedef unsigned u32x4 __attribute__((ext_vector_type(4)));
 
 struct V3Params {
   uint16_t* out;
@@ -111,43 +109,6 @@ struct V3Params {
 #define V3_TL_FENCE(CUR)
 #endif
 
-__device__ __forceinline__ uint32_t v3_pk_add(uint32_t a, uint32_t b) {
-  return __builtin_bit_cast(uint32_t, __builtin_bit_cast(f16x2, a) + __builtin_bit_cast(f16x2, b));
-}
-__device__ __forceinline__ uint32_t v3_pk_fma(uint32_t a, uint32_t b, uint32_t c) {
-  f16x2 r = __builtin_elementwise_fma(__builtin_bit_cast(f16x2, a), __builtin_bit_cast(f16x2, b),
-                                      __builtin_bit_cast(f16x2, c));
-  return __builtin_bit_cast(uint32_t, r);
-}
-__device__ __forceinline__ uint32_t v3_and_or(uint32_t w, uint32_t mask, uint32_t magic) {
-  uint32_t r;
-  asm("v_and_or_b32 %0, %1, %2, %3" : "=v"(r) : "v"(w), "s"(mask), "v"(magic));
-  return r;
-}
-// One packed word -> eight fp16 weights in natural k order (the packer stores nibble 2i of a k-octet at
-// position i and nibble 2i+1 at position 4+i).  Exact unpack: (w & 0x000F000F) | 0x6400 = (1024 + q_i,
-// 1024 + q_{4+i}); the offset is removed exactly, then ONE fp16 fma with (s, -z*s): the same arithmetic as
-// gemm_wq.hip.  Error against the reference's fp16(fp32((q - z) * s)): <= 3 fp16 ulps of the
-// weight (roundings of s, of z*s and of the fma), stated in DESIGN.md.
-__device__ __forceinline__ f16x8 v3_dequant(uint32_t w, uint32_t s, uint32_t nzs, uint32_t magic) {
-  const uint32_t w2 = w >> 8;
-  uint32_t a = v3_and_or(w, 0x000F000Fu, magic);
-  uint32_t b = v3_and_or(w, 0x00F000F0u, magic);
-  uint32_t c = v3_and_or(w2, 0x000F000Fu, magic);
-  uint32_t d = v3_and_or(w2, 0x00F000F0u, magic);
-  a = v3_pk_add(a, 0xE400E400u);
-  b = v3_pk_fma(b, 0x2C002C00u, 0xD400D400u);
-  c = v3_pk_add(c, 0xE400E400u);
-  d = v3_pk_fma(d, 0x2C002C00u, 0xD400D400u);
-  u32x4 o;
-  o.x = v3_pk_fma(a, s, nzs);
-  o.y = v3_pk_fma(b, s, nzs);
-  o.z = v3_pk_fma(c, s, nzs);
-  o.w = v3_pk_fma(d, s, nzs);
-  return __builtin_bit_cast(f16x8, o);
-}
-
-
 // The workgroup's unit sequence: up to three segments (tail of the last tile, the full tiles, head of the
 // first tile), each a run of consecutive chunks that wraps into the next tile.  A walker keeps (tile, chunk)
 // and two countdowns; the per-unit path is three scalar adds and two compares, the fix-up at the end of a tile
@@ -183,42 +144,6 @@ __device__ __forceinline__ void v3_walk_next(V3Walk& w, const V3Seq& q) {
   }
 }
 
-// LDS-DMA: 64 lanes x 16 B (or 4 B) from saddr + voff to the wave-uniform LDS byte address lds_dst + lane * size.
-// M0 carries the LDS address and is compiler-reserved: saved and restored inside the statement.
-__device__ __forceinline__ const void* v3_uniform_ptr(const void* p) {  // provably wave-uniform for the "s" constraint
-  const uint64_t a = (uint64_t)p;
-  const uint32_t lo = __builtin_amdgcn_readfirstlane((uint32_t)a), hi = __builtin_amdgcn_readfirstlane((uint32_t)(a >> 32));
-  return (const void*)(((uint64_t)hi << 32) | lo);
-}
-// NT: the non-temporal cache policy for data this CU reads once (the weight stream) -- never for the activation tile,
-// which every workgroup re-reads from L2
-#ifndef V3_NT_W
-#define V3_NT_W 1
-#endif
-template <bool NT = false>
-__device__ __forceinline__ void v3_dma16(uint32_t lds_dst, const void* sbase, uint32_t voff) {
-  uint32_t keep;
-  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
-  sbase = v3_uniform_ptr(sbase);
-  if constexpr (NT)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %2, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
-}
-template <bool NT = false>
-__device__ __forceinline__ void v3_dma4(uint32_t lds_dst, const void* sbase, uint32_t voff) {
-  uint32_t keep;
-  lds_dst = __builtin_amdgcn_readfirstlane(lds_dst);
-  sbase = v3_uniform_ptr(sbase);
-  if constexpr (NT)
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3 nt\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
-  else
-    asm volatile("s_mov_b32 %0, m0\n\ts_mov_b32 m0, %1\n\ts_nop 0\n\tglobal_load_lds_dword %2, %3\n\ts_mov_b32 m0, %0"
-                 : "=&s"(keep) : "s"(lds_dst), "v"(voff), "s"(sbase) : "memory");
-}
 // One statement per unit and loader wave (M0 saved / restored once, the pieces' LDS addresses in scalar registers): a weight
 // loader's four 1-KB pieces + two 256-B scale pieces, an activation loader's eight 1-KB pieces.
 #define V3_STR2(X) #X
@@ -280,10 +205,6 @@ __device__ __forceinline__ void v3_dma_x(uint32_t dx, const void* xb, const uint
 #ifndef V3_START_FILL
 #define V3_START_FILL 8
 #endif
-template <int N>
-__device__ __forceinline__ void v3_vmcnt() {
-  asm volatile("s_waitcnt vmcnt(%0)" ::"n"(N) : "memory");
-}
 // at most k units of OPS memory operations each may still be in flight
 template <int OPS>
 __device__ __forceinline__ void v3_wait_units(int k) {
@@ -1151,6 +1072,9 @@ static int v3_launch(void* out, const void* x, const void* wpacked, const void* 
   const bool partials = (epilogue & 3) == 2;
   if (partials && (bias || !ll_w4a16_partials_count(m, n, k, group_size))) return LL_ERR_SHAPE;
   const V3Plan pl = v3_plan(n, k, (epilogue >> 8) & 3, partials);
+  // round 5: the row-group engine (gemm_w4_v4.hip) takes the launch when its plan serves the shape -- same layouts, same planes
+  if (v4_wants(m, n, k, group_size, epilogue))
+    return v4_launch(out, x, wpacked, spacked, bias, m, n, k, group_size, x_stride_m, epilogue & 3, partials ? pl.gt : 1, stream);
   epilogue &= 3;
   V3Params p{};
   p.out = (uint16_t*)out; p.x = (const uint16_t*)x; p.wp = wpacked; p.sp = spacked; p.bias = (const uint16_t*)bias;

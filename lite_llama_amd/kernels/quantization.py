@@ -190,10 +190,11 @@ def w4a16_matmul_prepacked(x, packed_weight, packed_scales, *, group_size: int =
     return out.reshape(*leading, n_out)
 
 
-def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 128):
+def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 128, _unit_loop_engine: bool = False):
     """Decode-step extension: the projection as ``S`` fp32 split-K partial sums (:class:`PartialSums`) for
     :func:`skip_rmsnorm_partials` to add up -- the GEMM has no cross-workgroup merge then.  ``None`` when the shape
-    is not served (the caller runs :func:`w4a16_matmul_prepacked`)."""
+    is not served (the caller runs :func:`w4a16_matmul_prepacked`).  ``_unit_loop_engine`` (tests / tuning): the same planes
+    from the third-generation body (gemm_w4_v3.hip) instead of the row-group loop (gemm_w4_v4.hip)."""
     from .norm_act import PartialSums
     L.require_cuda(x, packed_weight, packed_scales)
     n, k = packed_weight.shape[0] * 128, packed_weight.shape[1] * 128
@@ -207,7 +208,8 @@ def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 
     if s < 1:
         return None
     parts = torch.empty((s, m, n), dtype=torch.float32, device=x.device)
-    _launch_prepacked(parts.data_ptr(), a, m, n, k, packed_weight, packed_scales, None, group_size, 2, "w4a16_matmul_partials")
+    _launch_prepacked(parts.data_ptr(), a, m, n, k, packed_weight, packed_scales, None, group_size,
+                      2 | (0x100 if _unit_loop_engine else 0), "w4a16_matmul_partials")
     return PartialSums(parts, (*x.shape[:-1], n), x.dtype)
 
 
