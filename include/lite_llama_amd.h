@@ -63,6 +63,11 @@ int ll_skip_rmsnorm(void* y, const void* x, void* residual, const void* weight,
 int ll_swiglu(void* c, const void* a, const void* b, int64_t rows, int64_t n, int dtype,
               void* stream);
 
+/* ---- element-wise activations  (kernels/activations.py:19-57: relu, leaky_relu, tanh, gelu) ----
+ * y[i] = f(x[i].f32) rounded to the storage dtype; kind 0 relu, 1 leaky_relu (slope 0.01 in the storage dtype),
+ * 2 tanh, 3 gelu (erf form); n contiguous elements, y may alias x. */
+int ll_activation(void* y, const void* x, int64_t n, int kind, int dtype, void* stream);
+
 /* ---- a2: rope_emb_forward  (kernels/rope_emb.py:86-134) ---------------------
  * In-place half-split rotation of q [tokens, n_qh, hd] and k [tokens, n_kh, hd]
  * (head and dim contiguous, row strides given).  Token t reads

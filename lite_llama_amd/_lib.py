@@ -27,6 +27,7 @@ SIGNATURES = {
     "ll_abi_version": [],
     "ll_skip_rmsnorm": [P, P, P, P, L, L, F, I, P],
     "ll_swiglu": [P, P, P, L, L, I, P],
+    "ll_activation": [P, P, L, I, I, P],
     "ll_rope": [P, P, P, P, L, I, I, I, L, L, L, L, L, L, L, I, I, P],
     "ll_rope_kv_update": [P, P, P, P, P, P, L, I, I, I, L, L, L, L, L, L, L, L, L, I, I, I, P, P],
     "ll_update_kv_buffer": [P, P, P, L, I, I, L, L, L, L, I, P],

@@ -398,6 +398,52 @@ extern "C" int ll_silu_and_mul(void* out, const void* x, int64_t rows, int64_t n
 }
 
 // --------------------------------------------------------------------------- //
+// relu / leaky_relu / tanh / gelu -- the element-wise names of lite_llama/kernels/activations.py:19-57 (device helpers of
+// the reference's Triton kernels; no caller in its models).  kind 0 relu: max(0, x); 1 leaky_relu: x >= 0 ? x : 0.01 x
+// (the slope in the storage dtype, as the reference casts it); 2 tanh: 2 / (1 + exp(-2 x)) - 1; 3 gelu: x / 2 (1 + erf(x / sqrt 2));
+// fp32 arithmetic, one rounding to the storage dtype.
+// --------------------------------------------------------------------------- //
+template <int DT, int VEC>
+__global__ __launch_bounds__(256) void activation_kernel(uint16_t* __restrict__ y, const uint16_t* __restrict__ x, int64_t n,
+                                                         int kind) {
+  const int64_t nvec = n / VEC;
+  for (int64_t i = (int64_t)blockIdx.x * 256 + threadIdx.x; i < nvec; i += (int64_t)gridDim.x * 256) {
+    uint16_t xv[VEC], yv[VEC];
+    VecIO<VEC>::load(x + i * VEC, xv);
+#pragma unroll
+    for (int j = 0; j < VEC; ++j) {
+      const float v = to_f32<DT>(xv[j]);
+      float r;
+      if (kind == 0) r = v > 0.f ? v : 0.f;
+      else if (kind == 1) r = v >= 0.f ? v : to_f32<DT>(mul_storage<DT>(from_f32<DT>(0.01f), xv[j]));
+      else if (kind == 2) r = 2.f / (1.f + expf(-2.f * v)) - 1.f;
+      else r = v * 0.5f * (1.f + erff(v * 0.70710678118654752440f));
+      yv[j] = (kind == 0 && v != v) ? xv[j] : from_f32<DT>(r);  // relu keeps a NaN (tl.maximum propagates it)
+    }
+    VecIO<VEC>::store(y + i * VEC, yv);
+  }
+}
+
+extern "C" int ll_activation(void* y, const void* x, int64_t n, int kind, int dtype, void* stream) {
+  if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (n < 0 || kind < 0 || kind > 3) return LL_ERR_SHAPE;
+  if (!y || !x) return n == 0 ? LL_OK : LL_ERR_ARG;
+  if (n == 0) return LL_OK;
+  hipStream_t st = (hipStream_t)stream;
+  const bool vec = (n % 8 == 0) && ll_aligned16(y) && ll_aligned16(x);
+  const int64_t total = vec ? n / 8 : n;
+  const unsigned grid = (unsigned)((total + 255) / 256 > 8192 ? 8192 : (total + 255) / 256);
+#define LL_ACT(DT, VEC) activation_kernel<DT, VEC><<<dim3(grid), 256, 0, st>>>((uint16_t*)y, (const uint16_t*)x, n, kind)
+  if (dtype == LL_F16) {
+    if (vec) LL_ACT(LL_F16, 8); else LL_ACT(LL_F16, 1);
+  } else {
+    if (vec) LL_ACT(LL_BF16, 8); else LL_ACT(LL_BF16, 1);
+  }
+#undef LL_ACT
+  return LL_LAUNCH_CHECK();
+}
+
+// --------------------------------------------------------------------------- //
 // moe_sum -- reference lite_llama/kernels/fused_moe.py:318-335
 // --------------------------------------------------------------------------- //
 template <int DT, int VEC>

@@ -98,6 +98,10 @@ class RowParallelLinear(LinearBase):
         all-reduce of the local answers -- ``LL_W4_NO_PARTIALS`` on any rank simply turns the route off for the group -- on
         the first eager call (every rank walks the same call sequence); a call inside a graph capture that finds no
         decision takes the unfused route, on every rank alike."""
+        # rank-uniform part first (format, group size, row count, bias: the same answer on every rank) -- formats that can
+        # never take the fused launch must not enter a host-synchronising collective at all (ADVICE round 4)
+        if not self._tp_partials_ok(rows):
+            return False
         cache = self.__dict__.setdefault("_tp_fused_cache", {})
         if rows in cache:
             return cache[rows]
@@ -105,7 +109,7 @@ class RowParallelLinear(LinearBase):
             return False
         from .distributed.parallel_state import all_reduce_min
         mine = 0
-        if self._tp_partials_ok(rows) and not os.environ.get("LL_W4_NO_PARTIALS"):
+        if not os.environ.get("LL_W4_NO_PARTIALS"):
             from . import _lib as L
             mine = 1 if L.lib().ll_w4a16_partials_count(rows, self.output_size, self.input_size, self.quant.group_k) > 0 else 0
         cache[rows] = bool(all_reduce_min(mine))

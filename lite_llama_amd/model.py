@@ -265,8 +265,13 @@ class Attention(nn.Module):
         # Qwen3: the per-head q / k RMSNorm rides inside the one-launch decode attention (head size 128)
         qk_norm = (self.q_norm_weight, self.k_norm_weight, self.eps) if self.use_qk_norm else None
         norm_fused = qk_norm is None or (self.head_dim == 128 and not os.environ.get("LL_NO_FUSED_QK_NORM"))
+        # smoothquant q|k|v planes are int32: the attention launch only takes them for head size 128, an fp16 pool and no head
+        # norm -- known before the projection runs, so other geometries keep the finished projection (the
+        # planes GEMM + a torch finish on every step otherwise, and a bias added after the first rounding)
+        int32_planes_ok = not getattr(self.q_proj.quant_method, "takes_int8_rows", False) or (
+            self.head_dim == 128 and qk_norm is None and atten_info.kv_buffer[layer_index].dtype == torch.float16)
         if (seq_len == 1 and norm_fused and not _TWO_CALL_ATTENTION and isinstance(position_embeddings, RopeTables)
-                and not fp8_pool and self._qkv.refresh() and not os.environ.get("LL_NO_QKV_PARTIALS")
+                and not fp8_pool and int32_planes_ok and self._qkv.refresh() and not os.environ.get("LL_NO_QKV_PARTIALS")
                 and decode_attention_partials_supported(atten_info.max_actual_seq_len, self.num_heads, self.num_kv_heads,
                                                         self.head_dim)):
             # decode, int4, TP = 1: the fused q|k|v projection leaves fp32 split-K partials and the one-launch attention
@@ -283,7 +288,10 @@ class Attention(nn.Module):
                     return self.o_proj(out.view(batch, seq_len, self.q_size), partials_ok)
                 # not served (context outside 129..1024 tokens, ...): finish the sums and take the ordinary route
                 if isinstance(pq[0], ScaledInt32Partials):
-                    qkv = pq[0].materialise() if pq[1] is None else (pq[0].materialise().float() + pq[1].float()).to(pq[0].dtype)
+                    # one rounding, the bias added in fp32 like smoothquant_matmul's epilogue (w8a8.py:118-149)
+                    sp = pq[0]
+                    qkv = ScaledInt32Partials(sp.parts, sp.shape, sp.a_scale, sp.w_scale,
+                                              bias=pq[1] if pq[1] is not None else sp.bias).materialise()
                 else:
                     qkv = pq[0].materialise() if pq[1] is None else (pq[0].parts.sum(0) + pq[1].float()).to(pq[0].dtype)
                 xq, xkv = torch.split(qkv.view(-1, self.q_size + 2 * self.kv_size), [self.q_size, 2 * self.kv_size], dim=-1)
@@ -345,7 +353,10 @@ def add_norm(hidden_states, residual, weight, eps, q8: bool = False):
     ``q8`` (smoothquant blocks): the consumer reads per-token int8 rows -- the quantiser runs inside the norm launch and the
     result is an ``Int8Rows``."""
     if isinstance(hidden_states, ScaledInt32Partials):
-        if hidden_states.parts.shape[2] % 8 == 0 and hidden_states.parts.shape[2] <= 8192:
+        s_count, _, width = hidden_states.parts.shape
+        # rows wider than 4096 keep four 8-value vectors per thread: more than 4 planes of them do not fit the register
+        # file at a useful occupancy (307 / 396 registers for 8 / 12 planes, ADVICE round 4) -- finish those sums first
+        if width % 8 == 0 and width <= 8192 and (width <= 4096 or s_count <= 4):
             return skip_rmsnorm_q8(hidden_states, residual, weight, eps, quantize=q8)
         hidden_states = hidden_states.materialise()
     if (q8 and torch.is_tensor(hidden_states) and hidden_states.is_cuda and hidden_states.dtype == torch.float16
@@ -544,6 +555,18 @@ class CausalLM(nn.Module):
         if freed:
             torch.cuda.empty_cache()
         return freed
+
+    def is_compacted(self) -> bool:
+        return any(getattr(m, "_w4_compact", False) or getattr(m, "_w4_compact_member", None) is not None
+                   for m in self.modules() if isinstance(m, LinearBase)) or \
+            any(getattr(mc._holder, "_w4_compact", False) for mc in self._merged_linears())
+
+    def state_dict(self, *args, **kwargs):
+        """A compacted model's int4 ``weight`` parameters alias the decode engine's load-time layout (permuted words): exporting
+        them as a checkpoint would be silently corrupt.  The reference-format tensors are restored first."""
+        if self.is_compacted():
+            self.expand_weights()
+        return super().state_dict(*args, **kwargs)
 
     @torch.no_grad()
     def expand_weights(self) -> None:

@@ -71,6 +71,11 @@ class UnquantizedLinearMethod(LinearQuantMethod):
             return None
         return dense_matmul_partials(x, layer.weight, max_splits=max_splits)
 
+    def apply_finished(self, layer, x):
+        """The measured policy for launches that write finished outputs (``dense16_wins``): own kernel where it beat the
+        library GEMM, ``F.linear`` elsewhere."""
+        return self.apply(layer, x)
+
 
 def _ordered_input(layer, x):
     """Activation-ordered GPTQ linears (``layer.act_perm``, set by the checkpoint loader) keep their weight columns in

@@ -189,6 +189,23 @@ def swiglu_forward(a, b):
     return ((af * torch.sigmoid(af)) * b.float()).to(a.dtype)
 
 
+# element-wise activation helpers (kernels/activations.py:19-57; fp32 arithmetic, one rounding)
+def activation(x, kind: str):
+    xf = x.float()
+    if kind == "relu":
+        y = torch.clamp_min(xf, 0)
+    elif kind == "leaky_relu":  # the slope is cast to the storage dtype first (activations.py:35-37)
+        slope = torch.tensor(1e-2).to(x.dtype)
+        return torch.where(x >= 0, x, slope * x)
+    elif kind == "tanh":
+        y = 2 / (1 + torch.exp(-2 * xf)) - 1
+    elif kind == "gelu":
+        y = xf * 0.5 * (1.0 + torch.erf(xf / math.sqrt(2.0)))
+    else:
+        raise ValueError(kind)
+    return y.to(x.dtype)
+
+
 # --------------------------------------------------------------------------- #
 # a8: w4a16_matmul  (kernels/quantization/w4a16.py:28-207)
 # --------------------------------------------------------------------------- #

@@ -102,6 +102,24 @@ def test_swiglu_oracle(shape):
     assert torch.count_nonzero(z) == 0
 
 
+@pytest.mark.parametrize("kind", ["relu", "leaky_relu", "tanh", "gelu"])
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_elementwise_activations_match_the_oracle(kind, dtype):
+    """The four element-wise names of kernels/activations.py through the HIP kernel (vector and scalar tails, both 16-bit
+    types) against the oracle; relu / leaky_relu are exact."""
+    for shape in [(3, 257), (64, 18944), (7,)]:
+        x = (torch.randn(shape) * 3).to(dtype)
+        got = getattr(K(), kind)(x.to(DEV)).cpu()
+        ref = O.activation(x, kind)
+        assert got.shape == x.shape and got.dtype == dtype
+        if kind in ("relu", "leaky_relu"):
+            assert torch.equal(got, ref)
+        else:
+            torch.testing.assert_close(got.float(), ref.float(), rtol=1e-2, atol=1e-2)
+    with pytest.raises((RuntimeError, ValueError)):
+        getattr(K(), kind)(torch.zeros(4, dtype=dtype))  # CPU tensor: no eager path
+
+
 @pytest.mark.parametrize("name", G.names("rope_"))
 def test_rope_golden(name):
     d = dev(G.load(name))

@@ -553,6 +553,77 @@ def test_smoothquant_shape_decode_layer_route_and_oracle(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_smoothquant_with_bias_and_small_heads_keeps_the_finished_projection(monkeypatch):
+    """Qwen2-style attention (q|k|v bias, heads of 64) under SmoothQuant: the one-launch attention does not take int32
+    planes for this geometry, so the step must not leave q|k|v as planes at all (planes GEMM + a torch
+    finish that added the bias after a first rounding) -- the q|k|v values equal ``smoothquant_matmul`` bit for bit and the
+    logits match the oracle."""
+    from lite_llama_amd.model import CausalLM, tiny_geometry
+    from lite_llama_amd.quantization import QuantConfig
+    from lite_llama_amd.kernels.norm_act import ScaledInt32Partials
+    from oracle.model import OracleModel
+    import lite_llama_amd.model as M
+
+    H, I, L, HQ, HKV, D, V = 1024, 2048, 1, 16, 4, 64, 512
+    B, CTX = 8, 200
+    g = torch.Generator().manual_seed(5)
+    geo = tiny_geometry(hidden_size=H, intermediate_size=I, num_layers=L, num_heads=HQ, num_kv_heads=HKV, head_dim=D,
+                        vocab_size=V, rope_theta=10000.0, rms_norm_eps=1e-6, qkv_bias=True)
+    m = CausalLM(geo)
+    params = {}
+    for name, t in m.state_dict().items():
+        if name.endswith("norm_weight") or name.endswith("layernorm_weight"):
+            params[name] = (1 + 0.1 * torch.randn(t.shape, generator=g)).half()
+        elif name.endswith(".bias"):
+            params[name] = (0.3 * torch.randn(t.shape, generator=g)).half()
+        else:
+            params[name] = (0.02 * torch.randn(t.shape, generator=g)).half()
+    m.load_state_dict(params, strict=True)
+    m = m.to("cuda")
+    m.quantize_(QuantConfig.smoothquant_per_channel())
+    m.rotary_emb.ensure(CTX + 8, "cuda")
+    rows = B * (CTX + 1)
+    kv_cpu = [(torch.randn(rows, 2 * HKV, D, generator=g) * 0.5).half() for _ in range(L)]
+    table = torch.arange(rows, dtype=torch.int32).view(B, CTX + 1)
+    ids = torch.randint(0, V, (B, 1), generator=g)
+    pos = torch.full((B, 1), CTX)
+
+    def info_on(dev, kv):
+        return types.SimpleNamespace(
+            kv_buffer=kv, cur_select_index=table[:, CTX].contiguous().to(dev), b_req_tokens_table=table.clone().to(dev),
+            b_start_loc=None, b_req_idx=torch.arange(B, dtype=torch.int32, device=dev),
+            b_seq_len=torch.full((B,), CTX + 1, dtype=torch.int32, device=dev), max_actual_seq_len=CTX + 1)
+
+    seen = {"int32_planes_into_attention": 0}
+    real_attn = M.decode_attention_partials
+
+    def attn(parts, *a, **k):
+        seen["int32_planes_into_attention"] += int(isinstance(parts, ScaledInt32Partials))
+        return real_attn(parts, *a, **k)
+
+    monkeypatch.setattr(M, "decode_attention_partials", attn)
+    kv_gpu = [k.clone().cuda() for k in kv_cpu]
+    with torch.no_grad():
+        got = m(ids.cuda(), pos.cuda(), info_on("cuda", kv_gpu))
+    assert seen["int32_planes_into_attention"] == 0
+    om = OracleModel({k: v.clone() for k, v in params.items()}, H, I, L, HQ, HKV, D, V, eps=geo.rms_norm_eps,
+                     rope_theta=geo.rope_theta, quant="smoothquant")
+    kv_ref = [k.clone() for k in kv_cpu]
+    ref = om.forward(ids, pos, info_on("cpu", kv_ref))
+    new_rows = table[:, CTX].long()
+    torch.testing.assert_close(kv_gpu[0][new_rows.cuda()].float().cpu(), kv_ref[0][new_rows].float(), rtol=3e-2, atol=3e-2)
+    torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=1e-1, atol=1e-1)
+
+    # the fallback value itself (a geometry check that fails AFTER the planes were made): one rounding, bias in fp32
+    from lite_llama_amd.kernels.quantization import smoothquant_matmul, smoothquant_matmul_partials
+    x = (torch.randn(B, H, generator=g) * 0.5).half().cuda()
+    lin = m.layers[0].self_attn.q_proj
+    planes = smoothquant_matmul_partials(x, lin.weight, lin.weight_scale_inv, bias=None)
+    one = ScaledInt32Partials(planes.parts, planes.shape, planes.a_scale, planes.w_scale, bias=lin.bias).materialise()
+    assert torch.equal(one, smoothquant_matmul(x, lin.weight, lin.weight_scale_inv, bias=lin.bias))
+
+
+@pytest.mark.gpu
 def test_engine_sampling_path_graph_equals_eager():
     """Non-greedy decode through the sampler kernels inside the captured step: with a vanishing top_p the
     nucleus is the single most probable token, so the stochastic path must reproduce greedy decoding
