@@ -664,17 +664,17 @@ def choose_allreduce(ps, elems, dev, strict):
             ok, why = 0, "a peer flag timed out"
     except Exception as exc:  # mapping refused, allocation failed, ...
         ok, why = 0, f"{type(exc).__name__}: {exc}"[:200]
-    flag = torch.tensor([ok], device=dev, dtype=torch.int32)
-    dist.all_reduce(flag, op=dist.ReduceOp.MIN, group=ps._TP_GROUP)
-    if int(flag.item()) == 1:
-        return f"oneshot (peer-mapped buffers, checked against the {ps._backend()} collective at start-up)"
+    # every rank learns every rank's verdict AND the first failing rank's reason (parallel_state.collective_decision)
+    use, label, reason = ps.collective_decision(ok, why, group=ps._TP_GROUP)
+    if use:
+        return f"oneshot (peer-mapped buffers, checked against the {ps._backend()} collective at start-up)", ""
     if ps._ONESHOT is not None:
         ps._ONESHOT.close()
         ps._ONESHOT = None
     if strict:
-        raise SystemExit(f"--allreduce oneshot: start-up check failed on this rank or a peer ({why or 'peer'})")
-    print(f"[bench] one-shot all-reduce not used ({why or 'a peer refused'}); RCCL carries the collective", file=sys.stderr)
-    return "rccl (one-shot kernel failed its start-up check)"
+        raise SystemExit(f"--allreduce oneshot: start-up check failed ({reason})")
+    print(f"[bench] one-shot all-reduce not used ({reason}); RCCL carries the collective", file=sys.stderr)
+    return label, reason
 
 
 def self_launch(args) -> int:
@@ -752,12 +752,15 @@ def main():
         plan_note = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, tp, unit).describe()
     dp = world // tp
     ps.init_parallel(rank, tp_size=tp, dp_size=dp, master_port=int(os.environ.get("MASTER_PORT", 29500)))
-    allreduce_how = "none (tp1)" if tp == 1 else "rccl"
+    allreduce_how, allreduce_reason = ("none (tp1)" if tp == 1 else "rccl"), ("" if tp == 1 else "--allreduce rccl")
     if tp > 1 and args.allreduce != "rccl":
-        allreduce_how = choose_allreduce(ps, args.batch * geo.hidden_size, dev, strict=args.allreduce == "oneshot")
+        allreduce_how, allreduce_reason = choose_allreduce(ps, args.batch * geo.hidden_size, dev, strict=args.allreduce == "oneshot")
     if world > 1 and not torch.distributed.is_initialized():  # pure DP: still need the timing barrier
         kw = {"device_id": dev} if ps._backend() == "nccl" else {}
         torch.distributed.init_process_group(ps._backend(), rank=rank, world_size=world, **kw)
+    devices = None
+    if world > 1:  # one rank per GPU when the box has the GPUs (a launcher pinning every rank to device 0 must not pass for a scaling point)
+        devices = ps.assert_distinct_devices(local_rank, world)
 
     quant = None if args.quant == "none" else QuantConfig.for_runtime_scheme(args.quant)
     t_build = time.perf_counter()
@@ -857,7 +860,8 @@ def main():
                                f"{args.ctx + total}, {graph_note}" + (", scattered KV rows" if args.scattered else "")
                                + (f", KV paged in blocks of {args.kv_block_size}" if args.kv_block_size else ""),
                    "global_batch": global_batch,
-                   "parallelism": f"dp{dp}xtp{tp}", "allreduce": allreduce_how, "ranks": world,
+                   "parallelism": f"dp{dp}xtp{tp}", "allreduce": allreduce_how, "allreduce_fallback_reason": allreduce_reason or None,
+                   "ranks": world, "rank_devices": None if devices is None else [f"{h}:{d}" for h, d, _ in devices],
                    "collective_backend": ("none" if world == 1 else ps._backend() + (" (= RCCL)" if ps._backend() == "nccl" else "")),
                    "shard_plan": plan_note, "steps_per_graph_launch": args.steps_per_graph if use_graph else None,
                    "parallelism_note": os.environ.get("LL_BENCH_SHARED_DEVICE"), "build_seconds": round(t_build, 1)},

@@ -304,3 +304,63 @@ def all_reduce_min(value: int) -> int:
     t = torch.tensor([value], dtype=torch.int64, device=device)
     dist.all_reduce(t, op=dist.ReduceOp.MIN, group=_TP_GROUP)
     return int(t.item())
+
+
+# ------------------------------------------------------------------------------------- #
+# multi-GPU start-up checks (round 5; the reference picks NCCL unconditionally, parallel_state.py:44-71, 208-213)
+# ------------------------------------------------------------------------------------- #
+def collective_decision(local_ok: int, local_reason: str, group=None, gather=None):
+    """Group-wide choice between the one-shot peer-to-peer all-reduce and the backend collective (RCCL), from every rank's
+    local start-up check: the kernel is used only if EVERY rank passed; otherwise every rank falls back, and every rank
+    learns WHY (the first failing rank's reason) so the JSON line of rank 0 can say it.  ``gather``: injection point for tests
+    (a callable that returns the list of every rank's ``(ok, reason)``); default ``all_gather_object`` over ``group``.
+    Returns ``(use_oneshot, label, reason)`` -- identical on all ranks."""
+    mine = (int(bool(local_ok)), str(local_reason or ""))
+    if gather is not None:
+        everyone = gather(mine)
+    elif dist.is_available() and dist.is_initialized():
+        everyone = [None] * dist.get_world_size(group)
+        dist.all_gather_object(everyone, mine, group=group)
+    else:
+        everyone = [mine]
+    failed = [(r, why) for r, (ok, why) in enumerate(everyone) if not ok]
+    if not failed:
+        return True, "oneshot (peer-mapped buffers, checked against the backend collective at start-up)", ""
+    r, why = failed[0]
+    reason = f"rank {r}: {why or 'start-up check failed'}" + (f" (+{len(failed) - 1} more rank(s))" if len(failed) > 1 else "")
+    return False, "rccl (one-shot kernel failed its start-up check)", reason
+
+
+def peer_access_matrix():
+    """``hipDeviceCanAccessPeer`` for every ordered pair of visible devices (row = accessing device): what the one-shot
+    all-reduce needs over xGMI.  Printed by tools/multi_gpu.sh before any bench."""
+    n = torch.cuda.device_count()
+    return [[1 if i == j else int(torch.cuda.can_device_access_peer(i, j)) for j in range(n)] for i in range(n)]
+
+
+def assert_distinct_devices(local_device: int, world: int, group=None, gather=None):
+    """On a box that HAS ``world`` devices every rank must sit on its own (a launcher that pins all ranks to device 0 would
+    silently measure a time-sliced GPU).  Returns the list of (host, device, uuid) per rank; raises on a collision unless the
+    debugging set-up (``LL_BENCH_DEVICE`` / fewer devices than ranks) was asked for."""
+    import socket
+    ident = (socket.gethostname(), int(local_device), _device_uuid(local_device))
+    if gather is not None:
+        everyone = gather(ident)
+    elif dist.is_available() and dist.is_initialized():
+        everyone = [None] * dist.get_world_size(group)
+        dist.all_gather_object(everyone, ident, group=group)
+    else:
+        everyone = [ident]
+    shared_ok = bool(os.environ.get("LL_BENCH_DEVICE")) or (torch.cuda.is_available() and torch.cuda.device_count() < world)
+    keys = [(h, u or d) for h, d, u in everyone]
+    if len(set(keys)) != len(keys) and not shared_ok:
+        raise RuntimeError(f"{world} ranks but only {len(set(keys))} distinct devices: {everyone} -- one rank per GPU expected "
+                           "(LOCAL_RANK -> device); set LL_BENCH_DEVICE to share a device on purpose")
+    return everyone
+
+
+def _device_uuid(index: int) -> str:
+    try:
+        return str(torch.cuda.get_device_properties(index).uuid)
+    except Exception:
+        return ""

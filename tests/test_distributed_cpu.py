@@ -264,3 +264,64 @@ def test_moe_block_shapes_under_an_inside_block_cut(monkeypatch):
     plan = M.shard_plan(M.GEOMETRY["qwen3-30b-a3b"], QuantConfig.fp8_per_channel(), tp=8)
     assert plan is not None and [n for _, n in plan.q_heads] == [4] * 8 and [s for s, _ in plan.kv_heads] == [0, 0, 1, 1, 2, 2, 3, 3]
     assert M.shard_plan(M.GEOMETRY["qwen3-30b-a3b"], QuantConfig.fp8_per_channel(), tp=4) is None  # the reference's equal cuts
+
+
+# ------------------------------------------------------------------------------------------------------------------ #
+# Multi-GPU start-up checks (round 5): the one-shot / RCCL decision and the one-rank-per-device assertion
+# ------------------------------------------------------------------------------------------------------------------ #
+def _decision_worker(rank, world, port, q):
+    import lite_llama_amd.distributed.parallel_state as ps
+    os.environ["LL_DIST_BACKEND"] = "gloo"
+    try:
+        ps.init_tensor_parallel(rank, world, master_port=port)
+        # case 1: every rank passed -> the kernel; case 2: rank 1 failed -> BOTH ranks fall back and both know why
+        a = ps.collective_decision(1, "", group=ps._TP_GROUP)
+        b = ps.collective_decision(0 if rank == 1 else 1, "sums differ from RCCL's" if rank == 1 else "", group=ps._TP_GROUP)
+        # two ranks on one host with the same (absent) device identity: a collision unless sharing was asked for
+        try:
+            ps.assert_distinct_devices(0, world, group=ps._TP_GROUP)
+            collided = False
+        except RuntimeError:
+            collided = True
+        q.put((rank, a, b, collided))
+    except Exception as exc:  # pragma: no cover
+        q.put((rank, repr(exc), None, None))
+    finally:
+        ps.destroy_parallel()
+
+
+def test_collective_fallback_decision_is_group_wide_and_carries_the_reason():
+    import lite_llama_amd.distributed.parallel_state as ps
+
+    # pure form (injected gather): all ok / one failure / several failures
+    use, label, why = ps.collective_decision(1, "", gather=lambda m: [m, (1, ""), (1, "")])
+    assert use and label.startswith("oneshot") and why == ""
+    use, label, why = ps.collective_decision(1, "", gather=lambda m: [m, (0, "a peer flag timed out"), (1, "")])
+    assert not use and label.startswith("rccl") and why == "rank 1: a peer flag timed out"
+    use, label, why = ps.collective_decision(0, "RuntimeError: hipIpcOpenMemHandle", gather=lambda m: [m, (0, "x"), (1, "")])
+    assert not use and why.startswith("rank 0: RuntimeError: hipIpcOpenMemHandle") and "+1 more" in why
+    # one rank per device: distinct identities pass, a collision raises, the debugging set-up is allowed through
+    ok = ps.assert_distinct_devices(0, 2, gather=lambda m: [("h", 0, "uuid-a"), ("h", 1, "uuid-b")])
+    assert len(ok) == 2
+    if not torch.cuda.is_available():  # (on a GPU box with fewer devices than ranks sharing is the documented fallback)
+        with pytest.raises(RuntimeError, match="distinct devices"):
+            ps.assert_distinct_devices(0, 2, gather=lambda m: [("h", 0, "uuid-a"), ("h", 0, "uuid-a")])
+    os.environ["LL_BENCH_DEVICE"] = "0"
+    try:
+        ps.assert_distinct_devices(0, 2, gather=lambda m: [("h", 0, "uuid-a"), ("h", 0, "uuid-a")])
+    finally:
+        os.environ.pop("LL_BENCH_DEVICE")
+    # over a real gloo group of two
+    ctx = mp.get_context("spawn")
+    q = ctx.Queue()
+    port = _free_port()
+    procs = [ctx.Process(target=_decision_worker, args=(r, 2, port, q)) for r in range(2)]
+    for p in procs:
+        p.start()
+    results = [q.get(timeout=120) for _ in procs]
+    for p in procs:
+        p.join(timeout=60)
+    for rank, a, b, collided in results:
+        assert a[0] is True and a[2] == "", (rank, a)
+        assert b[0] is False and b[1].startswith("rccl") and b[2] == "rank 1: sums differ from RCCL's", (rank, b)
+        assert collided is (not torch.cuda.is_available())
