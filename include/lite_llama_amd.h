@@ -230,6 +230,13 @@ int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* wpacked, con
                               const void* bias, int64_t m, int64_t n, int64_t k, int group_size,
                               int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,
                               void* stream);
+/* The same product for MANY rows (prefill: m = batch x prompt tokens; w4a16.py:152-207 tiles M x N) over the same load-time
+ * layouts: 256 x 256 x 64 MFMA tiles, the weight tile dequantised once per 256 rows (gemm_w4_prefill.hip).  epilogue 0: out
+ * [m][n] (+ bias); 1: fused gate|up rows interleaved -> out [m][n / 2] = silu(gate) * up.  n % 256 == 0, k % 128 == 0. */
+int ll_w4a16_mtiled_supported(int64_t m, int64_t n, int64_t k, int group_size); /* 1 / 0 */
+int ll_w4a16_matmul_prepacked_mtiled(void* out, const void* x, const void* wpacked, const void* spacked, const void* bias,
+                                     int64_t m, int64_t n, int64_t k, int group_size, int64_t x_stride_m, int epilogue,
+                                     void* stream);
 /* Host-side introspection (tests; no device work): the launch plan ll_w4a16_matmul_prepacked uses for (n, k,
  * epilogue) as 16 ints -- grid, 128-row blocks per tile, tiles, chunks, slab slots, tile-group split (gt, gbase, grem, lead,
  * xcd_shift), stream-K units per workgroup, four reserved zeros, compute units assumed.  tests/test_host_cpu.py restates the

@@ -123,6 +123,16 @@ __device__ __forceinline__ float ll_sigmoidf(float v) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
 }
 
+// silu(g) * u rounded to fp16 the way the reference rounds it: the fp32 product first (swiglu.py:45-65 computes in fp32 and
+// stores with .to(dtype)).  The product is pinned in a register before the narrowing conversion: hipcc may otherwise select
+// v_fma_mixlo_f16 for fptrunc(fmul) in ONE of several kernels that must agree bit for bit (single instead of double rounding,
+// different once in ~2^13 values -- found in round 4 on the smoothquant norms, again in round 5 on the M-tiled GEMM's epilogue).
+__device__ __forceinline__ float ll_silu_mul_f32(float g, float u) {
+  float p = g * ll_sigmoidf(g) * u;
+  asm volatile("" : "+v"(p));
+  return p;
+}
+
 static inline bool ll_aligned16(const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15u) == 0; }
 
 #define LL_LAUNCH_CHECK() (hipGetLastError() == hipSuccess ? LL_OK : LL_ERR_LAUNCH)

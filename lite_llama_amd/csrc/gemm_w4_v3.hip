@@ -589,8 +589,8 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
           // stand-alone kernels: the two GEMM outputs rounded to fp16, then silu(g) * u in fp32.
           const float g0 = f16_bits_to_f32(o[0]), u0 = f16_bits_to_f32(o[1]);
           const float g1 = f16_bits_to_f32(o[2]), u1 = f16_bits_to_f32(o[3]);
-          const uint32_t s0 = f32_to_f16_bits(g0 * ll_sigmoidf(g0) * u0);
-          const uint32_t s1 = f32_to_f16_bits(g1 * ll_sigmoidf(g1) * u1);
+          const uint32_t s0 = f32_to_f16_bits(ll_silu_mul_f32(g0, u0));
+          const uint32_t s1 = f32_to_f16_bits(ll_silu_mul_f32(g1, u1));
           sw[g] = s0 | (s1 << 16);
         }
       }

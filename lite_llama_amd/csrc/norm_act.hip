@@ -359,7 +359,7 @@ __global__ __launch_bounds__(256) void swiglu_kernel(uint16_t* __restrict__ c,
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
       const float g = to_f32<DT>(av[j]);
-      cv[j] = from_f32<DT>(g * ll_sigmoidf(g) * to_f32<DT>(bv[j]));
+      cv[j] = from_f32<DT>(ll_silu_mul_f32(g, to_f32<DT>(bv[j])));
     }
     VecIO<VEC>::store(c + row * n + col, cv);
   }

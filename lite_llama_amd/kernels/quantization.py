@@ -190,6 +190,38 @@ def w4a16_matmul_prepacked(x, packed_weight, packed_scales, *, group_size: int =
     return out.reshape(*leading, n_out)
 
 
+def w4a16_mtiled_supported(m: int, n: int, k: int, group_size: int) -> bool:
+    return bool(L.lib().ll_w4a16_mtiled_supported(m, n, k, int(group_size)))
+
+
+def w4a16_matmul_prepacked_rows(x, packed_weight, packed_scales, *, group_size: int = 128, bias=None, gate_up_swiglu=False):
+    """:func:`w4a16_matmul` for MANY rows (prefill) over the decode engine's load-time layouts: an M-tiled MFMA GEMM that
+    dequantises every weight tile once per 256 rows (csrc/gemm_w4_prefill.hip) -- the > 64-row calls of a compacted model no
+    longer rebuild the reference-format tensor, and the generic engine's 64-row weight-streaming tile is not looped over M.
+    Same arithmetic as the decode engines (bit-identical dequantisation, fp32 accumulation, fused bias / swiglu epilogues);
+    ``None`` when the shape is not served (N not a multiple of 256, ...)."""
+    if x.dtype != torch.float16:
+        raise ValueError(f"w4a16 activations must be fp16, got {x.dtype}")
+    L.require_cuda(x, packed_weight, packed_scales, bias)
+    n, k = packed_weight.shape[0] * 128, packed_weight.shape[1] * 128
+    if x.shape[-1] != k:
+        raise ValueError(f"x has {x.shape[-1]} cols but weight expects {k}")
+    a = _flatten(x, k)
+    m = a.shape[0]
+    if m < 1 or not w4a16_mtiled_supported(m, n, k, group_size) or (gate_up_swiglu and n % 2):
+        return None
+    if (m - 1) * a.stride(0) * 2 + k * 2 >= 2 ** 31:
+        return None
+    if bias is not None and bias.dtype != torch.float16:
+        bias = bias.half()
+    n_out = n // 2 if gate_up_swiglu else n
+    out = torch.empty((m, n_out), dtype=x.dtype, device=x.device)
+    L.check(L.lib().ll_w4a16_matmul_prepacked_mtiled(out.data_ptr(), a.data_ptr(), packed_weight.data_ptr(), packed_scales.data_ptr(),
+                                                     L.ptr(bias), m, n, k, int(group_size), a.stride(0), 1 if gate_up_swiglu else 0,
+                                                     L.stream_ptr()), "w4a16_matmul_prepacked_rows")
+    return out.reshape(*x.shape[:-1], n_out)
+
+
 def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 128, _unit_loop_engine: bool = False):
     """Decode-step extension: the projection as ``S`` fp32 split-K partial sums (:class:`PartialSums`) for
     :func:`skip_rmsnorm_partials` to add up -- the GEMM has no cross-workgroup merge then.  ``None`` when the shape

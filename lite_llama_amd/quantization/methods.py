@@ -17,6 +17,7 @@ import torch.nn.functional as F
 from ..kernels import fused_moe, smoothquant_matmul, w4a16_matmul, w8a16_matmul
 from ..kernels.quantization import smoothquant_gate_up_swiglu, smoothquant_matmul_partials
 from ..kernels.quantization import (dense16_linear, dense_matmul_partials, pack_w4a16_scales, pack_w4a16_weights, unpack_w4a16_weights, w4a16_matmul_partials,
+                                    w4a16_matmul_prepacked_rows, w4a16_mtiled_supported,
                                     w4a16_matmul_prepacked, w4a16_prepacked_supported)
 from .config import FP8, INT4, INT8, SMOOTHQUANT, QuantConfig
 from .params import (
@@ -98,8 +99,37 @@ class W4A16LinearMethod(LinearQuantMethod):
         pre = self._prepacked(layer, x)
         if pre is not None:
             return w4a16_matmul_prepacked(x, pre, self._packed(layer), group_size=layer.quant.group_k, bias=layer.bias)
+        rows = self._rows_layout(layer, x)
+        if rows is not None:  # prefill-shaped call: the M-tiled engine over the same load-time layout (round 5)
+            out = w4a16_matmul_prepacked_rows(x, rows, self._packed(layer), group_size=layer.quant.group_k, bias=layer.bias)
+            if out is not None:
+                return out
         return w4a16_matmul(x, self.reference_weight(layer), layer.weight_scale, layer.weight_zeros,
                             group_size=layer.quant.group_k, bias=layer.bias)
+
+    def _rows_layout(self, layer, x):
+        """The load-time layout for a call of MORE than 64 rows (``w4a16_matmul_prepacked_rows``): the compacted parameter
+        itself, the copy the decode engine already cached, or -- outside a graph capture -- a freshly packed one (kept, like the
+        decode engine's).  ``None`` -> the reference-layout engine (``LL_W4_NO_MTILED``, shapes off the 256-row grid, ...)."""
+        m = x.numel() // x.shape[-1] if x.shape[-1] else 0
+        if m <= 64 or os.environ.get("LL_W4_NO_MTILED") or not layer.weight.is_cuda:
+            return None
+        if getattr(layer, "_w4_compact_member", None) is not None:
+            return None
+        n, kp = layer.weight.shape
+        if not w4a16_mtiled_supported(m, n, kp * 8, layer.quant.group_k) or self._packed(layer) is None:
+            return None
+        if getattr(layer, "_w4_compact", False):
+            return self._as_packed(layer.weight.data)
+        key = (layer.weight.data_ptr(), layer.weight._version)
+        cached = getattr(layer, "_w4_prepacked", None)
+        if cached is not None and cached[0] == key:
+            return cached[1]
+        if torch.cuda.is_current_stream_capturing() or os.environ.get("LL_W4_NO_PREPACK"):
+            return None
+        pre = pack_w4a16_weights(layer.weight.data)
+        layer._w4_prepacked = (key, pre)
+        return pre
 
     # ---- one resident copy of the int4 weights (round 4) ------------------------------------------------------------
     @staticmethod
@@ -179,6 +209,9 @@ class W4A16LinearMethod(LinearQuantMethod):
         if pre is not None:
             return w4a16_matmul_prepacked(x, pre, self._packed(layer), group_size=layer.quant.group_k,
                                           gate_up_swiglu=True)
+        rows = self._rows_layout(layer, x)
+        if rows is not None:  # prefill: the fused epilogue of the M-tiled engine
+            return w4a16_matmul_prepacked_rows(x, rows, self._packed(layer), group_size=layer.quant.group_k, gate_up_swiglu=True)
         return None
 
     @staticmethod

@@ -553,6 +553,99 @@ def test_smoothquant_shape_decode_layer_route_and_oracle(monkeypatch):
 
 
 @pytest.mark.gpu
+def test_prefill_then_decode_at_batch_64_follows_the_oracle(monkeypatch):
+    """The reference's protocol end to end at batch 64 (benchmarks/common.py:100-137: prefill, then decode): int4 model with
+    widths on the M-tiled engine's grid, 64 prompts of 96..128 tokens through ``DecodeEngine.prefill`` (every projection a
+    > 64-row call: route asserted), then 6 captured decode steps.  The oracle model, teacher-forced with the engine's tokens,
+    must rank the engine's choice first (or within fp16 noise of its own first choice) at the prefill step and at every
+    decode step, and the K/V rows the prefill wrote must match the oracle's."""
+    from lite_llama_amd.executor import DecodeEngine
+    from lite_llama_amd.model import CausalLM, tiny_geometry
+    from lite_llama_amd.quantization import QuantConfig
+    from oracle.model import OracleModel
+    import lite_llama_amd.quantization.methods as QM
+
+    H, I, L, HQ, HKV, D, V = 512, 1280, 2, 4, 2, 128, 1024
+    B, LP, STEPS = 64, 128, 6
+    g = torch.Generator().manual_seed(31)
+    geo = tiny_geometry(hidden_size=H, intermediate_size=I, num_layers=L, num_heads=HQ, num_kv_heads=HKV, head_dim=D,
+                        vocab_size=V, rope_theta=10000.0, rms_norm_eps=1e-6, qkv_bias=True)
+    m = CausalLM(geo)
+    params = {}
+    for name, t in m.state_dict().items():
+        if name.endswith("norm_weight") or name.endswith("layernorm_weight"):
+            params[name] = (1 + 0.1 * torch.randn(t.shape, generator=g)).half()
+        elif name.endswith(".bias"):
+            params[name] = (0.1 * torch.randn(t.shape, generator=g)).half()
+        else:
+            params[name] = (0.05 * torch.randn(t.shape, generator=g)).half()
+    m.load_state_dict(params, strict=True)
+    m = m.to("cuda")
+    m.quantize_(QuantConfig.int4_groupwise(128))
+    m.compact_weights()
+    lens = torch.randint(96, LP + 1, (B,), generator=g).int()
+    lens[0] = LP
+    ids = torch.randint(0, V, (B, LP), generator=g)
+    calls = {"rows": 0, "generic": 0}
+    real_rows, real_gen = QM.w4a16_matmul_prepacked_rows, QM.w4a16_matmul
+
+    def rows(*a, **k):
+        calls["rows"] += 1
+        return real_rows(*a, **k)
+
+    def gen(*a, **k):
+        calls["generic"] += 1
+        return real_gen(*a, **k)
+
+    monkeypatch.setattr(QM, "w4a16_matmul_prepacked_rows", rows)
+    monkeypatch.setattr(QM, "w4a16_matmul", gen)
+    eng = DecodeEngine(m, max_batch=B, max_seq_len=LP + STEPS + 8)
+    first = eng.prefill(ids.cuda(), lens.cuda())
+    assert calls["generic"] == 0 and calls["rows"] == 4 * L, calls  # q|k|v, o, gate|up (+ swiglu), down per layer
+    toks = eng.decode(first, STEPS, use_graph=True).cpu()
+    kv_gpu = [k.clone().cpu() for k in eng.info.kv_buffer]
+
+    # ---- the oracle over the same prompt ----
+    om = OracleModel({k: v.clone() for k, v in params.items()}, H, I, L, HQ, HKV, D, V, eps=geo.rms_norm_eps,
+                     rope_theta=geo.rope_theta, quant="int4")
+    rows_total = B * (LP + STEPS + 8)
+    kv = [torch.zeros(rows_total, 2 * HKV, D, dtype=torch.float16) for _ in range(L)]
+    table = torch.zeros(B, LP + STEPS + 8, dtype=torch.int32)
+    sel = torch.arange(B * LP, dtype=torch.int32)
+    lens_l = lens.tolist()
+    for i, n in enumerate(lens_l):
+        table[i, :n] = sel[i * LP: i * LP + n]
+    info = _info(kv, table, sel, lens.clone(), torch.arange(B, dtype=torch.int32) * LP, LP)
+    pos = torch.arange(LP).unsqueeze(0).expand(B, LP).contiguous()
+    logits = om.forward(ids, pos, info)
+    lg = torch.stack([logits[i, n - 1] for i, n in enumerate(lens_l)]).float()
+    chosen = lg.gather(1, first.cpu().view(B, 1)).squeeze(1)
+    assert torch.all(lg.max(-1).values - chosen <= 3e-2)
+    valid = torch.cat([sel[i * LP: i * LP + n] for i, n in enumerate(lens_l)]).long()
+    for li in range(L):  # K/V rows of the valid prompt tokens (pad rows hold junk on both sides)
+        torch.testing.assert_close(kv_gpu[li][valid].float(), kv[li][valid].float(), rtol=3e-2, atol=3e-2)
+    seq = lens.clone()
+    next_row = B * LP
+    tok = first.cpu()
+    agree = 0
+    for step in range(STEPS):
+        info.cur_select_index = torch.arange(next_row, next_row + B, dtype=torch.int32)
+        next_row += B
+        seq = seq + 1
+        info.b_seq_len = seq
+        info.max_actual_seq_len = int(seq.max())
+        for i in range(B):
+            table[i, int(seq[i]) - 1] = info.cur_select_index[i]
+        lg = om.forward(tok.view(B, 1), (seq - 1).view(B, 1).long(), info)[:, -1].float()
+        mine = toks[:, step]
+        chosen = lg.gather(1, mine.view(B, 1)).squeeze(1)
+        assert torch.all(lg.max(-1).values - chosen <= 3e-2), (step, (lg.max(-1).values - chosen).max())
+        agree += int((lg.argmax(-1) == mine).sum())
+        tok = mine
+    assert agree >= int(0.9 * STEPS * B), agree
+
+
+@pytest.mark.gpu
 def test_smoothquant_with_bias_and_small_heads_keeps_the_finished_projection(monkeypatch):
     """Qwen2-style attention (q|k|v bias, heads of 64) under SmoothQuant: the one-launch attention does not take int32
     planes for this geometry, so the step must not leave q|k|v as planes at all (planes GEMM + a torch

@@ -376,3 +376,54 @@ def test_compacted_model_keeps_one_copy_of_the_int4_weights_and_the_same_numbers
         assert torch.equal(v, ref_params[k]), k
     first2, toks2, _ = run(True)
     assert torch.equal(first2, first0) and torch.equal(toks2, toks0)
+
+
+# ---------------------------------------------------------------------------------------------------------------- #
+# the M-tiled engine for prefill-shaped calls (csrc/gemm_w4_prefill.hip, round 5)
+# ---------------------------------------------------------------------------------------------------------------- #
+def test_mtiled_unpack_bit_exact_at_every_k_position():
+    """One-hot activation rows (more than 64 of them), scale 1, zero 0: the M-tiled GEMM's output IS the nibble matrix."""
+    n, k = 512, 256
+    qw = torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64).to(torch.int32)
+    sc, zr = torch.ones(n, k // 128), torch.zeros(n, k // 128)
+    pw, ps = Q().pack_w4a16_weights(qw.to(DEV)), Q().pack_w4a16_scales(sc.to(DEV), zr.to(DEV))
+    x = torch.eye(k, dtype=torch.float16, device=DEV)  # 256 rows: row i picks k position i
+    out = Q().w4a16_matmul_prepacked_rows(x, pw, ps)
+    assert out is not None and torch.equal(out.cpu().float().T.contiguous(), O.unpack_int4(qw).float())
+
+
+@pytest.mark.parametrize("m,n,k,gs", [(65, 256, 128, 128), (300, 512, 384, 128), (1000, 768, 512, 256), (257, 1024, 256, 128),
+                                      (4096, 4608, 3584, 128)])
+def test_mtiled_matches_oracle_and_generic_engine(m, n, k, gs):
+    """Prefill-shaped calls (ragged row counts, both group sizes, bias, the fused gate|up epilogue) against the CPU oracle at
+    1e-2 (the reference's own tolerance is 5e-2) and against the reference-layout engine; rows <= 64 of the same call equal
+    the decode engine's rows up to the fp32 summation order."""
+    g = torch.Generator().manual_seed(m + n + k)
+    w = torch.randn(n, k, generator=g) * 0.05
+    qw, sc, zr = O.quantize_int4_groupwise(w.half(), gs)
+    x = (torch.randn(m, k, generator=g) * 0.5).half()
+    bias = (torch.randn(n, generator=g) * 0.1).half()
+    pw, ps = Q().pack_w4a16_weights(qw.to(DEV)), Q().pack_w4a16_scales(sc.to(DEV), zr.to(DEV))
+    xd = x.to(DEV)
+    got = Q().w4a16_matmul_prepacked_rows(xd, pw, ps, group_size=gs, bias=bias.to(DEV))
+    assert got is not None and got.shape == (m, n)
+    if m * n * k <= 2 ** 31:
+        ref = O.w4a16_matmul(x, qw, sc, zr, group_size=gs, bias=bias)
+        close(got, ref, 1e-2)
+    gen = Q().w4a16_matmul(xd, qw.to(DEV), sc.to(DEV), zr.to(DEV), group_size=gs, bias=bias.to(DEV))
+    if m > 64:
+        close(got, gen, 1e-2)
+    dec = Q().w4a16_matmul_prepacked(xd[:64], pw, ps, group_size=gs, bias=bias.to(DEV))
+    close(got[:64], dec, 2e-3)
+    assert torch.equal(got, Q().w4a16_matmul_prepacked_rows(xd, pw, ps, group_size=gs, bias=bias.to(DEV)))  # deterministic
+    # fused gate|up: rows interleaved (gate_j, up_j) -> silu(gate) * up, the arithmetic of swiglu_forward on the fp16 outputs
+    sw = Q().w4a16_matmul_prepacked_rows(xd, pw, ps, group_size=gs, gate_up_swiglu=True)
+    plain = Q().w4a16_matmul_prepacked_rows(xd, pw, ps, group_size=gs)
+    from lite_llama_amd.kernels import swiglu_forward
+    assert torch.equal(sw, swiglu_forward(plain[:, 0::2].contiguous(), plain[:, 1::2].contiguous()))
+    # a strided activation view (row stride > k) and a shape off the 256-row grid
+    wide = torch.zeros(m, k + 64, dtype=torch.float16, device=DEV)
+    wide[:, :k] = xd
+    assert torch.equal(Q().w4a16_matmul_prepacked_rows(wide[:, :k], pw, ps, group_size=gs, bias=bias.to(DEV)), got)
+    if n > 256:
+        assert Q().w4a16_matmul_prepacked_rows(xd, pw[: (n - 128) // 128], ps[:, : n - 128].contiguous(), group_size=gs) is None
