@@ -305,7 +305,10 @@ int ll_dense16_matmul(void* out, const void* x, const void* w, const void* bias,
 int ll_moe_align_block_size(const void* topk_ids, int ids_width, int64_t num_slots, int num_experts,
                             int block_size, int32_t* sorted_ids, int32_t* expert_ids,
                             int32_t* num_post, void* stream);
-/* c[slot, :] = (a[slot / top_k, :] @ w[expert(slot)].T) (* topk_w[slot]) */
+/* c[slot, :] = (a[slot / top_k, :] @ w[expert(slot)].T) (* topk_w[slot]).  mul_routed_weight: bit 0 = multiply by topk_w[slot]
+ * (fp32, fused_moe.py:203-205); bit 1 (extension) = the rows of w are (gate_j, up_j) pairs -- a load-time interleave of the
+ * stacked gate|up matrix -- and c is [num_slots, n / 2] = silu(gate) * up on the fp16-rounded GEMM outputs: the values of
+ * ll_silu_and_mul over the [num_slots, n] tensor the two-launch form stores (fused_moe.py:298-315), one launch less. */
 int ll_moe_gemm(void* c, const void* a, const void* w, const float* w_scale, const void* topk_w,
                 const int32_t* sorted_ids, const int32_t* expert_ids, const int32_t* num_post,
                 int64_t num_slots, int64_t em, int block_m, int64_t n, int64_t k, int top_k,

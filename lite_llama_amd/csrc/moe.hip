@@ -121,6 +121,76 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const void* __restrict_
   }
 }
 
+// Decode-sized batches (<= 1024 slots, <= 1024 experts), round 5: one thread per SLOT.  The stable rank of a slot among the
+// earlier slots of its expert = (same-expert slots in earlier waves) + (same-expert lower lanes of its own wave): the second
+// term comes from wave ballots -- one round per DISTINCT expert present in the wave -- the first from per-(wave, expert)
+// counts in LDS that thread e turns into running offsets while it forms the expert's total.  Four barriers, no atomics, no
+// quadratic scan (the kernel above spends ~64 dependent LDS rounds on the last slot of a 512-slot batch: 12 us per call,
+// 48 calls per Qwen3-30B-A3B step).  Same outputs, bit for bit.
+__global__ __launch_bounds__(1024) void moe_align_small_kernel(const void* __restrict__ topk_ids, int ids_w, int num_slots,
+                                                               int num_experts, int block_size, int32_t* __restrict__ sorted_ids,
+                                                               int32_t* __restrict__ expert_ids, int32_t* __restrict__ num_post,
+                                                               int max_padded, int max_blocks) {
+  extern __shared__ int sm[];  // cw[waves][E] | starts[E] | bends[E]
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
+  int* cw = sm;
+  int* starts = sm + nw * num_experts;
+  int* bends = starts + num_experts;
+  __shared__ int wave_tot[16];
+  for (int i = tid; i < max_padded; i += nthreads) sorted_ids[i] = num_slots;  // sentinel
+  for (int i = tid; i < nw * num_experts; i += nthreads) cw[i] = 0;
+  __syncthreads();
+  const bool has = tid < num_slots;
+  const int e = has ? moe_clamp_id((int)moe_load_idx(topk_ids, tid, ids_w), num_experts) : -1;
+  int rank = 0;
+  unsigned long long todo = __ballot(has);
+  while (todo) {
+    const int leader = __ffsll((long long)todo) - 1;
+    const int e0 = __builtin_amdgcn_readlane(e, leader);
+    const unsigned long long m = __ballot(has && e == e0);
+    if (e == e0) rank = __popcll(m & ((1ull << lane) - 1ull));
+    if (lane == leader) cw[wave * num_experts + e0] = __popcll(m);
+    todo &= ~m;
+  }
+  __syncthreads();
+  // thread t owns expert t: per-wave running offsets, the expert's total, then the padded prefix over the experts
+  const int t = tid;
+  int count = 0;
+  if (t < num_experts) {
+    for (int w = 0; w < nw; ++w) {
+      const int c = cw[w * num_experts + t];
+      cw[w * num_experts + t] = count;
+      count += c;
+    }
+  }
+  const int padded = t < num_experts ? (count + block_size - 1) / block_size * block_size : 0;
+  int x = padded;
+#pragma unroll
+  for (int off = 1; off < 64; off <<= 1) {
+    const int y = __shfl_up(x, off, 64);
+    if (lane >= off) x += y;
+  }
+  if (lane == 63) wave_tot[wave] = x;
+  __syncthreads();
+  int before = 0;
+  for (int w = 0; w < wave; ++w) before += wave_tot[w];
+  if (t < num_experts) {
+    starts[t] = before + x - padded;
+    bends[t] = (before + x) / block_size;
+  }
+  if (tid == nthreads - 1) num_post[0] = before + x;
+  __syncthreads();
+  if (has) sorted_ids[starts[e] + cw[wave * num_experts + e] + rank] = tid;
+  for (int b = tid; b < max_blocks; b += nthreads) {  // expert_ids[b] = searchsorted(block_ends, b, right=True) clamped to E-1
+    int lo = 0, hi = num_experts;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (bends[mid] <= b) lo = mid + 1; else hi = mid;
+    }
+    expert_ids[b] = lo < num_experts - 1 ? lo : num_experts - 1;
+  }
+}
+
 extern "C" int ll_moe_align_block_size(const void* topk_ids, int ids_width, int64_t num_slots, int num_experts,
                                        int block_size, int32_t* sorted_ids, int32_t* expert_ids,
                                        int32_t* num_post, void* stream) {
@@ -128,6 +198,14 @@ extern "C" int ll_moe_align_block_size(const void* topk_ids, int ids_width, int6
   if (num_slots < 0 || num_experts <= 0 || block_size <= 0 || num_experts > 8192) return LL_ERR_SHAPE;
   const int max_padded = (int)num_slots + num_experts * (block_size - 1);
   const int max_blocks = (max_padded + block_size - 1) / block_size;
+  static const bool small_off = getenv("LL_MOE_ALIGN_V1") != nullptr;  // A/B knob, read once
+  if (!small_off && num_slots >= 1 && num_slots <= 1024 && num_experts <= 1024) {
+    int threads = (int)((num_slots > num_experts ? num_slots : num_experts) + 63) / 64 * 64;
+    const int nw = threads / 64;
+    moe_align_small_kernel<<<1, threads, (size_t)(nw * num_experts + 2 * num_experts) * sizeof(int), (hipStream_t)stream>>>(
+        topk_ids, ids_width, (int)num_slots, num_experts, block_size, sorted_ids, expert_ids, num_post, max_padded, max_blocks);
+    return LL_LAUNCH_CHECK();
+  }
   const int stage_ids = num_slots <= 4096 ? 1 : 0;  // the rank scan is quadratic: decode-sized batches only
   moe_align_kernel<<<1, 1024, (3 * num_experts + (stage_ids ? (int)num_slots + 8 : 0)) * sizeof(int), (hipStream_t)stream>>>(
       topk_ids, ids_width, (int)num_slots, num_experts, block_size, sorted_ids, expert_ids, num_post, max_padded,
@@ -274,7 +352,22 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel(const MoeParams p) {
     const int32_t slot = row_slot[m];
     if (m >= p.block_m || slot >= p.num_slots) continue;
     float rw = 1.f;
-    if (p.mul_w) rw = f16_bits_to_f32(p.topk_w[slot]);  // router weight multiplies in fp32 (:203-205)
+    if (p.mul_w & 1) rw = f16_bits_to_f32(p.topk_w[slot]);  // router weight multiplies in fp32 (:203-205)
+    if (p.mul_w & 2) {  // rows are (gate_j, up_j) pairs: silu(g) * u in the epilogue (see moe_gemm_kernel2)
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t nn = (int64_t)blockIdx.x * 128 + wv * 32 + 8 * g + 4 * h;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          if (nn + e + 1 < p.n) {
+            const float gv = f16_bits_to_f32(f32_to_f16_bits(acc[mt][4 * g + e] * rw));
+            const float uv = f16_bits_to_f32(f32_to_f16_bits(acc[mt][4 * g + e + 1] * rw));
+            p.c[(int64_t)slot * (p.n >> 1) + ((nn + e) >> 1)] = f32_to_f16_bits(ll_silu_mul_f32(gv, uv));
+          }
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int64_t nn = (int64_t)blockIdx.x * 128 + wv * 32 + 8 * g + 4 * h;
@@ -409,7 +502,24 @@ __global__ __launch_bounds__(256) void moe_gemm_kernel2(const MoeParams p) {
     const int32_t slot = row_slot[m];
     if (m >= p.block_m || slot >= p.num_slots) continue;
     float rw = 1.f;
-    if (p.mul_w) rw = f16_bits_to_f32(p.topk_w[slot]);
+    if (p.mul_w & 1) rw = f16_bits_to_f32(p.topk_w[slot]);
+    if (p.mul_w & 2) {
+      // rows are (gate_j, up_j) pairs (load-time interleave of gate|up, model.py::SparseMoeBlock): both GEMM outputs rounded to
+      // fp16, then silu(g) * u -- the arithmetic of silu_and_mul on the [slots, 2 I] tensor the unfused route stores
+#pragma unroll
+      for (int g = 0; g < 4; ++g) {
+        const int64_t nn = ntile + wv * 32 + 8 * g + 4 * h;
+#pragma unroll
+        for (int e = 0; e < 4; e += 2) {
+          if (nn + e + 1 < p.n) {
+            const float gv = f16_bits_to_f32(f32_to_f16_bits(acc[mt][4 * g + e] * rw));
+            const float uv = f16_bits_to_f32(f32_to_f16_bits(acc[mt][4 * g + e + 1] * rw));
+            p.c[(int64_t)slot * (p.n >> 1) + ((nn + e) >> 1)] = f32_to_f16_bits(ll_silu_mul_f32(gv, uv));
+          }
+        }
+      }
+      continue;
+    }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
       const int64_t nn = ntile + wv * 32 + 8 * g + 4 * h;
@@ -430,6 +540,7 @@ extern "C" int ll_moe_gemm(void* c, const void* a, const void* w, const float* w
   if (wfmt != LL_W_F16 && wfmt != LL_W_FP8E4M3 && wfmt != LL_W_INT8) return LL_ERR_DTYPE;
   if (block_m != 16 && block_m != 32 && block_m != 64) return LL_ERR_SHAPE;
   if (n <= 0 || k <= 0 || top_k <= 0 || k % 8 != 0 || a_stride_m % 8 != 0) return LL_ERR_SHAPE;
+  if (mul_routed_weight < 0 || mul_routed_weight > 3 || ((mul_routed_weight & 2) && (n & 1))) return LL_ERR_SHAPE;
   if (wfmt != LL_W_F16 && (!w_scale || group_n <= 0 || group_k <= 0)) return LL_ERR_ARG;
   if (wfmt != LL_W_F16 && group_k < k && group_k % 8 != 0) return LL_ERR_SHAPE;  // a scale block spans whole 8-k MFMA steps
   if (wfmt == LL_W_F16 ? (w_stride_n % 8 != 0) : (w_stride_n % 8 != 0)) return LL_ERR_SHAPE;

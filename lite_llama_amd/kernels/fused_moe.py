@@ -90,6 +90,7 @@ def fused_moe(
     w1_group: tuple | None = None,
     w2_group: tuple | None = None,
     slots_ok: bool = False,
+    w1_interleaved: bool = False,
 ) -> torch.Tensor:
     """``sum_k w_k * (silu(x W1g^T) * (x W1u^T)) W2^T`` over each token's top-k experts.
 
@@ -99,6 +100,10 @@ def fused_moe(
 
     ``slots_ok`` (extension): return the per-slot rows as a ``SlotSums`` for ``skip_rmsnorm_partials`` instead of running
     ``moe_sum`` (the same values, one launch less).
+
+    ``w1_interleaved`` (extension): the rows of ``w1`` (and of its scales) were interleaved at load time -- row ``2j`` =
+    ``gate_j``, row ``2j + 1`` = ``up_j`` instead of the stacked halves -- so that ``silu(gate) * up`` runs in the first grouped
+    GEMM's epilogue (same values as GEMM + ``silu_and_mul``: both outputs are rounded to the activation dtype first).
 
     Pipeline and intermediate dtypes as the reference: align -> GEMM1 (``[T*k, 2I]`` in x's
     dtype) -> silu*up -> GEMM2 with the router weight folded in fp32 -> fp32 sum over top_k."""
@@ -129,16 +134,19 @@ def fused_moe(
     block_m = _block_m(num_tokens)
     sorted_ids, expert_ids, num_post = moe_align_block_size(topk_ids, block_m, num_experts)
 
-    gate_up = torch.empty((num_tokens * top_k, two_inter), device=device, dtype=dtype)
-    _moe_gemm(hidden_states, w1, gate_up, w1_scale, flat_weights, sorted_ids, expert_ids, num_post,
-              top_k, False, wfmt, g1[0], g1[1], block_m)
-
     act = torch.empty((num_tokens * top_k, intermediate), device=device, dtype=dtype)
-    L.check(
-        L.lib().ll_silu_and_mul(act.data_ptr(), gate_up.data_ptr(), num_tokens * top_k, intermediate,
-                                L.dtype_code(dtype), L.stream_ptr()),
-        "silu_and_mul",
-    )
+    if w1_interleaved:
+        _moe_gemm(hidden_states, w1, act, w1_scale, flat_weights, sorted_ids, expert_ids, num_post,
+                  top_k, 2, wfmt, g1[0], g1[1], block_m)
+    else:
+        gate_up = torch.empty((num_tokens * top_k, two_inter), device=device, dtype=dtype)
+        _moe_gemm(hidden_states, w1, gate_up, w1_scale, flat_weights, sorted_ids, expert_ids, num_post,
+                  top_k, False, wfmt, g1[0], g1[1], block_m)
+        L.check(
+            L.lib().ll_silu_and_mul(act.data_ptr(), gate_up.data_ptr(), num_tokens * top_k, intermediate,
+                                    L.dtype_code(dtype), L.stream_ptr()),
+            "silu_and_mul",
+        )
 
     # GEMM2 gathers per-slot rows of ``act`` (top_k = 1 makes slot // top_k the identity,
     # fused_moe.py:420-430) and folds the router weight in fp32.

@@ -443,6 +443,59 @@ class SparseMoeBlock(nn.Module):
             return out
         return all_reduce_tp(out).view(shape)
 
+    # ---- load-time interleave of the stacked gate|up rows (round 5) ------------------------------------------------------
+    @torch.no_grad()
+    def interleave_gate_up_(self) -> bool:
+        """Re-order the rows of ``experts.gate_up_proj`` from the checkpoint's stacked halves ``[gate_0.. | up_0..]`` to pairs
+        ``(gate_j, up_j)`` IN PLACE (same storage, a permutation of the same rows; scales follow: per-row grids are permuted,
+        coarser blocks along N are first repeated down to one value per row), so that ``silu(gate) * up`` runs in the epilogue
+        of the first grouped GEMM (``fused_moe(..., w1_interleaved=True)``): one launch and a ``[slots, 2 I]`` round trip less
+        per layer.  Like ``CausalLM.compact_weights`` this changes what ``state_dict()`` would export:
+        ``deinterleave_gate_up_`` (called by ``expand_weights``) restores the checkpoint order bit for bit."""
+        if getattr(self, "_gu_interleaved", False) or os.environ.get("LL_MOE_NO_INTERLEAVE"):
+            return False
+        w = self.experts["gate_up_proj"]
+        if not w.is_cuda or torch.cuda.is_current_stream_capturing():
+            return False
+        e, two_i, h = w.shape
+        i = two_i // 2
+        w.data.copy_(torch.stack((w.data[:, :i], w.data[:, i:]), dim=2).reshape(e, two_i, h))
+        key = "gate_up_proj_scale_inv"
+        if key in self.experts:
+            sc = self.experts[key].data
+            gn = -(-two_i // sc.shape[1])  # rows per scale value along N
+            self._gu_scale_rows = gn
+            if gn > 1:
+                sc = sc.repeat_interleave(gn, dim=1)[:, :two_i]
+            sc = torch.stack((sc[:, :i], sc[:, i:]), dim=2).reshape(e, two_i, -1).contiguous()
+            self.experts[key] = type(self.experts[key])(sc) if gn > 1 else self.experts[key]
+            if gn == 1:
+                self.experts[key].data.copy_(sc)
+        self._gu_interleaved = True
+        return True
+
+    @torch.no_grad()
+    def deinterleave_gate_up_(self) -> None:
+        if not getattr(self, "_gu_interleaved", False):
+            return
+        w = self.experts["gate_up_proj"]
+        e, two_i, h = w.shape
+        i = two_i // 2
+        pairs = w.data.view(e, i, 2, h)
+        w.data.copy_(torch.cat((pairs[:, :, 0], pairs[:, :, 1]), dim=1))
+        key = "gate_up_proj_scale_inv"
+        if key in self.experts:
+            sc = self.experts[key].data
+            pairs = sc.view(e, i, 2, -1)
+            sc = torch.cat((pairs[:, :, 0], pairs[:, :, 1]), dim=1).contiguous()
+            gn = getattr(self, "_gu_scale_rows", 1)
+            if gn > 1:
+                sc = sc[:, ::gn].contiguous()
+                self.experts[key] = type(self.experts[key])(sc)
+            else:
+                self.experts[key].data.copy_(sc)
+        self._gu_interleaved = False
+
     @torch.no_grad()
     def quantize_experts_(self, quant: QuantConfig) -> None:
         if self.quant is not None:
@@ -552,13 +605,16 @@ class CausalLM(nn.Module):
         for m in self.modules():
             if isinstance(m, LinearBase) and id(m) not in members and hasattr(m.quant_method, "compact"):
                 freed += m.quant_method.compact(m)
+            if isinstance(m, SparseMoeBlock):
+                m.interleave_gate_up_()  # (frees nothing: the same storage, rows re-ordered for the fused epilogue)
         if freed:
             torch.cuda.empty_cache()
         return freed
 
     def is_compacted(self) -> bool:
-        return any(getattr(m, "_w4_compact", False) or getattr(m, "_w4_compact_member", None) is not None
-                   for m in self.modules() if isinstance(m, LinearBase)) or \
+        return any(getattr(m, "_gu_interleaved", False) for m in self.modules() if isinstance(m, SparseMoeBlock)) or \
+            any(getattr(m, "_w4_compact", False) or getattr(m, "_w4_compact_member", None) is not None
+                for m in self.modules() if isinstance(m, LinearBase)) or \
             any(getattr(mc._holder, "_w4_compact", False) for mc in self._merged_linears())
 
     def state_dict(self, *args, **kwargs):
@@ -575,6 +631,8 @@ class CausalLM(nn.Module):
         for m in self.modules():
             if isinstance(m, LinearBase) and hasattr(m.quant_method, "expand"):
                 m.quant_method.expand(m)
+            if isinstance(m, SparseMoeBlock):
+                m.deinterleave_gate_up_()
 
     def weight_bytes(self) -> int:
         """Bytes of every distinct parameter / derived-layout storage the model keeps resident (aliases counted once)."""

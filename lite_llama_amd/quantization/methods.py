@@ -343,7 +343,7 @@ class UnquantizedMoeMethod(MoeQuantMethod):
 
     def apply(self, block, x, topk_weights, topk_ids, slots_ok: bool = False):
         return fused_moe(x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids,
-                         slots_ok=slots_ok)
+                         slots_ok=slots_ok, w1_interleaved=getattr(block, "_gu_interleaved", False))
 
 
 class W8A16MoeMethod(MoeQuantMethod):
@@ -375,18 +375,21 @@ class W8A16MoeMethod(MoeQuantMethod):
 
     def apply(self, block, x, topk_weights, topk_ids, slots_ok: bool = False):
         q = block.quant
-        if getattr(block, "scale_cut", 0):
+        inter = getattr(block, "_gu_interleaved", False)  # rows paired (gate_j, up_j) at load time: scales are per row then
+        if getattr(block, "scale_cut", 0) or (inter and getattr(block, "_gu_scale_rows", 1) > 1):
             g1, g2 = self.groups(block)
+            g1n = 1 if inter else g1[0]
             return fused_moe(
                 x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids,
                 w1_scale=block.experts["gate_up_proj_scale_inv"], w2_scale=block.experts["down_proj_scale_inv"],
-                group_n=q.group_n, group_k=q.group_k, w1_group=(g1[0], min(g1[1], block.hidden_size)), w2_group=g2,
-                slots_ok=slots_ok,
+                group_n=q.group_n, group_k=q.group_k, w1_group=(g1n, min(g1[1], block.hidden_size)),
+                w2_group=(g2[0], min(g2[1], block.moe_intermediate_size)) if not getattr(block, "scale_cut", 0) else g2,
+                slots_ok=slots_ok, w1_interleaved=inter,
             )
         return fused_moe(
             x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids,
             w1_scale=block.experts["gate_up_proj_scale_inv"], w2_scale=block.experts["down_proj_scale_inv"],
-            group_n=q.group_n, group_k=min(q.group_k, block.hidden_size), slots_ok=slots_ok,
+            group_n=q.group_n, group_k=min(q.group_k, block.hidden_size), slots_ok=slots_ok, w1_interleaved=inter,
         )
 
     def convert_from_fp16(self, block, quant):

@@ -332,3 +332,46 @@ def test_rccl_all_reduce_inside_captured_decode_step():
     p.join(timeout=60)
     assert ok is True, same
     assert same is True, toks
+
+
+def test_moe_model_with_interleaved_gate_up_equals_the_stacked_layout():
+    """``CausalLM.compact_weights()`` on a Qwen3-MoE-shaped fp8 model pairs the gate|up rows of every expert (the fused
+    epilogue route): same logits bit for bit as the stacked layout, route taken, and ``state_dict()`` / ``expand_weights()``
+    give the checkpoint order back bit for bit."""
+    import types
+    from lite_llama_amd.model import CausalLM, SparseMoeBlock, tiny_geometry
+    from lite_llama_amd.quantization import QuantConfig
+
+    geo = tiny_geometry(hidden_size=256, intermediate_size=512, num_layers=2, num_heads=4, num_kv_heads=2, head_dim=128,
+                        vocab_size=512, qkv_bias=False, use_qk_norm=True, num_experts=16, num_experts_per_tok=4,
+                        moe_intermediate_size=128)
+    g = torch.Generator().manual_seed(3)
+    m = CausalLM(geo)
+    params = {k: ((1 + 0.1 * torch.randn(v.shape, generator=g)) if k.endswith("norm_weight") else 0.05 * torch.randn(v.shape, generator=g)).half()
+              for k, v in m.state_dict().items()}
+    m.load_state_dict(params, strict=True)
+    m = m.to("cuda")
+    m.quantize_(QuantConfig.fp8_per_channel())
+    before = {k: v.clone() for k, v in m.state_dict().items()}
+    B, CTX = 8, 40
+    m.rotary_emb.ensure(CTX + 8, "cuda")
+    rows = B * (CTX + 1)
+    table = torch.arange(rows, dtype=torch.int32, device="cuda").view(B, CTX + 1)
+    kv0 = [(torch.randn(rows, 4, 128, generator=g) * 0.5).half().cuda() for _ in range(2)]
+
+    def run():
+        kv = [k.clone() for k in kv0]
+        info = types.SimpleNamespace(kv_buffer=kv, cur_select_index=table[:, CTX].contiguous(), b_req_tokens_table=table, b_start_loc=None,
+                                     b_req_idx=torch.arange(B, dtype=torch.int32, device="cuda"),
+                                     b_seq_len=torch.full((B,), CTX + 1, dtype=torch.int32, device="cuda"), max_actual_seq_len=CTX + 1)
+        with torch.no_grad():
+            return m(torch.arange(B, device="cuda").view(B, 1), torch.full((B, 1), CTX, device="cuda"), info)
+
+    stacked = run()
+    m.compact_weights()
+    blocks = [b for b in m.modules() if isinstance(b, SparseMoeBlock)]
+    assert blocks and all(getattr(b, "_gu_interleaved", False) for b in blocks) and m.is_compacted()
+    assert torch.equal(run(), stacked)
+    after = m.state_dict()  # expands first
+    assert not m.is_compacted() and all(torch.equal(after[k], before[k]) for k in before)
+    assert torch.equal(run(), stacked)

@@ -940,6 +940,63 @@ def test_fused_moe_routing_weight_and_quant():
         K().fused_moe(x.to(DEV), q1.to(DEV), w2.half().to(DEV), wts.to(DEV), ids.to(DEV), w1_scale=s1.to(DEV))
 
 
+def _interleave_rows(w):
+    e, two_i = w.shape[0], w.shape[1]
+    i = two_i // 2
+    return torch.stack((w[:, :i], w[:, i:]), dim=2).reshape(e, two_i, *w.shape[2:]).contiguous()
+
+
+@pytest.mark.parametrize("fmt", ["f16", "fp8_channel", "int8_channel", "fp8_block"])
+@pytest.mark.parametrize("num_tokens,num_experts,top_k", [(64, 128, 8), (5, 8, 2), (37, 16, 4)])
+def test_fused_moe_with_interleaved_gate_up_equals_the_two_launch_form(fmt, num_tokens, num_experts, top_k):
+    """Round 5: gate|up rows paired (gate_j, up_j) at load time -> silu(gate) * up in the first grouped GEMM's epilogue.
+    Bit-identical to GEMM + silu_and_mul over the stacked layout (both outputs are rounded to fp16 before the activation),
+    for fp16 / per-channel fp8 / per-channel int8 experts and for 128 x 128 fp8 blocks re-expressed as per-row scales."""
+    hidden, inter = 256, 256
+    g = torch.Generator().manual_seed(num_tokens + num_experts)
+    x = (torch.randn(num_tokens, hidden, generator=g) / hidden**0.5).half().to(DEV)
+    w1 = (torch.randn(num_experts, 2 * inter, hidden, generator=g) / hidden**0.5)
+    w2 = (torch.randn(num_experts, hidden, inter, generator=g) / inter**0.5)
+    ids = torch.randint(0, num_experts, (num_tokens, top_k), generator=g).to(DEV)
+    wts = torch.softmax(torch.randn(num_tokens, top_k, generator=g), dim=-1).half().to(DEV)
+    if fmt == "f16":
+        a = K().fused_moe(x, w1.half().to(DEV), w2.half().to(DEV), wts, ids)
+        b = K().fused_moe(x, _interleave_rows(w1.half()).to(DEV), w2.half().to(DEV), wts, ids, w1_interleaved=True)
+    elif fmt in ("fp8_channel", "int8_channel"):
+        qf = O.quantize_fp8_per_channel if fmt.startswith("fp8") else O.quantize_int8_per_channel
+        q1, s1 = qf(w1)
+        q2, s2 = qf(w2)
+        kw = dict(w2_scale=s2.to(DEV), group_n=1, group_k=hidden)
+        a = K().fused_moe(x, q1.to(DEV), q2.to(DEV), wts, ids, w1_scale=s1.to(DEV), **kw)
+        b = K().fused_moe(x, _interleave_rows(q1).to(DEV), q2.to(DEV), wts, ids, w1_scale=_interleave_rows(s1).to(DEV),
+                          w1_interleaved=True, **kw)
+    else:
+        q1 = (w1 * 8).to(torch.float8_e4m3fn).view(torch.uint8)
+        q2 = (w2 * 8).to(torch.float8_e4m3fn).view(torch.uint8)
+        s1 = (torch.rand(num_experts, 2 * inter // 128, hidden // 128, generator=g) + 0.5) / 8
+        s2 = (torch.rand(num_experts, hidden // 128, inter // 128, generator=g) + 0.5) / 8
+        a = K().fused_moe(x, q1.to(DEV), q2.to(DEV), wts, ids, w1_scale=s1.to(DEV), w2_scale=s2.to(DEV), group_n=128, group_k=128)
+        rows = _interleave_rows(s1.repeat_interleave(128, dim=1)[:, : 2 * inter])
+        b = K().fused_moe(x, _interleave_rows(q1).to(DEV), q2.to(DEV), wts, ids, w1_scale=rows.to(DEV), w2_scale=s2.to(DEV),
+                          group_n=128, group_k=128, w1_group=(1, 128), w2_group=(128, 128), w1_interleaved=True)
+    assert torch.equal(a, b)
+
+
+@pytest.mark.parametrize("slots,experts,block", [(512, 128, 32), (8, 8, 16), (1024, 1024, 64), (1, 128, 16), (777, 60, 32)])
+def test_moe_align_small_kernel_equals_the_general_kernel(slots, experts, block, monkeypatch):
+    """The one-thread-per-slot align kernel (<= 1024 slots) against the oracle and -- LL_MOE_ALIGN_V1 is read once per
+    process, so through the oracle only -- for int32 and int64 ids, including ids that every slot shares."""
+    g = torch.Generator().manual_seed(slots)
+    for ids in (torch.randint(0, experts, (slots,), generator=g), torch.full((slots,), experts - 1), torch.zeros(slots, dtype=torch.int64)):
+        ref = O.moe_align_block_size(ids.view(-1, 1), block, experts)
+        for dt in (torch.int32, torch.int64):
+            got = K().moe_align_block_size(ids.to(dt).view(-1, 1).to(DEV), block, experts)
+            npost = int(got[2].item())
+            assert npost == int(ref[2].item())
+            assert torch.equal(got[0][:npost].cpu(), ref[0][:npost].to(torch.int32))
+            assert torch.equal(got[1][: npost // block].cpu(), ref[1][: npost // block].to(torch.int32))
+
+
 # ------------------------------------------------------------------------------------- #
 # decode-step fusions (extensions): bit-identical to the reference-shaped call sequences
 # ------------------------------------------------------------------------------------- #

@@ -7,7 +7,10 @@ pass B: SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS
 Derived (MI355X_MICROARCH.md, "rocprofv3 PMC slots" / cycle constants): SQ_WAVE_CYCLES, SQ_WAIT_*, SQ_ACTIVE_INST_* count quad-cycles
 summed over waves; SQ_VALU_MFMA_BUSY_CYCLES counts SIMD cycles the matrix pipe is busy, summed over the chip's 1024 SIMDs;
 GRBM_GUI_ACTIVE = cycles the launch was on the chip.
-  mfma_util          = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x GRBM_GUI_ACTIVE)
+  kernel_cycles      = SQ_BUSY_CYCLES / 32   (the counter is summed over the chip's 32 shader engines; it matches the un-profiled
+                       kernel duration x shader clock, whereas GRBM_GUI_ACTIVE -- summed over 8 XCDs -- also covers the
+                       profiler's per-dispatch overhead: wgemm4 50 k vs 71 k cycles)
+  mfma_util          = SQ_VALU_MFMA_BUSY_CYCLES / (1024 x kernel_cycles)
   wave_wait_frac     = SQ_WAIT_ANY / SQ_WAVE_CYCLES        (parked on s_waitcnt / barrier)
   wave_issue_stall   = SQ_WAIT_INST_ANY / SQ_WAVE_CYCLES   (ready but not issued)
   lds_conflict_frac  = SQ_LDS_BANK_CONFLICT / SQ_LDS_IDX_ACTIVE
@@ -36,8 +39,10 @@ def main():
         g = lambda d, k: d.get(k, (0, None))[1]
         gui = g(cb, "GRBM_GUI_ACTIVE") or g(ca, "GRBM_GUI_ACTIVE")
         wave = g(ca, "SQ_WAVE_CYCLES")
-        r = {"kernel": name[:70], "launches": (ca or cb).get("GRBM_GUI_ACTIVE", (0, 0))[0], "gui_cycles": gui,
-             "mfma_util": (g(cb, "SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * gui)) if gui and g(cb, "SQ_VALU_MFMA_BUSY_CYCLES") is not None else None,
+        kc = (g(ca, "SQ_BUSY_CYCLES") / 32.0) if g(ca, "SQ_BUSY_CYCLES") else (gui / 8.0 if gui else None)
+        r = {"kernel": name[:70], "launches": (ca or cb).get("GRBM_GUI_ACTIVE", (0, 0))[0], "kernel_cycles": kc, "gui_cycles_per_xcd": gui / 8.0 if gui else None,
+             "mfma_util": (g(cb, "SQ_VALU_MFMA_BUSY_CYCLES") / (1024.0 * kc)) if kc and g(cb, "SQ_VALU_MFMA_BUSY_CYCLES") is not None else None,
+             "lds_busy": (g(cb, "SQ_LDS_IDX_ACTIVE") / (256.0 * kc)) if kc and g(cb, "SQ_LDS_IDX_ACTIVE") is not None else None,
              "insts_mfma": g(cb, "SQ_INSTS_MFMA"), "insts_valu": g(cb, "SQ_INSTS_VALU"), "insts_lds": g(cb, "SQ_INSTS_LDS"),
              "wave_wait_frac": (g(ca, "SQ_WAIT_ANY") / wave) if wave and g(ca, "SQ_WAIT_ANY") is not None else None,
              "wave_issue_stall_frac": (g(ca, "SQ_WAIT_INST_ANY") / wave) if wave and g(ca, "SQ_WAIT_INST_ANY") is not None else None,
@@ -47,10 +52,10 @@ def main():
              "wait_inst_lds_per_wave_cycle": (g(cb, "SQ_WAIT_INST_LDS") / wave) if wave and g(cb, "SQ_WAIT_INST_LDS") is not None else None}
         rows.append(r)
     f = lambda v, p=3: "-" if v is None else (f"{v:.{p}f}" if isinstance(v, float) else str(v))
-    print("| kernel | launches | MFMA util | wave wait | issue stall | wave active | VALU active | LDS conflict | MFMA / VALU / LDS insts |")
-    print("|---|---|---|---|---|---|---|---|---|")
+    print("| kernel | launches | kernel cycles | MFMA util | LDS busy | wave wait | issue stall | wave active | VALU active | LDS conflict | MFMA / VALU / LDS insts |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|")
     for r in rows:
-        print(f"| `{r['kernel']}` | {r['launches']} | {f(r['mfma_util'])} | {f(r['wave_wait_frac'])} | {f(r['wave_issue_stall_frac'])} | {f(r['wave_active_frac'])} | "
+        print(f"| `{r['kernel']}` | {r['launches']} | {f(r['kernel_cycles'], 0)} | {f(r['mfma_util'])} | {f(r['lds_busy'])} | {f(r['wave_wait_frac'])} | {f(r['wave_issue_stall_frac'])} | {f(r['wave_active_frac'])} | "
               f"{f(r['valu_active_frac'])} | {f(r['lds_conflict_frac'], 4)} | {f(r['insts_mfma'], 0)} / {f(r['insts_valu'], 0)} / {f(r['insts_lds'], 0)} |")
     print()
     print(json.dumps(rows))

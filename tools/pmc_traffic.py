@@ -24,7 +24,7 @@ def weighted(d):
 
 def main():
     fetch_db, write_db, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-    gf, gw = per_kernel(fetch_db, "FETCH_SIZE", "wgemm3"), per_kernel(write_db, "WRITE_SIZE", "wgemm3")
+    gf, gw = per_kernel(fetch_db, "FETCH_SIZE", "wgemm"), per_kernel(write_db, "WRITE_SIZE", "wgemm")
     af, aw = per_kernel(fetch_db, "FETCH_SIZE", "fd_stage1"), per_kernel(write_db, "WRITE_SIZE", "fd_stage1")
     f_kb, n_f = weighted(gf)
     w_kb, _ = weighted(gw)
