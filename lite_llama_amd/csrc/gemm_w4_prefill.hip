@@ -25,6 +25,9 @@
 #define PF_BN 256
 #define PF_BK 64
 #define PF_TILE (256 * PF_BK * 2)  // bytes of one [256][64] fp16 tile
+#ifndef PF_XR
+#define PF_XR 3  // activation-tile ring slots (32 KB each): tiles are requested PF_XR - 1 k-steps ahead
+#endif
 
 struct PfParams {
   uint16_t* out;
@@ -43,8 +46,7 @@ __device__ __forceinline__ int pf_swz(int row, int slot) { return slot ^ ((row >
 
 __global__ __launch_bounds__(PF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgemm_prefill_kernel(const PfParams p) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
-  unsigned char* const wt = lds;                 // [2][256 weight rows][64 k] fp16, swizzled
-  unsigned char* const xt = lds + 2 * PF_TILE;   // [2][256 token rows][64 k] fp16, swizzled
+  unsigned char* const xt = lds;  // [PF_XR][256 token rows][64 k] fp16, swizzled
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   // block -> tile: groups of 16 x 16 tiles; inside a group workgroup 8 j + xcd (on XCD xcd under the round-robin dispatch)
@@ -62,8 +64,7 @@ __global__ __launch_bounds__(PF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   const int64_t m0 = (int64_t)tm * PF_BM, n0 = (int64_t)tn * PF_BN;
   const int ksteps = (int)(p.k / PF_BK);
 
-  // ---- per-thread roles of the two loaders ----
-  // activations: wave w issues pieces 4w .. 4w + 3 (8 rows x 128 B each); lane -> (row, physical slot), source slot swizzled
+  // ---- activation loader role: wave w issues pieces 4w .. 4w + 3 (8 rows x 128 B each); lane -> (row, physical slot) ----
   uint32_t xoff[4];
 #pragma unroll
   for (int j = 0; j < 4; ++j) {
@@ -72,37 +73,37 @@ __global__ __launch_bounds__(PF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     if (row >= p.m) row = p.m - 1;  // rows >= M feed only unstored outputs
     xoff[j] = (uint32_t)(row * p.x_stride * 2 + pf_swz(r, ps) * 16);
   }
-  // weights: thread (wave w, lane l) owns the 16 packed bytes of piece (tile128 = w >> 2, ng = w & 3) lane l of every k-half:
-  // weight row wr of the tile, k-octets h * 4 + 0..3 of the 64-k step
-  const int nl = lane & 31, h = lane >> 5;
-  const int wr = (wv >> 2) * 128 + (wv & 3) * 32 + nl;
-  const char* wsrc = (const char*)p.wp + ((size_t)(n0 / 128 + (wv >> 2)) * p.chunks) * 8192 + (size_t)((wv & 3) * 1024 + lane * 16);
-  const char* ssrc = (const char*)p.sp + (size_t)(n0 + wr) * 8;
-  uint32_t magic = 0x64006400u;
-  asm volatile("" : "+v"(magic));
-
   auto issue_x = [&](int ks, int buf) {
     const char* xb = (const char*)p.x + (size_t)ks * (PF_BK * 2);
 #pragma unroll
-    for (int j = 0; j < 4; ++j) v3_dma16<false>((uint32_t)(2 * PF_TILE + buf * PF_TILE + (wv * 4 + j) * 1024), xb, xoff[j]);
-  };
-  auto load_w = [&](int ks, u32x4& w, u32x2& sc) {
-    const int c = ks >> 1, kh = ks & 1;
-    w = *reinterpret_cast<const u32x4*>(wsrc + (size_t)c * 8192 + kh * 4096);
-    sc = *reinterpret_cast<const u32x2*>(ssrc + (size_t)(c >> p.gshift) * (size_t)p.n * 8);
-  };
-  auto park_w = [&](const u32x4& w, const u32x2& sc, int buf) {
-    unsigned char* base = wt + buf * PF_TILE + wr * 128;
-#pragma unroll
-    for (int j = 0; j < 4; ++j) {
-      const uint32_t word = j == 0 ? w.x : j == 1 ? w.y : j == 2 ? w.z : w.w;
-      const f16x8 d = v3_dequant(word, sc.x, sc.y, magic);
-      *reinterpret_cast<f16x8*>(base + pf_swz(wr, h * 4 + j) * 16) = d;
-    }
+    for (int j = 0; j < 4; ++j) v3_dma16<false>((uint32_t)(buf * PF_TILE + (wv * 4 + j) * 1024), xb, xoff[j]);
   };
 
-  // ---- consumer geometry: wave (wm, wn) multiplies token rows wm * 128 .. + 127 by weight rows wn * 64 .. + 63 ----
+  // ---- consumer geometry: wave (wm, wn) multiplies token rows wm * 128 .. + 127 by weight rows wn * 64 .. + 63.  Its weight
+  // words come STRAIGHT from the packed stream into registers: lane (nl, h) of piece (128-row tile wn >> 1, row group
+  // (wn & 1) * 2 + ni, k-half) holds the four words = k-octets h * 4 + 0..3 of weight row nl -- word kk IS the A operand of MFMA
+  // k-step kk (the decode engines' pairing: a k-step contracts octets kk and 4 + kk), so nothing is staged through LDS and
+  // nothing is written back; the two waves that share a weight quarter each dequantise it (VALU under the other wave's MFMAs).
   const int wm = wv >> 2, wn = wv & 3;
+  const int nl = lane & 31, h = lane >> 5;
+  const char* wsrc[2];
+  const char* ssrc[2];
+#pragma unroll
+  for (int ni = 0; ni < 2; ++ni) {
+    const int ng = (wn & 1) * 2 + ni;
+    wsrc[ni] = (const char*)p.wp + ((size_t)(n0 / 128 + (wn >> 1)) * p.chunks) * 8192 + (size_t)(ng * 1024 + lane * 16);
+    ssrc[ni] = (const char*)p.sp + (size_t)(n0 + wn * 64 + ni * 32 + nl) * 8;
+  }
+  uint32_t magic = 0x64006400u;
+  asm volatile("" : "+v"(magic));
+  auto load_w = [&](int ks, u32x4 (&w)[2], u32x2 (&sc)[2]) {
+    const int c = ks >> 1, kh = ks & 1;
+#pragma unroll
+    for (int ni = 0; ni < 2; ++ni) {
+      w[ni] = *reinterpret_cast<const u32x4*>(wsrc[ni] + (size_t)c * 8192 + kh * 4096);
+      sc[ni] = *reinterpret_cast<const u32x2*>(ssrc[ni] + (size_t)(c >> p.gshift) * (size_t)p.n * 8);
+    }
+  };
   f32x16 acc[2][4];
 #pragma unroll
   for (int ni = 0; ni < 2; ++ni)
@@ -110,13 +111,7 @@ __global__ __launch_bounds__(PF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     for (int mi = 0; mi < 4; ++mi)
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[ni][mi][e] = 0.f;
-  int wrow_off[2], xrow_off[4], wsw[2], xsw[4];
-#pragma unroll
-  for (int ni = 0; ni < 2; ++ni) {
-    const int r = wn * 64 + ni * 32 + nl;
-    wrow_off[ni] = r * 128;
-    wsw[ni] = (r >> 1) & 7;
-  }
+  int xrow_off[4], xsw[4];
 #pragma unroll
   for (int mi = 0; mi < 4; ++mi) {
     const int r = wm * 128 + mi * 32 + nl;
@@ -124,52 +119,65 @@ __global__ __launch_bounds__(PF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     xsw[mi] = (r >> 1) & 7;
   }
 
-  // ---- prologue: step 0 into buffer 0 ----
-  u32x4 wq;
-  u32x2 wsc;
-  issue_x(0, 0);
-  load_w(0, wq, wsc);
-  park_w(wq, wsc, 0);  // (waits for its own two loads)
-  __builtin_amdgcn_s_waitcnt(0x0070);
+  // ---- prologue: the activation tiles of steps 0 .. PF_XR - 2, the weight words of step 0 ----
+  u32x4 wA[2], wB[2];
+  u32x2 sA[2], sB[2];
+  for (int s0 = 0; s0 < PF_XR - 1 && s0 < ksteps; ++s0) issue_x(s0, s0);
+  load_w(0, wA, sA);
+  __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0): (the builtin -- see the loop)
   __builtin_amdgcn_s_barrier();
 
-  for (int ks = 0; ks < ksteps; ++ks) {
-    const int buf = ks & 1;
-    const bool more = ks + 1 < ksteps;
-    if (more) {
-      issue_x(ks + 1, buf ^ 1);  // the other buffers were last read in step ks - 1: every wave has passed that step's barrier
-      load_w(ks + 1, wq, wsc);
-    }
-    const unsigned char* wb = wt + buf * PF_TILE;
-    const unsigned char* xb = xt + buf * PF_TILE;
-    // fragments of k-step kk + 1 are read while the eight MFMAs of k-step kk run (two register sets)
-    f16x8 wf[2][2], xf[2][4];
-    auto read_frags = [&](int set, int kk) {
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni) wf[set][ni] = *reinterpret_cast<const f16x8*>(wb + wrow_off[ni] + (((2 * kk + h) ^ wsw[ni]) * 16));
-#pragma unroll
-      for (int mi = 0; mi < 4; ++mi) xf[set][mi] = *reinterpret_cast<const f16x8*>(xb + xrow_off[mi] + (((2 * kk + h) ^ xsw[mi]) * 16));
-    };
-    read_frags(0, 0);
-#pragma unroll
-    for (int kk = 0; kk < 4; ++kk) {
-      const int cur = kk & 1;
-      if (kk < 3) read_frags(cur ^ 1, kk + 1);
-      __builtin_amdgcn_sched_barrier(0);
-#pragma unroll
-      for (int ni = 0; ni < 2; ++ni)
-#pragma unroll
-        for (int mi = 0; mi < 4; ++mi)
-          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][ni], xf[cur][mi], acc[ni][mi], 0, 0, 0);
-      __builtin_amdgcn_sched_barrier(0);
-    }
-    if (more) park_w(wq, wsc, buf ^ 1);
-    // (the builtin, not an asm string: hipcc's wait-count pass cannot see the LDS-DMA statements and, not knowing that this wait
-    // drained the counters, protected the re-use of the weight registers at the top of the next step with vmcnt waits that in
-    // hardware also waited for the activation DMA issued just before them -- a full memory latency per k-step, round 5)
-    __builtin_amdgcn_s_waitcnt(0x0070);  // vmcnt(0) lgkmcnt(0)
-    __builtin_amdgcn_s_barrier();
+#if defined(PF_KEEP) && PF_KEEP  /* A/B: keep the youngest requests (the tile two steps ahead + next step's weight words) in flight */
+#define PF_END_WAIT asm volatile("s_waitcnt vmcnt(8) lgkmcnt(0)" ::: "memory");
+#else
+#define PF_END_WAIT __builtin_amdgcn_s_waitcnt(0x0070);
+#endif
+#define PF_STEP(WC, SC, WN, SN)                                                                                        \
+  {                                                                                                                    \
+    const unsigned char* xb = xt + (ks % PF_XR) * PF_TILE;                                                             \
+    /* fragments + first weight fragments first (the MFMAs can start), then the requests of the steps ahead */        \
+    f16x8 xf[2][4], wf[2][2];                                                                                          \
+    _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                                   \
+        xf[0][mi] = *reinterpret_cast<const f16x8*>(xb + xrow_off[mi] + (((h * 4 + 0) ^ xsw[mi]) * 16));               \
+    _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) wf[0][ni] = v3_dequant(WC[ni].x, SC[ni].x, SC[ni].y, magic);      \
+    if (ks + PF_XR - 1 < ksteps) issue_x(ks + PF_XR - 1, (ks + PF_XR - 1) % PF_XR); /* that buffer was read in step ks - 1 */ \
+    if (ks + 1 < ksteps) load_w(ks + 1, WN, SN);                                                                        \
+    __builtin_amdgcn_sched_barrier(0);                                                                                 \
+    _Pragma("unroll") for (int kk = 0; kk < 4; ++kk) {                                                                 \
+      const int cur = kk & 1;                                                                                          \
+      /* k-step kk + 1: activation fragments read and weight fragments dequantised UNDER the eight MFMAs of k-step kk */ \
+      if (kk < 3) {                                                                                                    \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                               \
+            xf[cur ^ 1][mi] = *reinterpret_cast<const f16x8*>(xb + xrow_off[mi] + (((h * 4 + kk + 1) ^ xsw[mi]) * 16)); \
+        _Pragma("unroll") for (int ni = 0; ni < 2; ++ni) {                                                             \
+          const uint32_t word = kk == 0 ? WC[ni].y : kk == 1 ? WC[ni].z : WC[ni].w;                                    \
+          wf[cur ^ 1][ni] = v3_dequant(word, SC[ni].x, SC[ni].y, magic);                                               \
+        }                                                                                                              \
+      }                                                                                                                \
+      _Pragma("unroll") for (int ni = 0; ni < 2; ++ni)                                                                 \
+        _Pragma("unroll") for (int mi = 0; mi < 4; ++mi)                                                               \
+          acc[ni][mi] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[cur][ni], xf[cur][mi], acc[ni][mi], 0, 0, 0);        \
+      if (kk < 3) {                                                                                                    \
+        _Pragma("unroll") for (int i = 0; i < 8; ++i) {                                                                \
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0); /* one MFMA */                                            \
+          __builtin_amdgcn_sched_group_barrier(0x002, 4, 0); /* four VALU of the next dequantisation */                \
+          if (i < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0); /* one fragment read */                        \
+        }                                                                                                              \
+      }                                                                                                                \
+      __builtin_amdgcn_sched_barrier(0);                                                                               \
+    }                                                                                                                  \
+    PF_END_WAIT                                                                                                        \
+    __builtin_amdgcn_s_barrier();                                                                                      \
+    ++ks;                                                                                                              \
   }
+  int ks = 0;
+  for (;;) {
+    PF_STEP(wA, sA, wB, sB)
+    if (ks >= ksteps) break;
+    PF_STEP(wB, sB, wA, sA)
+    if (ks >= ksteps) break;
+  }
+#undef PF_STEP
 
   // ---- epilogue (the decode engines'): a lane holds, for token row m = nl, the weight rows 8g + 4h .. + 3 of a 32-row group ----
   auto swap32 = [](uint32_t& a, uint32_t& b) {
@@ -267,9 +275,9 @@ extern "C" int ll_w4a16_matmul_prepacked_mtiled(void* out, const void* x, const 
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute((const void*)wgemm_prefill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, 4 * PF_TILE);
+    (void)hipFuncSetAttribute((const void*)wgemm_prefill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PF_XR * PF_TILE);
     attr_set[dev] = true;
   }
-  wgemm_prefill_kernel<<<dim3((unsigned)grid), PF_THREADS, 4 * PF_TILE, (hipStream_t)stream>>>(p);
+  wgemm_prefill_kernel<<<dim3((unsigned)grid), PF_THREADS, PF_XR * PF_TILE, (hipStream_t)stream>>>(p);
   return LL_LAUNCH_CHECK();
 }

@@ -132,6 +132,9 @@ __global__ __launch_bounds__(V4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 
   if (wv >= 8) {
     // ======================================== loaders ======================================== //
+#if defined(V4_LOADER_PRIO) && V4_LOADER_PRIO > 0  // A/B: the loaders are the youngest waves of their SIMDs (arbitration losers by age)
+    __builtin_amdgcn_s_setprio(V4_LOADER_PRIO);
+#endif
     const int L = wv & 1;
     int issued = 0;
     const bool wl = wv < 10;  // waves 8, 9: weights + scale pairs; 10, 11: the activation tile
