@@ -176,8 +176,22 @@ def gemm_roofline(model, batch, quant, iters=6):
                                 "WRITE_SIZE uncalibrated)")
         except Exception:
             traffic = None
+    mfma_util = None
+    spath = os.path.join(ROOT, "profiles", "pmc_sq.json")
+    if os.path.exists(spath) and quant in ("int4", "smoothquant"):
+        try:  # north_star's "MFMA-utilisation counters": stored values of the last tools/pmc_round.sh pass, not live counters
+            sj = json.load(open(spath))
+            pick = {"int4": ["wgemm4_kernel<5, 2>", "wgemm3_kernel<2, 1>"], "smoothquant": ["dense8_kernel<3, 1>"]}[quant]
+            mfma_util = {"source": "stored profile values (profiles/pmc_sq.json <- tools/pmc_round.sh: SQ_VALU_MFMA_BUSY_CYCLES / "
+                                   "(1024 SIMDs x SQ_BUSY_CYCLES / 32), separate --pmc passes over the step's eager launches)",
+                         "kernels": {k: {"mfma_util": v.get("mfma_util"), "lds_busy": v.get("lds_busy"),
+                                         "lds_bank_conflict_frac": v.get("lds_conflict_frac"), "wave_wait_frac": v.get("wave_wait_frac")}
+                                     for k, v in sj.items() if any(t in k for t in pick)}}
+        except Exception:
+            mfma_util = None
     kernel = {
-        "int4": "wgemm3_kernel (w4a16 dequant-GEMM over pre-packed weights, decode engine; gemm_w4_v3.hip)",
+        "int4": "wgemm4_kernel (row-group engine, the fused gate|up + swiglu launch; gemm_w4_v4.hip) + wgemm3_kernel (unit-loop engine, "
+                "the q|k|v / o / down split-K partial launches; gemm_w4_v3.hip) -- w4a16 dequant-GEMM over pre-packed weights",
         "int8": "dense8_kernel + dense8_finish (w8a16 int8, split-K weight streaming; gemm_w8_skinny.hip)",
         "fp8": "dense8_kernel + dense8_finish (w8a16 fp8-e4m3, split-K weight streaming; gemm_w8_skinny.hip)",
         "smoothquant": "dense8_kernel (int8 x int8 MFMA, split-K planes; gemm_w8_skinny.hip) with the per-token quantiser / scale "
@@ -194,7 +208,7 @@ def gemm_roofline(model, batch, quant, iters=6):
         "achieved": round(achieved / 1e9, 1), "peak": PEAK_HBM / 1e9, "unit": "GB/s",
         "frac": round(achieved / PEAK_HBM, 4), "traffic": traffic, "traffic_parts": traffic_parts, "traffic_source": traffic_source,
         "bytes_per_launch": int(bytes_per_launch), "avg_launch_us": round(avg_s * 1e6, 2),
-        "launches_timed": launches, "timed_as": how,
+        "launches_timed": launches, "timed_as": how, "mfma_util": mfma_util,
     }
 
 

@@ -13,16 +13,23 @@ run_pass() {  # tag, counters, bench flags...
 }
 run_pass hA "$A"
 run_pass hB "$B"
-python tools/pmc_sq.py /tmp/pmc_hA/p_results.db /tmp/pmc_hB/p_results.db wgemm4 wgemm3 fd_stage1 skip_rmsnorm_partials > $O/pmc_sq_headline_$V.md 2>&1
+rm -f $O/pmc_sq_$V.json
+PMC_SQ_JSON=$O/pmc_sq_$V.json python tools/pmc_sq.py /tmp/pmc_hA/p_results.db /tmp/pmc_hB/p_results.db wgemm4 wgemm3 fd_stage1 skip_rmsnorm_partials > $O/pmc_sq_headline_$V.md 2>&1
 python tools/rocpd.py pmc /tmp/pmc_hA/p_results.db wgemm > $O/pmc_sq_headline_passA_$V.txt 2>&1
 python tools/rocpd.py pmc /tmp/pmc_hB/p_results.db wgemm > $O/pmc_sq_headline_passB_$V.txt 2>&1
 run_pass cA "$A" --model llama-3-8b --quant smoothquant --batch 32
 run_pass cB "$B" --model llama-3-8b --quant smoothquant --batch 32
-python tools/pmc_sq.py /tmp/pmc_cA/p_results.db /tmp/pmc_cB/p_results.db dense8_kernel fd_stage1 skip_rmsnorm_q8 > $O/pmc_sq_cfg4_$V.md 2>&1
+PMC_SQ_JSON=$O/pmc_sq_$V.json python tools/pmc_sq.py /tmp/pmc_cA/p_results.db /tmp/pmc_cB/p_results.db dense8_kernel skip_rmsnorm_q8 w8a8 > $O/pmc_sq_cfg4_$V.md 2>&1
+# prefill GEMM (M-tiled): MFMA utilisation of the 64 x 512 prompt pass
+cd /tmp && rm -rf /tmp/pmc_pA /tmp/pmc_pB
+timeout 600 rocprofv3 --kernel-trace --pmc $A -d /tmp/pmc_pA -o p -- python $ROOT/benchmarks/prefill_gemm.py > /dev/null 2> $O/pmc_pA.err
+timeout 600 rocprofv3 --kernel-trace --pmc $B -d /tmp/pmc_pB -o p -- python $ROOT/benchmarks/prefill_gemm.py > /dev/null 2> $O/pmc_pB.err
+cd $ROOT
+PMC_SQ_JSON=$O/pmc_sq_$V.json python tools/pmc_sq.py /tmp/pmc_pA/p_results.db /tmp/pmc_pB/p_results.db wgemm_prefill > $O/pmc_sq_prefill_$V.md 2>&1
 for C in FETCH_SIZE WRITE_SIZE; do
   run_pass $C $C
   python tools/rocpd.py pmc /tmp/pmc_$C/p_results.db wgemm > $O/pmc_${C}_gemm_$V.txt 2>&1
   python tools/rocpd.py pmc /tmp/pmc_$C/p_results.db fd_stage1 > $O/pmc_${C}_attention_$V.txt 2>&1
 done
 python tools/pmc_traffic.py /tmp/pmc_FETCH_SIZE/p_results.db /tmp/pmc_WRITE_SIZE/p_results.db ${R}_$V > $O/pmc_traffic_$V.json 2>&1
-head -12 $O/pmc_sq_headline_$V.md; head -8 $O/pmc_sq_cfg4_$V.md; head -30 $O/pmc_traffic_$V.json
+head -8 $O/pmc_sq_headline_$V.md; head -8 $O/pmc_sq_cfg4_$V.md; head -4 $O/pmc_sq_prefill_$V.md; head -8 $O/pmc_traffic_$V.json

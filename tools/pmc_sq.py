@@ -59,6 +59,13 @@ def main():
               f"{f(r['valu_active_frac'])} | {f(r['lds_conflict_frac'], 4)} | {f(r['insts_mfma'], 0)} / {f(r['insts_valu'], 0)} / {f(r['insts_lds'], 0)} |")
     print()
     print(json.dumps(rows))
+    import os
+    if os.environ.get("PMC_SQ_JSON"):  # merged store read by bench.py (roofline.mfma_util: a stored profile value, labelled so)
+        path = os.environ["PMC_SQ_JSON"]
+        store = json.load(open(path)) if os.path.exists(path) else {}
+        for r in rows:
+            store[r["kernel"]] = {k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items() if k != "kernel"}
+        json.dump(store, open(path, "w"), indent=1)
 
 
 if __name__ == "__main__":
