@@ -356,7 +356,9 @@ def prefill_point(model, args, dev, act_dtype, geo, tp, prompt_len=512, reps=2):
            "frac_of_mfma_peak": round((lin_flops + att_flops) / dt / peak, 4),
            "flops": {"linear": lin_flops, "attention": att_flops}, "reps_ms": [round(t * 1e3, 2) for t in times],
            "first_tokens_checksum": int(first.long().sum().item()),
-           "route": "w4a16 > 64 rows: see roofline notes in DESIGN.md 5.3 (prefill GEMM route); attention: fa_prefill2"}
+           "route": {"int4": "wgemm_prefill_kernel (M-tiled W4A16 MFMA GEMM over the load-time layout, gemm_w4_prefill.hip) + fa_prefill2",
+                     "none": "library GEMM (F.linear) + fa_prefill2"}.get(args.quant, "wgemm_kernel (generic engine, gemm_wq.hip) + fa_prefill2"),
+           "mfma_peak_note": "2.5 PF = nominal dense fp16 peak at 2.4 GHz; under this load the part clocks ~1.6 GHz (DESIGN.md 5.3)"}
     del eng
     torch.cuda.empty_cache()
     return out
