@@ -230,6 +230,11 @@ int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* wpacked, con
                               const void* bias, int64_t m, int64_t n, int64_t k, int group_size,
                               int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,
                               void* stream);
+/* Host-side introspection of the row-group engine (gemm_w4_v4.hip, round 5) for a finished-output launch (epilogue 0 / 1): out8 =
+ * [takes the launch 0 / 1, grid, row groups per workgroup, rbase, rrem, compute units assumed, LDS bytes, 0]; workgroup t owns the
+ * 32-row groups [t * rbase + min(t, rrem), + rbase + (t < rrem)).  No device work. */
+int ll_w4a16_v4_plan(int64_t m, int64_t n, int64_t k, int group_size, int epilogue, int32_t* out8);
+
 /* The same product for MANY rows (prefill: m = batch x prompt tokens; w4a16.py:152-207 tiles M x N) over the same load-time
  * layouts: 256 x 256 x 64 MFMA tiles, the weight tile dequantised once per 256 rows (gemm_w4_prefill.hip).  epilogue 0: out
  * [m][n] (+ bias); 1: fused gate|up rows interleaved -> out [m][n / 2] = silu(gate) * up.  n % 256 == 0, k % 128 == 0. */

@@ -49,6 +49,7 @@ SIGNATURES = {
     "ll_skip_rmsnorm_partials": [P, P, I, P, P, L, L, F, I, P],
     "ll_skip_rmsnorm_slots": [P, P, I, P, P, L, L, F, I, P],
     "ll_w4a16_matmul_prepacked": [P, P, P, P, P, L, L, L, I, L, P, P, I, P],
+    "ll_w4a16_v4_plan": [L, L, L, I, I, P],
     "ll_w4a16_mtiled_supported": [L, L, L, I],
     "ll_w4a16_matmul_prepacked_mtiled": [P, P, P, P, P, L, L, L, I, L, I, P],
     "ll_w4a16_v3_plan": [L, L, L, I, I, P],

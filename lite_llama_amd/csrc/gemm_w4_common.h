@@ -89,6 +89,7 @@ __device__ __forceinline__ void v3_vmcnt() {
 }
 
 // host-side dispatch between the two engines (gemm_w4_v4.hip)
+extern "C" int ll_w4a16_prepacked_supported(int64_t m, int64_t n, int64_t k, int group_size);
 int v4_wants(int64_t m, int64_t n, int64_t k, int group_size, int epilogue);
 int v4_launch(void* out, const void* x, const void* wpacked, const void* spacked, const void* bias, int64_t m, int64_t n, int64_t k,
               int group_size, int64_t x_stride_m, int epilogue, int kslices, void* stream);

@@ -509,6 +509,25 @@ int v4_wants(int64_t m, int64_t n, int64_t k, int group_size, int epilogue) {
   return (kn.on & 1) && v4_full_nrgt(n) ? 1 : 0;
 }
 
+// Host-side introspection (tests; no device work): the row-group engine's plan for a finished-output launch
+// (epilogue 0 / 1) of n weight rows as 8 ints -- [0] 1 if the engine takes the launch (else the unit loop does), [1] grid, [2] row
+// groups per workgroup (template bound), [3] rbase, [4] rrem (workgroup t owns groups [t * rbase + min(t, rrem), + rbase + (t < rrem))),
+// [5] compute units assumed, [6] LDS bytes, [7] 0.
+extern "C" int ll_w4a16_v4_plan(int64_t m, int64_t n, int64_t k, int group_size, int epilogue, int32_t* out8) {
+  if (!out8) return LL_ERR_ARG;
+  if (!ll_w4a16_prepacked_supported(m, n, k, group_size)) return LL_ERR_SHAPE;
+  for (int i = 0; i < 8; ++i) out8[i] = 0;
+  const int nrgt = ((epilogue & 3) == 2) ? 0 : v4_full_nrgt(n);
+  out8[5] = v4_num_cus();
+  if (!nrgt || !v4_wants(m, n, k, group_size, epilogue)) return LL_OK;
+  const int rgs = (int)(n / 32);
+  int ntiles = v4_num_cus();
+  if (ntiles > rgs) ntiles = rgs;
+  out8[0] = 1; out8[1] = ntiles; out8[2] = nrgt; out8[3] = rgs / ntiles; out8[4] = rgs % ntiles;
+  out8[6] = nrgt == 2 ? V4Lds<2>::BYTES : nrgt == 4 ? V4Lds<4>::BYTES : V4Lds<5>::BYTES;
+  return LL_OK;
+}
+
 template <int NRGT, int MT>
 static void v4_go(const V4Params& p, int grid, hipStream_t st) {
   static bool attr_set[16] = {false};

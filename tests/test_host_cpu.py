@@ -259,6 +259,38 @@ def test_w4a16_plans_cover_every_unit_once():
     assert (pl["nf"], pl["tiles"], pl["chunks"], pl["upw"], pl["grid"]) == (2, 148, 28, 17, 244), pl
 
 
+def test_row_group_engine_plan_assigns_every_row_group_once():
+    """The round-5 row-group engine (gemm_w4_v4.hip) for finished-output launches: workgroup t owns 32-row groups
+    ``[t * rbase + min(t, rrem), + rbase + (t < rrem))`` and all of K -- every group exactly once, each workgroup within one of the
+    template bound, the headline gate|up as 160 workgroups of five groups + 96 of four; shapes it does not serve stay on the unit loop."""
+    import ctypes
+    from lite_llama_amd import _lib
+
+    lib = _lib.lib()
+
+    def plan(n, k, ep):
+        out = (ctypes.c_int32 * 8)()
+        assert lib.ll_w4a16_v4_plan(64, n, k, 128, ep, ctypes.cast(out, ctypes.c_void_p)) == 0
+        return list(out)
+
+    takes, grid, nrgt, rbase, rrem, cus, lds, _ = plan(37888, 3584, 1)
+    assert (takes, grid, nrgt, rbase, rrem) == (1, 256, 5, 4, 160) and lds <= 160 * 1024
+    for n in (37888, 28672, 40960, 33024, 32768 + 128):
+        takes, grid, nrgt, rbase, rrem, cus, lds, _ = plan(n, 512, 0)
+        if not takes:
+            continue
+        owned = []
+        for t in range(grid):
+            lo = t * rbase + min(t, rrem)
+            cnt = rbase + (1 if t < rrem else 0)
+            assert nrgt - 1 <= cnt <= nrgt, (n, t, cnt, nrgt)
+            owned += list(range(lo, lo + cnt))
+        assert owned == list(range(n // 32)), n
+    assert plan(4608, 3584, 0)[0] == 0 and plan(3584, 18944, 0)[0] == 0   # too few row groups per CU: the unit loop
+    assert plan(37888, 3584, 2)[0] == 0                                    # split-K partial launches: unit loop by default
+    assert plan(37888, 3584, 1 | (2 << 8))[0] == 0                         # a forced unit-loop tile width (tests / tuning)
+
+
 def test_int8_rows_regroup_only_their_leading_dimensions():
     """kernels/norm_act.py::Int8Rows stands in for the fp16 activations of a smoothquant block (the quantiser ran inside the
     norm launch): callers re-group its leading dimensions like a tensor's; the row width never changes."""
