@@ -198,8 +198,8 @@ def gemm_roofline(model, batch, quant, iters=6):
                        "epilogue fused into the neighbouring launches where the step fuses them (w8a8_fused.hip): as timed here, "
                        "q|k|v = quantiser + GEMM + finish, gate|up = quantiser + GEMM + finish-swiglu, o / down = quantiser + GEMM",
         "none": "dense8_kernel 16-bit form in split-K partial mode for q|k|v, o, down (gemm_w8_skinny.hip; planes summed by the "
-                "consuming norm / attention launch) + hipBLASLt through torch F.linear for the fused gate|up GEMM (followed by the "
-                "in-tree swiglu launch) -- the mix the decode step runs; averaged over the launches",
+                "consuming norm / attention launch) + wgemm16_rows_kernel (16-bit row-group loop, gemm_w16_rows.hip) for the fused "
+                "gate|up incl. its swiglu -- in-tree kernels only; averaged over the launches",
     }[quant] if batch <= 64 or quant == "none" else "wgemm_kernel (generic engine, M > 64; gemm_wq.hip)"
     return {
         "bound": "hbm", "kernel": kernel,

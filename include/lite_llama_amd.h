@@ -303,6 +303,13 @@ int ll_quant_act_cached_try(int8_t* q, float* a_scale, const void* x, int64_t m,
  * library GEMM), < 0 on error. */
 int ll_dense16_matmul(void* out, const void* x, const void* w, const void* bias, int64_t m, int64_t n, int64_t k,
                       int64_t x_stride, int64_t w_stride, int dtype, void* partials, void* stream);
+/* Round 5: the same product on the row-group loop (gemm_w16_rows.hip) -- every workgroup owns a run of 32-row groups and all of K,
+ * weights and activations streamed through an LDS ring by LDS-DMA, finished outputs only (no planes, no finish launch).
+ * epilogue 0: out [m][n] (+ bias); 1: the rows of w are (gate_j, up_j) pairs -> out [m][n / 2] = silu(gate) * up (swiglu_forward's
+ * arithmetic on the rounded outputs).  m <= 64, n % 32 == 0, k % 128 == 0, element strides % 8 == 0. */
+int ll_dense16_rows_supported(int64_t m, int64_t n, int64_t k, int epilogue); /* 1 / 0 */
+int ll_dense16_rows_matmul(void* out, const void* x, const void* w, const void* bias, int64_t m, int64_t n, int64_t k,
+                           int64_t x_stride_m, int64_t w_stride_n, int dtype, int epilogue, void* stream);
 
 /* ---- a11: fused_moe pieces  (kernels/fused_moe.py:45-99, :236-292, :298-335) ---
  * moe_align_block_size: sorted_ids int32[num_slots + E*(block-1)] (sentinel =
@@ -321,6 +328,8 @@ int ll_moe_gemm(void* c, const void* a, const void* w, const float* w_scale, con
                 int64_t w_stride_e, int64_t w_stride_n, int64_t s_stride_e, int64_t s_stride_n,
                 int64_t s_stride_k, int dtype, void* stream);
 int ll_silu_and_mul(void* out, const void* x, int64_t rows, int64_t n, int dtype, void* stream);
+/* out[r, j] = silu(x[r, 2 j]) * x[r, 2 j + 1] over x [rows, 2 n]: the fused gate|up output of row-INTERLEAVED weights (round 5). */
+int ll_silu_and_mul_pairs(void* out, const void* x, int64_t rows, int64_t n, int dtype, void* stream);
 int ll_moe_sum(void* out, const void* x, int64_t tokens, int top_k, int64_t n, int dtype,
                void* stream);
 /* Router tail (models/qwen3_moe.py:85-100 after the router GEMM): probabilities = softmax over ALL experts in fp32 of

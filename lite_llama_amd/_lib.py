@@ -56,6 +56,8 @@ SIGNATURES = {
     "ll_w8a16_matmul": [P, P, P, P, P, L, L, L, I, L, I, L, L, L, L, P, P, P],
     "ll_quantize_activations_int8": [P, P, P, L, L, L, P],
     "ll_dense16_matmul": [P, P, P, P, L, L, L, L, L, I, P, P],
+    "ll_dense16_rows_supported": [L, L, L, I],
+    "ll_dense16_rows_matmul": [P, P, P, P, L, L, L, L, L, I, I, P],
     "ll_dense_partials_count": [L, L, L, I, I],
     "ll_dense_partials": [P, P, P, P, L, L, L, I, L, I, L, L, L, L, I, P],
     "ll_skip_rmsnorm_q8": [P, P, P, P, P, I, P, P, P, P, P, L, L, F, P],
@@ -65,6 +67,7 @@ SIGNATURES = {
     "ll_moe_align_block_size": [P, I, L, I, I, P, P, P, P],
     "ll_moe_gemm": [P, P, P, P, P, P, P, P, L, L, I, L, L, I, I, I, I, L, L, L, L, L, L, L, I, P],
     "ll_silu_and_mul": [P, P, L, L, I, P],
+    "ll_silu_and_mul_pairs": [P, P, L, L, I, P],
     "ll_moe_sum": [P, P, L, I, L, I, P],
     "ll_moe_route_topk": [P, P, P, L, I, L, I, I, I, P],
     "ll_argmax": [P, P, L, L, L, I, P],

@@ -339,6 +339,8 @@ extern "C" int ll_skip_rmsnorm_slots(void* y, const void* slots, int k_count, vo
 
 // MODE 0: c[row, col] = silu(a[row, col]) * b[row, col]
 // MODE 1: c[row, col] = silu(x[row, col]) * x[row, n + col]   (x has 2n columns)
+// MODE 2: c[row, col] = silu(x[row, 2 col]) * x[row, 2 col + 1]  (x has 2n columns: the output of a fused gate|up projection
+//         whose rows were interleaved (gate_j, up_j) at load time, called with more rows than the fused launch serves)
 template <int DT, int VEC, int MODE>
 __global__ __launch_bounds__(256) void swiglu_kernel(uint16_t* __restrict__ c,
                                                      const uint16_t* __restrict__ a,
@@ -352,9 +354,23 @@ __global__ __launch_bounds__(256) void swiglu_kernel(uint16_t* __restrict__ c,
     if constexpr (MODE == 0) {
       VecIO<VEC>::load(a + row * n + col, av);
       VecIO<VEC>::load(b + row * n + col, bv);
-    } else {
+    } else if constexpr (MODE == 1) {
       VecIO<VEC>::load(a + row * 2 * n + col, av);
       VecIO<VEC>::load(a + row * 2 * n + n + col, bv);
+    } else {
+      uint16_t lo[VEC], hi[VEC];  // 2 VEC consecutive values = VEC (gate, up) pairs
+      VecIO<VEC>::load(a + row * 2 * n + 2 * col, lo);
+      if constexpr (VEC > 1) {
+        VecIO<VEC>::load(a + row * 2 * n + 2 * col + VEC, hi);
+#pragma unroll
+        for (int j = 0; j < VEC / 2; ++j) {
+          av[j] = lo[2 * j]; bv[j] = lo[2 * j + 1];
+          av[VEC / 2 + j] = hi[2 * j]; bv[VEC / 2 + j] = hi[2 * j + 1];
+        }
+      } else {
+        av[0] = lo[0];
+        bv[0] = a[row * 2 * n + 2 * col + 1];
+      }
     }
 #pragma unroll
     for (int j = 0; j < VEC; ++j) {
@@ -372,7 +388,7 @@ static int launch_swiglu(void* c, const void* a, const void* b, int64_t rows, in
   if (rows < 0 || n <= 0) return LL_ERR_SHAPE;
   if (rows == 0) return LL_OK;
   hipStream_t st = (hipStream_t)stream;
-  const bool vec = (n % 8 == 0) && ll_aligned16(c) && ll_aligned16(a) && (MODE == 1 || ll_aligned16(b));
+  const bool vec = (n % 8 == 0) && ll_aligned16(c) && ll_aligned16(a) && (MODE != 0 || ll_aligned16(b));
   const int64_t total = rows * (vec ? n / 8 : n);
   const unsigned grid = (unsigned)((total + 255) / 256 > 4096 ? 4096 : (total + 255) / 256);
   auto cc = (uint16_t*)c;
@@ -395,6 +411,9 @@ extern "C" int ll_swiglu(void* c, const void* a, const void* b, int64_t rows, in
 extern "C" int ll_silu_and_mul(void* out, const void* x, int64_t rows, int64_t n, int dtype,
                                void* stream) {
   return launch_swiglu<1>(out, x, nullptr, rows, n, dtype, stream);
+}
+extern "C" int ll_silu_and_mul_pairs(void* out, const void* x, int64_t rows, int64_t n, int dtype, void* stream) {
+  return launch_swiglu<2>(out, x, nullptr, rows, n, dtype, stream);
 }
 
 // --------------------------------------------------------------------------- //

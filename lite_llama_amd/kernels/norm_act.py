@@ -248,6 +248,16 @@ def swiglu_forward(a, b):
         L.check(L.lib().ll_silu_and_mul(c.data_ptr(), a.data_ptr(), rows, n_cols, L.dtype_code(a.dtype),
                                         L.stream_ptr()), "swiglu_forward")
         return c
+    if (a.dim() >= 2 and a.dtype == b.dtype and a.shape == b.shape and a.stride() == b.stride() and a.stride(-1) == 2
+            and b.data_ptr() == a.data_ptr() + a.element_size() and a.stride(-2) == 2 * n_cols
+            and all(a.stride(i) == a.stride(i + 1) * a.shape[i + 1] for i in range(a.dim() - 2)) and a.data_ptr() % 16 == 0):
+        # a / b are the even / odd columns of one row-major [rows, 2n] buffer: a fused gate|up projection over row-interleaved
+        # weights called with more rows than its fused launch serves (prefill) -- read the pairs in place
+        rows = a.numel() // n_cols
+        c = torch.empty(ori_shape, dtype=a.dtype, device=a.device)
+        L.check(L.lib().ll_silu_and_mul_pairs(c.data_ptr(), a.data_ptr(), rows, n_cols, L.dtype_code(a.dtype), L.stream_ptr()),
+                "swiglu_forward")
+        return c
     a2 = a.reshape(-1, n_cols)
     b2 = b.reshape(-1, n_cols)
     if not a2.is_contiguous():

@@ -489,6 +489,40 @@ def dense16_wins(m: int, n: int, k: int) -> bool:
     return m <= 32 and (k >= 4096 or n >= 32768)
 
 
+def dense16_rows_wins(m: int, n: int, k: int) -> bool:
+    """Where the 16-bit row-group kernel measured faster than the library GEMM and than the split-K 16-bit engine on MI355X
+    (benchmarks/dense16_rows.py, round 5, hipGraph replays over rotating weights, us per launch rows / library / split-K):
+    fused gate|up 17920 x 1536 at batch 32 incl. the swiglu 13.4 / 25.2 / 30.9; lm_head 151936 x 1536 at batch 32 80.6 / 106.4 /
+    96.9 (5.8 TB/s); lm_head 152064 x 3584 at batch 64 204.8 / 210.9 / 226.8; gate|up 37888 x 3584 fp16 at batch 64 55.7 / 76.0 /
+    85.3.  It needs about one 32-row group per CU to fill the chip: narrow outputs (down 1536 x 8960: 35.8 / 21.8 / 20.7) keep the
+    split-K engine or the library."""
+    return 1 <= m <= 64 and n >= 8192 and n % 32 == 0 and k % 128 == 0
+
+
+def dense16_rows_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None, *, gate_up_swiglu: bool = False):
+    """Extension (round 5): ``F.linear(x, weight, bias)`` -- or, with ``gate_up_swiglu``, ``silu(gate) * up`` of a fused gate|up
+    weight whose rows are interleaved ``(gate_j, up_j)`` -- for decode shapes (<= 64 rows) of an UNQUANTISED fp16 / bf16 weight
+    on the row-group weight-streaming kernel (csrc/gemm_w16_rows.hip): finished outputs in one launch, no planes.  ``None`` when
+    the call is not served (shape / dtype / alignment, ``LL_DENSE16_ROWS_OFF``): the caller keeps its route."""
+    if (not x.is_cuda or x.dtype not in (torch.float16, torch.bfloat16) or weight.dtype != x.dtype or weight.dim() != 2
+            or os.environ.get("LL_DENSE16_ROWS_OFF")):
+        return None
+    n, k = weight.shape
+    if x.shape[-1] != k or (bias is not None and (bias.dtype != x.dtype or bias.numel() != n or gate_up_swiglu)):
+        return None
+    a = _flatten(x, k)
+    m = a.shape[0]
+    if (not L.lib().ll_dense16_rows_supported(m, n, k, 1 if gate_up_swiglu else 0) or weight.stride(1) != 1 or weight.stride(0) % 8
+            or weight.data_ptr() % 16 or (m - 1) * a.stride(0) * 2 + k * 2 >= 2 ** 31):
+        return None
+    n_out = n // 2 if gate_up_swiglu else n
+    out = torch.empty((m, n_out), dtype=x.dtype, device=x.device)
+    L.check(L.lib().ll_dense16_rows_matmul(out.data_ptr(), a.data_ptr(), weight.data_ptr(), L.ptr(bias), m, n, k, a.stride(0),
+                                           weight.stride(0), L.dtype_code(x.dtype), 1 if gate_up_swiglu else 0, L.stream_ptr()),
+            "dense16_rows_linear")
+    return out.reshape(*x.shape[:-1], n_out)
+
+
 def dense16_linear(x: torch.Tensor, weight: torch.Tensor, bias: torch.Tensor | None = None, policy: str = "always"):
     """Extension: ``F.linear(x, weight, bias)`` for decode shapes (<= 64 rows) of an UNQUANTISED fp16 / bf16 weight
     ``[N, K]`` on the split-K weight-streaming kernel (csrc/gemm_w8_skinny.hip, 16-bit form) -- the reference's

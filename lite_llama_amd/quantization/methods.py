@@ -16,7 +16,7 @@ import torch.nn.functional as F
 
 from ..kernels import fused_moe, smoothquant_matmul, w4a16_matmul, w8a16_matmul
 from ..kernels.quantization import smoothquant_gate_up_swiglu, smoothquant_matmul_partials
-from ..kernels.quantization import (dense16_linear, dense_matmul_partials, pack_w4a16_scales, pack_w4a16_weights, unpack_w4a16_weights, w4a16_matmul_partials,
+from ..kernels.quantization import (dense16_linear, dense16_rows_linear, dense16_rows_wins, dense_matmul_partials, pack_w4a16_scales, pack_w4a16_weights, unpack_w4a16_weights, w4a16_matmul_partials,
                                     w4a16_matmul_prepacked_rows, w4a16_mtiled_supported,
                                     w4a16_matmul_prepacked, w4a16_prepacked_supported)
 from .config import FP8, INT4, INT8, SMOOTHQUANT, QuantConfig
@@ -62,8 +62,22 @@ class UnquantizedLinearMethod(LinearQuantMethod):
         layer.weight = nn.Parameter(torch.empty(output_size, input_size, dtype=torch.float16), requires_grad=False)
 
     def apply(self, layer, x):
+        m = x.numel() // x.shape[-1] if x.shape[-1] else 0
+        if dense16_rows_wins(m, layer.weight.shape[0], layer.weight.shape[1]):  # wide outputs: the row-group loop (round 5)
+            out = dense16_rows_linear(x, layer.weight, layer.bias)
+            if out is not None:
+                return out
         out = dense16_linear(x, layer.weight, layer.bias, policy="auto")  # decode shapes where the own kernel measured faster
         return out if out is not None else F.linear(x, layer.weight, layer.bias)
+
+    def apply_gate_up_swiglu(self, layer, x):
+        """``layer`` holds gate / up row-interleaved (linear.py::MergedColumnLinear): projection + ``silu(gate) * up`` as ONE launch
+        of the 16-bit row-group kernel for decode shapes; ``None`` -> the caller runs the merged GEMM + ``swiglu_forward`` (which
+        reads the interleaved pairs in place)."""
+        m = x.numel() // x.shape[-1] if x.shape[-1] else 0
+        if layer.bias is not None or not dense16_rows_wins(m, layer.weight.shape[0], layer.weight.shape[1]):
+            return None
+        return dense16_rows_linear(x, layer.weight, gate_up_swiglu=True)
 
     def apply_partials(self, layer, x, allow_bias: bool = False, max_splits: int = 12):
         """Decode-shaped projection left as fp32 split-K partials for its consumer (round 4, as the int4 method's): ``None``

@@ -375,3 +375,64 @@ def test_moe_model_with_interleaved_gate_up_equals_the_stacked_layout():
     after = m.state_dict()  # expands first
     assert not m.is_compacted() and all(torch.equal(after[k], before[k]) for k in before)
     assert torch.equal(run(), stacked)
+
+
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+def test_unquantised_wide_mlp_and_lm_head_take_the_row_group_kernel(dtype, monkeypatch):
+    """BASELINE config 2's route (round 5): an unquantised model whose fused gate|up and lm_head are wide enough runs them on
+    the in-tree 16-bit row-group kernel -- gate|up + swiglu as ONE launch over row-interleaved weights, no library GEMM on the
+    step -- and still matches the oracle; prefill (more rows than the kernel serves) reads the interleaved pairs in place."""
+    import types
+    from lite_llama_amd.model import CausalLM, tiny_geometry
+    from oracle.model import OracleModel
+    import lite_llama_amd.quantization.methods as QM
+    import lite_llama_amd.kernels.quantization as KQ
+    import lite_llama_amd.model as M
+
+    H, I, L, HQ, HKV, D, V = 256, 4096, 1, 2, 2, 128, 8192
+    B, CTX = 4, 140
+    g = torch.Generator().manual_seed(11)
+    geo = tiny_geometry(hidden_size=H, intermediate_size=I, num_layers=L, num_heads=HQ, num_kv_heads=HKV, head_dim=D, vocab_size=V,
+                        qkv_bias=True)
+    m = CausalLM(geo)
+    params = {k: ((1 + 0.1 * torch.randn(v.shape, generator=g)) if k.endswith("norm_weight") else 0.03 * torch.randn(v.shape, generator=g)).half()
+              for k, v in m.state_dict().items()}
+    m.load_state_dict(params, strict=True)
+    m = m.to("cuda").to(dtype)
+    calls = {"rows": 0, "swiglu": 0}
+    real = KQ.dense16_rows_linear
+
+    def rows(x, w, bias=None, *, gate_up_swiglu=False):
+        out = real(x, w, bias, gate_up_swiglu=gate_up_swiglu)
+        calls["rows"] += int(out is not None)
+        calls["swiglu"] += int(out is not None and gate_up_swiglu)
+        return out
+
+    monkeypatch.setattr(QM, "dense16_rows_linear", rows)
+    monkeypatch.setattr(KQ, "dense16_rows_linear", rows)
+    m.rotary_emb.ensure(CTX + 8, "cuda", dtype)
+    rows_total = B * (CTX + 1)
+    kv_cpu = [(torch.randn(rows_total, 2 * HKV, D, generator=g) * 0.5).half() for _ in range(L)]
+    table = torch.arange(rows_total, dtype=torch.int32).view(B, CTX + 1)
+    ids = torch.randint(0, V, (B, 1), generator=g)
+    pos = torch.full((B, 1), CTX)
+
+    def info_on(dev, kv):
+        return types.SimpleNamespace(kv_buffer=kv, cur_select_index=table[:, CTX].contiguous().to(dev), b_req_tokens_table=table.clone().to(dev),
+                                     b_start_loc=None, b_req_idx=torch.arange(B, dtype=torch.int32, device=dev),
+                                     b_seq_len=torch.full((B,), CTX + 1, dtype=torch.int32, device=dev), max_actual_seq_len=CTX + 1)
+
+    with torch.no_grad():
+        got = m(ids.cuda(), pos.cuda(), info_on("cuda", [k.clone().cuda().to(dtype) for k in kv_cpu]))
+    assert calls == {"rows": 2, "swiglu": 1}, calls  # fused gate|up + swiglu, lm_head
+    om = OracleModel({k: v.clone() for k, v in params.items()}, H, I, L, HQ, HKV, D, V, eps=geo.rms_norm_eps, rope_theta=geo.rope_theta)
+    ref = om.forward(ids, pos, info_on("cpu", [k.clone() for k in kv_cpu]))
+    tol = 6e-2 if dtype == torch.bfloat16 else 3e-2
+    torch.testing.assert_close(got.float().cpu(), ref.float(), rtol=tol, atol=tol)
+    # prefill-shaped call of the same block: more rows than the kernel serves -> merged GEMM + in-place pair swiglu
+    xp = (torch.randn(96, H, generator=g) * 0.5).to(dtype).cuda()
+    mlp = m.layers[0].mlp
+    with torch.no_grad():
+        many = mlp(xp.view(1, 96, H)).view(96, H)
+        few = torch.cat([mlp(xp[i: i + 32].view(1, 32, H)).view(32, H) for i in range(0, 96, 32)])
+    torch.testing.assert_close(many.float(), few.float(), rtol=2e-2, atol=2e-2)

@@ -1331,3 +1331,41 @@ def test_dense_partials_sum_to_the_finished_projection(fmt, M, N, K_, cap):
     assert dense_matmul_partials(torch.zeros(65, K_, dtype=dt, device=DEV), w if fmt in ("f16", "bf16") else qw,
                                  None if fmt in ("f16", "bf16") else sc, group_n=1 if fmt in ("f16", "bf16") else gn,
                                  group_k=0 if fmt in ("f16", "bf16") else gk) is None
+
+
+# ------------------------------------------------------------------------------------- #
+# round 5: 16-bit row-group weight-streaming kernel (csrc/gemm_w16_rows.hip)
+# ------------------------------------------------------------------------------------- #
+@pytest.mark.parametrize("dtype", [torch.float16, torch.bfloat16])
+@pytest.mark.parametrize("m,n,k", [(1, 8192, 128), (32, 17920, 1536), (33, 8224, 384), (64, 9600, 256), (17, 32, 128)])
+def test_dense16_rows_kernel_matches_fp32_reference(dtype, m, n, k):
+    """F.linear for decode shapes on the row-group loop: plain, with bias, and the fused swiglu of row-interleaved gate|up --
+    against an fp32 product (2 ulp-scale tolerances of the storage type) and, for the swiglu, bit for bit against the plain launch
+    followed by ``swiglu_forward`` on the interleaved pairs (which itself must equal the two-tensor form)."""
+    from lite_llama_amd.kernels.quantization import dense16_rows_linear
+    g = torch.Generator().manual_seed(m * 7 + n + k)
+    w = (torch.randn(n, k, generator=g) * 0.05).to(dtype)
+    x = (torch.randn(m, k, generator=g) * 0.5).to(dtype)
+    bias = (torch.randn(n, generator=g) * 0.1).to(dtype)
+    tol = 2e-2 if dtype == torch.bfloat16 else 4e-3
+    ref = x.float() @ w.float().T
+    xd, wd = x.to(DEV), w.to(DEV)
+    y = dense16_rows_linear(xd, wd)
+    assert y is not None and y.shape == (m, n) and y.dtype == dtype
+    torch.testing.assert_close(y.float().cpu(), ref, rtol=tol, atol=tol * ref.abs().max().item())
+    yb = dense16_rows_linear(xd, wd, bias.to(DEV))
+    torch.testing.assert_close(yb.float().cpu(), ref + bias.float(), rtol=tol, atol=tol * ref.abs().max().item())
+    sw = dense16_rows_linear(xd, wd, gate_up_swiglu=True)
+    pairs = K().swiglu_forward(y[:, 0::2], y[:, 1::2])           # reads the interleaved pairs in place
+    halves = K().swiglu_forward(y[:, 0::2].contiguous(), y[:, 1::2].contiguous())
+    assert torch.equal(pairs, halves) and torch.equal(sw, pairs)
+    assert torch.equal(y, dense16_rows_linear(xd, wd))           # deterministic
+    # a strided activation view and a weight view with a row stride
+    wide = torch.zeros(m, k + 8, dtype=dtype, device=DEV)
+    wide[:, :k] = xd
+    assert torch.equal(dense16_rows_linear(wide[:, :k], wd), y)
+    wbig = torch.zeros(n, k + 16, dtype=dtype, device=DEV)
+    wbig[:, :k] = wd
+    assert torch.equal(dense16_rows_linear(xd, wbig[:, :k]), y)
+    assert dense16_rows_linear(torch.zeros(65, k, dtype=dtype, device=DEV), wd) is None
+    assert dense16_rows_linear(xd[:, : k - 8], wd[:, : k - 8]) is None
