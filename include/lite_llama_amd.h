@@ -310,6 +310,14 @@ int ll_dense16_matmul(void* out, const void* x, const void* w, const void* bias,
 int ll_dense16_rows_supported(int64_t m, int64_t n, int64_t k, int epilogue); /* 1 / 0 */
 int ll_dense16_rows_matmul(void* out, const void* x, const void* w, const void* bias, int64_t m, int64_t n, int64_t k,
                            int64_t x_stride_m, int64_t w_stride_n, int dtype, int epilogue, void* stream);
+/* The same loop for a SmoothQuant (W8A8) projection whose rows arrive already quantised: exact int32 sums on mfma_i32_32x32x32_i8,
+ * then ll_w8a8_matmul's epilogue fp16(((float)sum * a_scale[m]) * w_scale[n] (+ bias)) (kernels/quantization/w8a8.py:118-149);
+ * epilogue 1: rows of qw interleaved (gate_j, up_j) -> out [m][n / 2] = silu(gate) * up (= ll_w8a8_finish_swiglu).  One launch,
+ * no planes.  m <= 64, n % 32 == 0, k % 256 == 0, byte strides % 16 == 0. */
+int ll_w8a8_rows_supported(int64_t m, int64_t n, int64_t k, int epilogue); /* 1 / 0 */
+int ll_w8a8_rows_matmul(void* out, const int8_t* qa, const float* a_scale, const int8_t* qw, const float* w_scale,
+                        const void* bias, int64_t m, int64_t n, int64_t k, int64_t qa_stride_m, int64_t qw_stride_n,
+                        int epilogue, void* stream);
 
 /* ---- a11: fused_moe pieces  (kernels/fused_moe.py:45-99, :236-292, :298-335) ---
  * moe_align_block_size: sorted_ids int32[num_slots + E*(block-1)] (sentinel =

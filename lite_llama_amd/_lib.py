@@ -56,6 +56,8 @@ SIGNATURES = {
     "ll_w8a16_matmul": [P, P, P, P, P, L, L, L, I, L, I, L, L, L, L, P, P, P],
     "ll_quantize_activations_int8": [P, P, P, L, L, L, P],
     "ll_dense16_matmul": [P, P, P, P, L, L, L, L, L, I, P, P],
+    "ll_w8a8_rows_supported": [L, L, L, I],
+    "ll_w8a8_rows_matmul": [P, P, P, P, P, P, L, L, L, L, L, I, P],
     "ll_dense16_rows_supported": [L, L, L, I],
     "ll_dense16_rows_matmul": [P, P, P, P, L, L, L, L, L, I, I, P],
     "ll_dense_partials_count": [L, L, L, I, I],

@@ -38,7 +38,10 @@ struct R16Params {
   int chunks;        // K / 128
   int rbase, rrem;   // workgroup b owns row groups [b * rbase + min(b, rrem), + rbase + (b < rrem))
   int epi;           // 0: out[m, n] (+ bias);  1: rows are (gate_j, up_j) pairs -> out[m, n / 2] = silu(gate) * up
+  const float* a_scale;  // R16_I8 only: per-token activation scales [m], per-channel weight scales [n] (smoothquant, w8a8.py:118-149)
+  const float* w_scale;
 };
+#define R16_I8 2  // DT code of the int8 x int8 form: x / w are int8 rows of 256 k per chunk, out is fp16
 
 template <int N>
 __device__ __forceinline__ void r16_wait_units(int k) {  // at most k units of N operations each may still be in flight
@@ -116,11 +119,13 @@ __global__ __launch_bounds__(R16_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
   // ======================================= consumers ======================================= //
   const int nl = lane & 31, h = lane >> 5;
   const int wrow = wv * 8192 + nl * 256;  // this wave's row group of the tile, weight row nl
+  constexpr int ODT = DT == R16_I8 ? LL_F16 : DT;  // output / bias storage type
   f32x16 acc[MT];
+  i32x16 iacc[MT];
 #pragma unroll
   for (int mt = 0; mt < MT; ++mt)
 #pragma unroll
-    for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
+    for (int e = 0; e < 16; ++e) { acc[mt][e] = 0.f; iacc[mt][e] = 0; }
   auto swap32 = [](uint32_t& a, uint32_t& bb) {
     const auto r = __builtin_amdgcn_permlane32_swap(a, bb, false, false);
     a = r[0];
@@ -145,8 +150,10 @@ __global__ __launch_bounds__(R16_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
           const u32x4 xf = *reinterpret_cast<const u32x4*>(xb + mt * 8192 + off);
           if constexpr (DT == LL_F16)
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, wf), __builtin_bit_cast(f16x8, xf), acc[mt], 0, 0, 0);
-          else
+          else if constexpr (DT == LL_BF16)
             acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(r16_bf16x8, wf), __builtin_bit_cast(r16_bf16x8, xf), acc[mt], 0, 0, 0);
+          else  // 16 int8 per lane and k-step of 32: the same 16-byte slots, exact int32 sums
+            iacc[mt] = __builtin_amdgcn_mfma_i32_32x32x32_i8(__builtin_bit_cast(i32x4, wf), __builtin_bit_cast(i32x4, xf), iacc[mt], 0, 0, 0);
         }
       }
     }
@@ -162,16 +169,32 @@ __global__ __launch_bounds__(R16_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
           const int64_t mrow = nl + mt * 32;
           const bool row_ok = mrow < p.m;
           float v[16];
+          if constexpr (DT == R16_I8) {
+            // (acc.f32 * a_scale[m]) * w_scale[n], each product rounded to fp32 before the next (w8a8.py:118-120): pinned so that
+            // the narrowing conversion below cannot be fused into it (common.h::ll_silu_mul_f32 has the story)
+            const float as = p.a_scale[row_ok ? mrow : 0];
 #pragma unroll
-          for (int e = 0; e < 16; ++e) v[e] = acc[mt][e];
+            for (int g = 0; g < 4; ++g) {
+              const f32x4 ws = *reinterpret_cast<const f32x4*>(p.w_scale + ncol + 8 * g + 4 * h);
+#pragma unroll
+              for (int e = 0; e < 4; ++e) {
+                float f = ((float)iacc[mt][4 * g + e] * as) * ws[e];
+                asm volatile("" : "+v"(f));
+                v[4 * g + e] = f;
+              }
+            }
+          } else {
+#pragma unroll
+            for (int e = 0; e < 16; ++e) v[e] = acc[mt][e];
+          }
           if (has_bias) {
 #pragma unroll
             for (int g = 0; g < 4; ++g) {
               const uint2 bb = *reinterpret_cast<const uint2*>(p.bias + ncol + 8 * g + 4 * h);
-              v[4 * g + 0] += to_f32<DT>((uint16_t)(bb.x & 0xffffu));
-              v[4 * g + 1] += to_f32<DT>((uint16_t)(bb.x >> 16));
-              v[4 * g + 2] += to_f32<DT>((uint16_t)(bb.y & 0xffffu));
-              v[4 * g + 3] += to_f32<DT>((uint16_t)(bb.y >> 16));
+              v[4 * g + 0] += to_f32<ODT>((uint16_t)(bb.x & 0xffffu));
+              v[4 * g + 1] += to_f32<ODT>((uint16_t)(bb.x >> 16));
+              v[4 * g + 2] += to_f32<ODT>((uint16_t)(bb.y & 0xffffu));
+              v[4 * g + 3] += to_f32<ODT>((uint16_t)(bb.y >> 16));
             }
           }
           uint32_t lo2[4], hi2[4], sw[4];
@@ -179,12 +202,16 @@ __global__ __launch_bounds__(R16_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
           for (int g = 0; g < 4; ++g) {
             uint16_t o[4];
 #pragma unroll
-            for (int e = 0; e < 4; ++e) o[e] = from_f32<DT>(v[4 * g + e]);
+            for (int e = 0; e < 4; ++e) {
+              float f = v[4 * g + e];
+              asm volatile("" : "+v"(f));
+              o[e] = from_f32<ODT>(f);
+            }
             lo2[g] = (uint32_t)o[0] | ((uint32_t)o[1] << 16);
             hi2[g] = (uint32_t)o[2] | ((uint32_t)o[3] << 16);
             if (p.epi)  // both outputs rounded to the storage dtype, then silu(g) * u in fp32: swiglu_forward's arithmetic
-              sw[g] = (uint32_t)from_f32<DT>(ll_silu_mul_f32(to_f32<DT>(o[0]), to_f32<DT>(o[1]))) |
-                      ((uint32_t)from_f32<DT>(ll_silu_mul_f32(to_f32<DT>(o[2]), to_f32<DT>(o[3]))) << 16);
+              sw[g] = (uint32_t)from_f32<ODT>(ll_silu_mul_f32(to_f32<ODT>(o[0]), to_f32<ODT>(o[1]))) |
+                      ((uint32_t)from_f32<ODT>(ll_silu_mul_f32(to_f32<ODT>(o[2]), to_f32<ODT>(o[3]))) << 16);
           }
           const int64_t nn = ncol + 16 * h;
           if (p.epi) {
@@ -202,7 +229,7 @@ __global__ __launch_bounds__(R16_THREADS) __attribute__((amdgpu_waves_per_eu(2, 
             }
           }
 #pragma unroll
-          for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
+          for (int e = 0; e < 16; ++e) { acc[mt][e] = 0.f; iacc[mt][e] = 0; }
         }
       }
       ++t;
@@ -262,5 +289,49 @@ extern "C" int ll_dense16_rows_matmul(void* out, const void* x, const void* w, c
     if (dtype == LL_F16) R16_GO(2, LL_F16) else R16_GO(2, LL_BF16)
   }
 #undef R16_GO
+  return LL_LAUNCH_CHECK();
+}
+
+// smoothquant (W8A8) form: out [m][n] fp16 (epilogue 0, + bias) or [m][n / 2] (epilogue 1: rows of qw interleaved (gate_j, up_j)) =
+// fp16(((float)(qa [m][k] int8 @ qw [n][k]^T int32) * a_scale[m]) * w_scale[n] (+ bias)) -- ll_w8a8_matmul's epilogue
+// (kernels/quantization/w8a8.py:118-149), exact int32 sums on mfma_i32_32x32x32_i8; then silu(gate) * up on the rounded outputs
+// (= ll_w8a8_finish_swiglu).  m <= 64, n % 32 == 0, k % 256 == 0, row strides (bytes) % 16 == 0.
+extern "C" int ll_w8a8_rows_supported(int64_t m, int64_t n, int64_t k, int epilogue) {
+  return (m >= 1 && m <= 64 && n >= 32 && n % 32 == 0 && k >= 256 && k % 256 == 0 && (epilogue == 0 || epilogue == 1)) ? 1 : 0;
+}
+
+extern "C" int ll_w8a8_rows_matmul(void* out, const int8_t* qa, const float* a_scale, const int8_t* qw, const float* w_scale,
+                                   const void* bias, int64_t m, int64_t n, int64_t k, int64_t qa_stride_m, int64_t qw_stride_n,
+                                   int epilogue, void* stream) {
+  if (m < 0 || n <= 0 || k <= 0) return LL_ERR_SHAPE;
+  if (m == 0) return LL_OK;
+  if (!ll_w8a8_rows_supported(m, n, k, epilogue) || qa_stride_m % 16 != 0 || qw_stride_n % 16 != 0) return LL_ERR_SHAPE;
+  if (!out || !qa || !qw || !a_scale || !w_scale || !ll_aligned16(out) || !ll_aligned16(qa) || !ll_aligned16(qw) || !ll_aligned16(w_scale) ||
+      (bias && ((uintptr_t)bias & 7)))
+    return LL_ERR_ARG;
+  if ((m - 1) * qa_stride_m + k >= (1ll << 31) || 32 * qw_stride_n >= (1ll << 31)) return LL_ERR_SHAPE;
+  R16Params p{};
+  p.out = (uint16_t*)out; p.x = (const uint16_t*)qa; p.w = (const uint16_t*)qw; p.bias = (const uint16_t*)bias;
+  p.a_scale = a_scale; p.w_scale = w_scale;
+  p.m = m; p.n = n; p.k = k;
+  p.x_stride = qa_stride_m / 2; p.w_stride = qw_stride_n / 2;  // the kernel addresses rows in 2-byte units
+  p.chunks = (int)(k / 256);                                    // 256 bytes of a row per chunk
+  p.epi = epilogue;
+  const int64_t rgs = n / 32;
+  int grid = r16_num_cus();
+  if (grid > rgs) grid = (int)rgs;
+  p.rbase = (int)(rgs / grid); p.rrem = (int)(rgs % grid);
+  hipStream_t st = (hipStream_t)stream;
+#define R16_GO8(MT)                                                                                                      \
+  {                                                                                                                      \
+    static bool attr_ = false;                                                                                           \
+    if (!attr_) {                                                                                                        \
+      (void)hipFuncSetAttribute((const void*)wgemm16_rows_kernel<MT, R16_I8>, hipFuncAttributeMaxDynamicSharedMemorySize, R16Lds<MT>::BYTES); \
+      attr_ = true;                                                                                                      \
+    }                                                                                                                    \
+    wgemm16_rows_kernel<MT, R16_I8><<<dim3((unsigned)grid), R16_THREADS, R16Lds<MT>::BYTES, st>>>(p);                      \
+  }
+  if (m <= 32) R16_GO8(1) else R16_GO8(2)
+#undef R16_GO8
   return LL_LAUNCH_CHECK();
 }

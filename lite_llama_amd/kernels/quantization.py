@@ -435,6 +435,43 @@ def smoothquant_gate_up_swiglu(x, qweight, weight_scales, *, max_splits: int = 1
     return out.view(*x.shape[:-1], n // 2)
 
 
+def smoothquant_rows_matmul(x, qweight, weight_scales, *, bias=None, gate_up_swiglu: bool = False):
+    """Extension (round 5): :func:`smoothquant_matmul` -- or, with ``gate_up_swiglu``, ``silu(gate) * up`` of a fused gate|up
+    projection whose rows are interleaved ``(gate_j, up_j)`` -- for decode shapes with a WIDE output on the row-group loop
+    (csrc/gemm_w16_rows.hip, int8 form): ONE launch, exact int32 sums, the reference's scale epilogue, no planes and no finish
+    launch.  ``x``: fp16 rows or ``Int8Rows``.  Same values as ``smoothquant_matmul`` (+ ``swiglu_forward``) bit for bit.
+    ``None`` when not served (more than 64 rows, n < 8192, k % 256, ``LL_W8A8_ROWS_OFF``)."""
+    from .norm_act import Int8Rows
+    n, k = qweight.shape
+    if (qweight.dtype != torch.int8 or qweight.stride(1) != 1 or x.shape[-1] != k or os.environ.get("LL_W8A8_ROWS_OFF")
+            or n < 8192 or (gate_up_swiglu and bias is not None)):
+        return None
+    if isinstance(x, Int8Rows):
+        qa, a_scale = x.q, x.scale
+    else:
+        if not x.is_cuda or x.dtype != torch.float16:
+            return None
+        a = x.reshape(-1, k)
+        if a.shape[0] < 1 or a.shape[0] > 64:
+            return None
+        if a.stride(-1) != 1:
+            a = a.contiguous()
+        qa, a_scale = quantize_activations_int8(a)
+    m = qa.shape[0]
+    if (not L.lib().ll_w8a8_rows_supported(m, n, k, 1 if gate_up_swiglu else 0) or qa.stride(0) % 16 or qweight.stride(0) % 16
+            or qa.data_ptr() % 16 or qweight.data_ptr() % 16):
+        return None
+    ws = _w8a8_scales(weight_scales)
+    if bias is not None and bias.dtype != torch.float16:
+        bias = bias.half()
+    n_out = n // 2 if gate_up_swiglu else n
+    out = torch.empty((m, n_out), dtype=torch.float16, device=qa.device)
+    L.check(L.lib().ll_w8a8_rows_matmul(out.data_ptr(), qa.data_ptr(), a_scale.data_ptr(), qweight.data_ptr(), ws.data_ptr(), L.ptr(bias),
+                                        m, n, k, qa.stride(0), qweight.stride(0), 1 if gate_up_swiglu else 0, L.stream_ptr()),
+            "smoothquant_rows_matmul")
+    return out.view(*x.shape[:-1], n_out)
+
+
 def dense_matmul_partials(x: torch.Tensor, weight: torch.Tensor, scales: torch.Tensor | None = None, *, group_n: int = 1,
                           group_k: int = 0, max_splits: int = 12):
     """Decode-step extension for the 8-bit and the unquantised 16-bit formats (the int4 route's

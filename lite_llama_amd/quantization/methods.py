@@ -15,7 +15,7 @@ import torch.nn as nn
 import torch.nn.functional as F
 
 from ..kernels import fused_moe, smoothquant_matmul, w4a16_matmul, w8a16_matmul
-from ..kernels.quantization import smoothquant_gate_up_swiglu, smoothquant_matmul_partials
+from ..kernels.quantization import smoothquant_gate_up_swiglu, smoothquant_matmul_partials, smoothquant_rows_matmul
 from ..kernels.quantization import (dense16_linear, dense16_rows_linear, dense16_rows_wins, dense_matmul_partials, pack_w4a16_scales, pack_w4a16_weights, unpack_w4a16_weights, w4a16_matmul_partials,
                                     w4a16_matmul_prepacked_rows, w4a16_mtiled_supported,
                                     w4a16_matmul_prepacked, w4a16_prepacked_supported)
@@ -336,7 +336,8 @@ class SmoothQuantLinearMethod(LinearQuantMethod):
         """``layer`` holds gate/up row-interleaved: the int8 GEMM + ONE launch for the scale epilogue and the activation."""
         if layer.bias is not None:
             return None
-        return smoothquant_gate_up_swiglu(x, layer.weight, layer.weight_scale_inv)
+        out = smoothquant_rows_matmul(x, layer.weight, layer.weight_scale_inv, gate_up_swiglu=True)  # wide outputs: one launch (round 5)
+        return out if out is not None else smoothquant_gate_up_swiglu(x, layer.weight, layer.weight_scale_inv)
 
     def convert_from_fp16(self, layer, quant):
         qw, sc = quantize_int8_per_channel(layer.weight.data)

@@ -1369,3 +1369,30 @@ def test_dense16_rows_kernel_matches_fp32_reference(dtype, m, n, k):
     assert torch.equal(dense16_rows_linear(xd, wbig[:, :k]), y)
     assert dense16_rows_linear(torch.zeros(65, k, dtype=dtype, device=DEV), wd) is None
     assert dense16_rows_linear(xd[:, : k - 8], wd[:, : k - 8]) is None
+
+
+@pytest.mark.parametrize("m,n,k", [(32, 28672, 4096), (1, 8192, 256), (33, 8224, 512), (64, 9600, 768)])
+def test_smoothquant_rows_kernel_equals_smoothquant_matmul_bit_for_bit(m, n, k):
+    """The W8A8 form of the row-group loop: exact int32 sums + the reference's scale epilogue in ONE launch -- equal to
+    ``smoothquant_matmul`` (with and without bias, from fp16 rows and from ``Int8Rows``) and, for the fused gate|up, to
+    ``smoothquant_gate_up_swiglu`` (planes + finish-swiglu) bit for bit; against the oracle at the reference's 1e-1."""
+    from lite_llama_amd.kernels.quantization import (quantize_activations_int8, smoothquant_gate_up_swiglu, smoothquant_matmul,
+                                                     smoothquant_rows_matmul)
+    from lite_llama_amd.kernels.norm_act import Int8Rows
+    g = torch.Generator().manual_seed(m + n + k)
+    w = torch.randn(n, k, generator=g) * 0.05
+    qw, sc = O.quantize_int8_per_channel(w)
+    x = (torch.randn(m, k, generator=g) * 0.5).half()
+    bias = (torch.randn(n, generator=g) * 0.1).half()
+    xd, qd, sd = x.to(DEV), qw.to(DEV), sc.to(DEV)
+    got = smoothquant_rows_matmul(xd, qd, sd)
+    assert got is not None and torch.equal(got, smoothquant_matmul(xd, qd, sd))
+    assert torch.equal(smoothquant_rows_matmul(xd, qd, sd, bias=bias.to(DEV)), smoothquant_matmul(xd, qd, sd, bias=bias.to(DEV)))
+    q8, s8 = quantize_activations_int8(xd)
+    assert torch.equal(smoothquant_rows_matmul(Int8Rows(q8, s8, (m, k)), qd, sd), got)
+    close(got, O.smoothquant_matmul(x, qw, sc), 1e-1)
+    sw = smoothquant_rows_matmul(xd, qd, sd, gate_up_swiglu=True)
+    ref = smoothquant_gate_up_swiglu(xd, qd, sd)
+    assert ref is not None and torch.equal(sw, ref)
+    assert torch.equal(sw, K().swiglu_forward(got[:, 0::2], got[:, 1::2]))
+    assert smoothquant_rows_matmul(xd, qd[:4096], sd[:4096]) is None  # narrow outputs keep the split-K engine
