@@ -924,9 +924,13 @@ struct V3Knobs {
   int wgs = 0, lead = 4, gt_cap_div = 5, gt_cap = -1, nf = 0;
   int xcd = 8;  // split-K partial launches take a power-of-two split <= this and the XCD-aware map (LL_GEMM3_XCD=0: off)
   int fill = 85;  // ... when the launch still fills this percentage of the CUs (LL_GEMM3_FILL)
+  int short_k_xcd = 8;   // LL_GEMM3_SHORTK_XCD: the same cap for projections with a SHORT contraction (<= 32 chunks) and <= 32 tiles
+                         // (the attention output projection): fewer k-slices = fewer fp32 planes for the add-and-normalise that
+                         // follows, at a GEMM that fills fewer CUs -- A/B knob of the round-4 review's "4-plane o" 
   V3Knobs() {
     if (const char* e = getenv("LL_GEMM3_XCD")) xcd = atoi(e);
     if (const char* e = getenv("LL_GEMM3_FILL")) fill = atoi(e);
+    if (const char* e = getenv("LL_GEMM3_SHORTK_XCD")) short_k_xcd = atoi(e);
     if (const char* e = getenv("LL_GEMM3_WGS")) wgs = atoi(e);
     if (const char* e = getenv("LL_GEMM3_LEAD")) lead = atoi(e);
     if (const char* e = getenv("LL_GEMM3_GT")) gt_cap = atoi(e);
@@ -975,6 +979,8 @@ static V3Plan v3_plan(int64_t n, int64_t k, int nf_force = 0, bool partials = fa
   if (partials && kn.xcd > 0 && pl.nblocks > 0) {
     int want = target / pl.nblocks;  // (not capped by gt_cap: the XCD-aware split trades chunks per workgroup for L2 locality)
     if (want > kn.xcd) want = kn.xcd;
+    const bool short_k = pl.chunks <= 32 && pl.nblocks <= 32 && kn.short_k_xcd > 0 && kn.short_k_xcd < want;
+    if (short_k) want = kn.short_k_xcd;
     if (want > 8) want = 8;
     if (want > pl.chunks) want = pl.chunks;
     int g2 = 1, sh = 0;
@@ -983,7 +989,7 @@ static V3Plan v3_plan(int64_t n, int64_t k, int nf_force = 0, bool partials = fa
     // instead of 9), FETCH_SIZE of the 128-row launches 13.4 -> 9.6 MB on average (down 28.2 -> 19.9: the activation matrix
     // crosses the fabric once instead of once per XCD); q|k|v 4608 x 3584 would drop to 4 slices = 144 workgroups and is
     // SLOWER (9.19 -> 9.45): taken only when the launch still fills >= 85 % of the CUs.
-    if ((pl.nblocks * g2) % 8 == 0 && pl.nblocks * g2 * 100 >= target * kn.fill) {
+    if ((pl.nblocks * g2) % 8 == 0 && (short_k || pl.nblocks * g2 * 100 >= target * kn.fill)) {
       gt = g2;
       pl.xcd_shift = sh;
     }
