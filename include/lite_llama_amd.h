@@ -226,6 +226,13 @@ int ll_w4a16_prepacked_supported(int64_t m, int64_t n, int64_t k, int group_size
  * the S partial sums are added by the consumer of the projection, ll_skip_rmsnorm_partials below -- the
  * GEMM then has no cross-workgroup merge at all (bias must be NULL). */
 int ll_w4a16_partials_count(int64_t m, int64_t n, int64_t k, int group_size);
+/* ... for a launch that will be given `epilogue` (2, or 2 | 0x100 = the unit loop forced: tests / tuning -- its k-split differs from
+ * the short-stream engine's, which takes the launches of a few tens of KB per CU since round 6, gemm_short.hip). */
+int ll_w4a16_partials_count_ex(int64_t m, int64_t n, int64_t k, int group_size, int epilogue);
+/* Host-side introspection of the short-stream engine (no device work): out8 = [takes the split-K partial launch 0 / 1, grid, row
+ * groups per work item R, k-slices S (= planes), pieces per consumer wave (template bound), 64-k blocks per slice, slices with one
+ * block more, LDS bytes]. */
+int ll_w4a16_short_plan(int64_t m, int64_t n, int64_t k, int group_size, int32_t* out8);
 int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* wpacked, const void* spacked,
                               const void* bias, int64_t m, int64_t n, int64_t k, int group_size,
                               int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,

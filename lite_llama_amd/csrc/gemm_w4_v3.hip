@@ -1030,10 +1030,23 @@ extern "C" int ll_w4a16_prepacked_supported(int64_t m, int64_t n, int64_t k, int
 
 // Split-K partial mode (epilogue 2 of ll_w4a16_matmul_prepacked): number of fp32 partials [S][M][N] the launch
 // writes; 0 when the shape has too many tiles for the tile-group split (use the ordinary epilogue then).
-extern "C" int ll_w4a16_partials_count(int64_t m, int64_t n, int64_t k, int group_size) {
+static int v3_partials_count(int64_t m, int64_t n, int64_t k, int group_size) {
   if (!ll_w4a16_prepacked_supported(m, n, k, group_size)) return 0;
   const V3Plan pl = v3_plan(n, k, 1, true);
   return pl.gt >= 1 && pl.grid == pl.nblocks * pl.gt ? pl.gt : 0;
+}
+// `epilogue` = the value the launch will be given: bits 8-9 (a forced unit-loop tile width, tests / tuning) keep the launch off the
+// short-stream engine (gemm_short.hip), whose k-split differs from the unit loop's.
+extern "C" int ll_w4a16_partials_count_ex(int64_t m, int64_t n, int64_t k, int group_size, int epilogue) {
+  if (!ll_w4a16_prepacked_supported(m, n, k, group_size)) return 0;
+  if (!((epilogue >> 8) & 3)) {
+    const int s = ss_partials_slices(m, n, k, group_size);
+    if (s > 0) return s;
+  }
+  return v3_partials_count(m, n, k, group_size);
+}
+extern "C" int ll_w4a16_partials_count(int64_t m, int64_t n, int64_t k, int group_size) {
+  return ll_w4a16_partials_count_ex(m, n, k, group_size, 2);
 }
 
 // The launch plan of ll_w4a16_matmul_prepacked for (n, k, epilogue) as 16 ints -- host-side introspection for tests and
@@ -1043,7 +1056,7 @@ extern "C" int ll_w4a16_v3_plan(int64_t m, int64_t n, int64_t k, int group_size,
   if (!out16) return LL_ERR_ARG;
   if (!ll_w4a16_prepacked_supported(m, n, k, group_size)) return LL_ERR_SHAPE;
   const bool partials = (epilogue & 3) == 2;
-  if (partials && !ll_w4a16_partials_count(m, n, k, group_size)) return LL_ERR_SHAPE;
+  if (partials && !v3_partials_count(m, n, k, group_size)) return LL_ERR_SHAPE;
   const V3Plan pl = v3_plan(n, k, (epilogue >> 8) & 3, partials);
   const int v[16] = {pl.grid, pl.nf, pl.nblocks, pl.chunks, pl.slots, pl.gt, pl.gbase, pl.grem, pl.glead,
                      (partials && pl.gt >= 1 && pl.grid == pl.nblocks * pl.gt) ? pl.xcd_shift : -1, pl.upw, 0, 0,
@@ -1076,7 +1089,10 @@ static int v3_launch(void* out, const void* x, const void* wpacked, const void* 
   if (!ll_aligned16(x) || !ll_aligned16(wpacked) || !ll_aligned16(spacked)) return LL_ERR_ARG;
   if ((m - 1) * x_stride_m * 2 + k * 2 >= (1ll << 31)) return LL_ERR_SHAPE;
   const bool partials = (epilogue & 3) == 2;
-  if (partials && (bias || !ll_w4a16_partials_count(m, n, k, group_size))) return LL_ERR_SHAPE;
+  if (partials && (bias || !v3_partials_count(m, n, k, group_size))) return LL_ERR_SHAPE;
+  // round 6: split-K partial launches whose stream is a few tens of KB per CU run on the short-stream engine (gemm_short.hip)
+  if (partials && !((epilogue >> 8) & 3) && ss_partials_slices(m, n, k, group_size) > 0)
+    return ss_launch(out, x, wpacked, spacked, m, n, k, group_size, x_stride_m, stream);
   const V3Plan pl = v3_plan(n, k, (epilogue >> 8) & 3, partials);
   // round 5: the row-group engine (gemm_w4_v4.hip) takes the launch when its plan serves the shape -- same layouts, same planes
   if (v4_wants(m, n, k, group_size, epilogue))

@@ -236,12 +236,13 @@ def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 
     m = a.shape[0]
     if m < 1 or m > 64:
         return None
-    s = L.lib().ll_w4a16_partials_count(m, n, k, int(group_size))
+    epilogue = 2 | (0x100 if _unit_loop_engine else 0)
+    s = L.lib().ll_w4a16_partials_count_ex(m, n, k, int(group_size), epilogue)
     if s < 1:
         return None
     parts = torch.empty((s, m, n), dtype=torch.float32, device=x.device)
     _launch_prepacked(parts.data_ptr(), a, m, n, k, packed_weight, packed_scales, None, group_size,
-                      2 | (0x100 if _unit_loop_engine else 0), "w4a16_matmul_partials")
+                      epilogue, "w4a16_matmul_partials")
     return PartialSums(parts, (*x.shape[:-1], n), x.dtype)
 
 

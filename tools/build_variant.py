@@ -17,10 +17,11 @@ if sys.argv[1] == "--regs":
     pat = sys.argv[3] if len(sys.argv) > 3 and not sys.argv[3].startswith("-") else ""
     flags = [a for a in sys.argv[3:] if a.startswith("-")]
     with tempfile.TemporaryDirectory() as d:
-        subprocess.run([B._hipcc(), *B.FLAGS, *flags, "-save-temps=obj", "-c", os.path.join(B.CSRC, os.path.basename(src)), "-o",
-                        os.path.join(d, "k.o")], check=True, stderr=subprocess.DEVNULL)
-        asm = [f for f in os.listdir(d) if f.endswith(".s") and "amdgcn" in f][0]
-        text = open(os.path.join(d, asm)).read()
+        # device-only assembly (not -save-temps: the host pass of a -save-temps build rejects the kernarg-preload clones of gemm_short.hip)
+        asm = os.path.join(d, "k.s")
+        subprocess.run([B._hipcc(), *[f for f in B.flags_for(src) if f != "-fPIC"], *flags, "--cuda-device-only", "-S",
+                        os.path.join(B.CSRC, os.path.basename(src)), "-o", asm], check=True, stderr=subprocess.DEVNULL)
+        text = open(asm).read()
     keys = ["sgpr_count", "sgpr_spill_count", "vgpr_count", "vgpr_spill_count", "private_segment_fixed_size"]
     for blk in text.split("  - .agpr_count:")[1:]:
         nm = re.search(r"\.name:\s+(\S+)", blk)
@@ -37,7 +38,7 @@ abdir = os.path.join(B.LIBDIR, "ab")
 os.makedirs(abdir, exist_ok=True)
 base = os.path.basename(src)[:-4]
 obj = os.path.join(abdir, f"{name}_{base}.o")
-subprocess.run([B._hipcc(), *B.FLAGS, *flags, "-c", os.path.join(B.CSRC, os.path.basename(src)), "-o", obj], check=True)
+subprocess.run([B._hipcc(), *B.flags_for(src), *flags, "-c", os.path.join(B.CSRC, os.path.basename(src)), "-o", obj], check=True)
 objs = [obj] + [os.path.join(objdir, f) for f in sorted(os.listdir(objdir)) if f.endswith(".o") and f != base + ".o"]
 out = os.path.join(abdir, name + ".so")
 subprocess.run([B._hipcc(), "-shared", "-fPIC", f"--offload-arch={B.ARCH}", *objs, "-o", out], check=True)
