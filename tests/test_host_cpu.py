@@ -37,10 +37,43 @@ def test_w4a16_decode_plan_host_side():
     assert lib.ll_w4a16_prepacked_supported(64, 4608, 3584, 128) == 1
     assert lib.ll_w4a16_prepacked_supported(65, 4608, 3584, 128) == 0          # the decode engine stops at 64 rows
     assert lib.ll_w4a16_prepacked_supported(64, 4608, 3584, 96) == 0           # groups of 128 * 2^j
-    counts = {(n, k): lib.ll_w4a16_partials_count(64, n, k, 128) for n, k in [(4608, 3584), (3584, 3584), (3584, 18944)]}
+    # the unit loop's own split (epilogue 2 | 0x100 = the unit loop forced)
+    counts = {(n, k): lib.ll_w4a16_partials_count_ex(64, n, k, 128, 2 | 0x100) for n, k in [(4608, 3584), (3584, 3584), (3584, 18944)]}
     assert counts == {(4608, 3584): 5, (3584, 3584): 8, (3584, 18944): 8}, counts
     assert all(1 <= c <= 12 for c in counts.values())                         # what ll_skip_rmsnorm_partials accepts
     assert lib.ll_w4a16_partials_count(64, 37888, 3584, 128) == 1             # many tiles: one plane (= no split)
+    assert lib.ll_w4a16_partials_count(64, 3584, 18944, 128) == 8             # down: 149 KB per CU is not a short stream
+
+
+def test_w4a16_short_stream_plan_host_side():
+    """Host-side plan of the short-stream engine (csrc/gemm_short.hip, round 6; 256 CUs assumed without a device): it takes the
+    split-K partial launches whose weight stream is a few tens of KB per CU -- the headline's q|k|v and o, TP shards -- with one
+    round of workgroups, <= 8 planes (what ll_decode_attention_partials adds up), the k-slice of the activations resident in LDS;
+    ll_w4a16_partials_count reports ITS plane count for those launches."""
+    import ctypes
+    from lite_llama_amd import _lib
+
+    lib = _lib.lib()
+
+    def plan(m, n, k, g=128):
+        out = (ctypes.c_int32 * 8)()
+        assert lib.ll_w4a16_short_plan(m, n, k, g, out) == 0
+        return dict(zip(("takes", "grid", "R", "S", "P", "kb_base", "kb_rem", "lds"), out))
+
+    for m in (1, 32, 33, 64):
+        for n, k in [(4608, 3584), (3584, 3584), (2304, 3584), (3584, 1792), (3584, 2432), (5120, 2048), (2048, 4096)]:
+            p = plan(m, n, k)
+            assert p["takes"] == 1, (m, n, k, p)
+            assert lib.ll_w4a16_partials_count(m, n, k, 128) == p["S"]
+            assert 1 <= p["S"] <= 8 and p["R"] in (1, 2, 4, 8) and (n // 32) % p["R"] == 0
+            items = (n // 32 // p["R"]) * p["S"]
+            assert items <= 256 and p["grid"] == 8 * ((items + 7) // 8)       # one workgroup per CU, one round
+            assert p["kb_base"] * p["S"] + p["kb_rem"] == k // 64            # the slices tile K in 64-k blocks
+            blocks = p["kb_base"] + (1 if p["kb_rem"] else 0)
+            assert (blocks + 8 // p["R"] - 1) // (8 // p["R"]) <= p["P"]     # pieces per consumer wave fit the template bound
+            assert p["lds"] <= 160 * 1024 and p["lds"] >= (blocks // 2) * (2 if m > 32 else 1) * 32 * 256
+    assert plan(64, 3584, 18944)["takes"] == 0 and plan(64, 37888, 3584)["takes"] == 0
+    assert plan(65, 4608, 3584)["takes"] == 0 and plan(64, 4608, 3584, 96)["takes"] == 0
 
 
 def test_kernel_names_match_reference_surface():
