@@ -83,16 +83,20 @@ __device__ __forceinline__ void ss_wait_outstanding(int n) {
 }
 
 // MT: 32-row batch halves (1: M <= 32, 2: M <= 64); R: row groups per work item (8 / R k-quarters per row group);
-// P: pieces (1 KB of packed weights = 32 rows x 64 k) per consumer wave at most; EXACT: every k-slice is exactly P * (8 / R) blocks
-// starting at an even block (the headline's q|k|v and o) -- every count below is then a compile-time constant: no piece past the
-// slice, no run-time wait counts, the scalar prologue in front of the first weight request shrinks to the work-item decode.
-template <int MT, int R, int P, bool EXACT>
+// P: pieces (1 KB of packed weights = 32 rows x 64 k) per consumer wave at most; NKB > 0: every k-slice is exactly NKB 64-k blocks
+// (NKB even, so slices start on a chunk boundary: the headline's q|k|v and o) -- every count below is then a compile-time
+// constant: no run-time wait counts, pieces past the slice only in the last round, and the scalar prologue in front of the first
+// weight request shrinks to the work-item decode.  NKB = 0: slice lengths from the arguments.
+template <int MT, int R, int P, int NKB>
 __global__ __launch_bounds__(SS_THREADS) void wss_kernel(SS_ARGS) {
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   constexpr int KQ = SS_CONSUMERS / R;
+  constexpr bool EXACT = NKB > 0;
   constexpr int PH = P / 2;          // pieces per activation stage
   constexpr int XT = MT * 32 * 256;  // one chunk's activation tile: [MT * 32 rows][16 x 16 B], slot j of row r at j ^ (r & 15)
-  static_assert(P % 2 == 0 && (PH * KQ) % 2 == 0, "stage 0 ends on a chunk boundary");
+  constexpr int SNC = NKB / 2;                                              // static: chunks of a slice ...
+  constexpr int SNC0 = (PH * KQ + 1) / 2 < SNC ? (PH * KQ + 1) / 2 : SNC;   // ... of which stage 0 delivers these
+  static_assert(P % 2 == 0 && NKB % 2 == 0 && (!EXACT || (P * KQ >= NKB && (P - 1) * KQ < NKB)), "piece bound");
   const int tid = threadIdx.x, lane = tid & 63;
   const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
   SS_TL(0)
@@ -100,12 +104,12 @@ __global__ __launch_bounds__(SS_THREADS) void wss_kernel(SS_ARGS) {
   const int item = ((int)blockIdx.x & 7) * p_cap + ((int)blockIdx.x >> 3);
   if (item >= p_total) return;
   const int s = p_rb_magic ? (int)__umulhi((uint32_t)item, p_rb_magic) : item, rb = item - s * p_RB;
-  const int kb_lo = EXACT ? s * (P * KQ) : s * p_kb_base + (s < p_kb_rem ? s : p_kb_rem);
-  const int nkb = EXACT ? P * KQ : p_kb_base + (s < p_kb_rem ? 1 : 0);
+  const int kb_lo = EXACT ? s * NKB : s * p_kb_base + (s < p_kb_rem ? s : p_kb_rem);
+  const int nkb = EXACT ? NKB : p_kb_base + (s < p_kb_rem ? 1 : 0);
   const int c_lo = kb_lo >> 1;
-  const int nC = EXACT ? P * KQ / 2 : ((kb_lo + nkb + 1) >> 1) - c_lo;  // activation chunks the slice touches
+  const int nC = EXACT ? SNC : ((kb_lo + nkb + 1) >> 1) - c_lo;  // activation chunks the slice touches
   // stage 0 (barrier A) delivers the chunks of the first PH pieces of every consumer: 64-k blocks [kb_lo, kb_lo + PH * KQ)
-  int nC0 = EXACT ? PH * KQ / 2 : ((kb_lo + PH * KQ - 1) >> 1) - c_lo + 1;
+  int nC0 = EXACT ? SNC0 : ((kb_lo + PH * KQ - 1) >> 1) - c_lo + 1;
   if (!EXACT && nC0 > nC) nC0 = nC;
 
   if (wv >= SS_CONSUMERS) {
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(SS_THREADS) void wss_kernel(SS_ARGS) {
     if (!SS_ABL(1)) {
       if constexpr (EXACT) {
 #pragma unroll
-        for (int c = 0; c < P * KQ / 2; ++c)
+        for (int c = 0; c < SNC; ++c)
 #pragma unroll
           for (int j = 0; j < PPL; ++j) v3_dma16<false>((uint32_t)(c * XT + (L * PPL + j) * 1024), xb + (size_t)c * 256, voff[j]);
       } else {
@@ -135,7 +139,7 @@ __global__ __launch_bounds__(SS_THREADS) void wss_kernel(SS_ARGS) {
       }
     }
     SS_TL(1)
-    if constexpr (EXACT) v3_vmcnt<((P * KQ / 2 - PH * KQ / 2) * PPL <= 63 ? (P * KQ / 2 - PH * KQ / 2) * PPL : 0)>();  // (> 63: never launched)
+    if constexpr (EXACT) v3_vmcnt<((SNC - SNC0) * PPL <= 63 ? (SNC - SNC0) * PPL : 0)>();
     else ss_wait_outstanding((nC - nC0) * PPL);
     SS_TL(2)
     ss_barrier();  // A: chunks [0, nC0) of the slice are in LDS
@@ -160,7 +164,8 @@ __global__ __launch_bounds__(SS_THREADS) void wss_kernel(SS_ARGS) {
 #pragma unroll
     for (int i = 0; i < P; ++i) {
       const int kk = i * KQ + q;
-      const int kb = kb_lo + (EXACT || kk < nkb ? kk : 0);  // pieces past the slice re-read its first one (multiplied by zero)
+      const bool valid = (EXACT && i * KQ + KQ - 1 < NKB) || kk < nkb;  // (static for every round but the last)
+      const int kb = kb_lo + (valid ? kk : 0);  // pieces past the slice re-read its first one (multiplied by zero)
       if (SS_ABL(2)) {
         w[i] = u32x4{0x12345678u + (uint32_t)lane, 0x9abcdef0u, 0x0f1e2d3cu, 0x4b5a6978u};
         sc[i] = u32x2{0x1c001c00u, 0xa400a400u};
@@ -186,7 +191,8 @@ __global__ __launch_bounds__(SS_THREADS) void wss_kernel(SS_ARGS) {
   // fragments of a piece are read one piece ahead of its MFMAs (inside a stage); every count is static.
   auto read_x = [&](f16x8 (&a)[4][MT], int i) {
     const int kk = i * KQ + q;
-    const int kb = kb_lo + (EXACT || kk < nkb ? kk : 0);  // (a piece past the slice: finite, landed data x exact zeros)
+    const bool valid = (EXACT && i * KQ + KQ - 1 < NKB) || kk < nkb;
+    const int kb = kb_lo + (valid ? kk : 0);  // (a piece past the slice: finite, landed data x exact zeros)
     const unsigned char* xb = lds + ((kb >> 1) - c_lo) * XT;
     const int kx = (kb & 1) * 128;
 #pragma unroll
@@ -196,7 +202,7 @@ __global__ __launch_bounds__(SS_THREADS) void wss_kernel(SS_ARGS) {
   };
   auto mul = [&](const f16x8 (&a)[4][MT], int i) {
     uint32_t s0 = sc[i].x, s1 = sc[i].y;
-    if constexpr (!EXACT) {
+    if (!(EXACT && i * KQ + KQ - 1 < NKB)) {  // (compile-time false for a static slice's full rounds)
       const uint32_t keep = (i * KQ + q) < nkb ? 0xffffffffu : 0u;
       s0 &= keep;
       s1 &= keep;
@@ -359,14 +365,18 @@ static SSPlan ss_plan(int64_t m, int64_t n, int64_t k, int group_size) {
       if (pw > 8) continue;
       const int mc = ss_max_chunks(kbs, S);
       if (mc > SS_MAX_CHUNKS) continue;
-      const double w_kb = (double)R * nkb * (1.0 + 0.0625);           // pieces + scale pairs of the busiest workgroup
-      const double hbm = (double)n * (double)k * 0.5625 / 6.0e6;      // the whole stream at ~6 TB/s, us
-      const double per_cu = w_kb / 55.0;                              // what one CU pulls alone, us
-      const double x_us = (double)mc * mt * 8.0 / 130.0;
-      const double cost = (hbm > per_cu ? hbm : per_cu) + x_us + 0.12 * S + (total * 10 < cus * 7 ? 1.0 : 0.0);
+      // Measured on MI355X (benchmarks/gemm_short.py): a CU's share of the weight stream arrives at the chip's
+      // HBM rate (~27 KB / us / CU), its activation slice at ~100 KB / us, its planes leave at ~25 KB / us (the dirty bytes are
+      // written back at the kernel boundary), and every plane costs the consumer launch ~0.15 us.
+      const int slots = ((pw + 1) / 2) * 2 * KQ;                        // pieces multiplied per row group (incl. zeroed ones)
+      const double w_us = (double)R * nkb * 1.0625 / 27.0;
+      const double hbm = (double)n * (double)k * 0.5625 / 6.5e6;       // the whole stream at ~6.5 TB/s, us
+      const double x_us = (double)mc * mt * 8.0 / 100.0;
+      const double p_us = (double)R * mt * 4.0 / 25.0;
+      const double cost = (hbm > w_us ? hbm : w_us) + x_us + p_us + 0.15 * S + 0.02 * R * (slots - nkb);
       if (cost < best_cost) {
         best_cost = cost;
-        best.ok = 1; best.R = R; best.S = S; best.P = pw <= 4 ? 4 : 8;
+        best.ok = 1; best.R = R; best.S = S; best.P = ((pw + 1) / 2) * 2;
         best.kb_base = kbs / S; best.kb_rem = kbs % S; best.RB = RB; best.total = total;
         best.cap = (total + 7) / 8; best.grid = best.cap * 8; best.max_chunks = mc;
         const int xbytes = mc * mt * 32 * 256, rbytes = 8 * mt * 32 * 128;
@@ -393,16 +403,16 @@ extern "C" int ll_w4a16_short_plan(int64_t m, int64_t n, int64_t k, int group_si
   return LL_OK;
 }
 
-template <int MT, int R, int P, bool EXACT>
+template <int MT, int R, int P, int NKB>
 static void ss_go(const SSParams& p, const SSPlan& pl, hipStream_t st) {
   static bool attr_set[16] = {false};
   int dev = 0;
   (void)hipGetDevice(&dev);
   if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute((const void*)wss_kernel<MT, R, P, EXACT>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_MAX_CHUNKS * 2 * 32 * 256);
+    (void)hipFuncSetAttribute((const void*)wss_kernel<MT, R, P, NKB>, hipFuncAttributeMaxDynamicSharedMemorySize, SS_MAX_CHUNKS * 2 * 32 * 256);
     attr_set[dev] = true;
   }
-  wss_kernel<MT, R, P, EXACT><<<dim3((unsigned)pl.grid), SS_THREADS, pl.lds, st>>>(SS_PASS(p));
+  wss_kernel<MT, R, P, NKB><<<dim3((unsigned)pl.grid), SS_THREADS, pl.lds, st>>>(SS_PASS(p));
 }
 
 // Shapes / pointers were validated by the caller (v3_launch).
@@ -425,15 +435,24 @@ int ss_launch(void* out, const void* x, const void* wpacked, const void* spacked
 #endif
   hipStream_t st = (hipStream_t)stream;
   const bool two = m > 32;
-  // exact: every slice is P * KQ blocks and starts at an even block
-  const int kq = 8 / pl.R;
-  const bool exact = pl.kb_rem == 0 && pl.kb_base == pl.P * kq && (pl.kb_base & 1) == 0;
-#define SS_GO(MTT, RR, PP) do { if (exact) ss_go<MTT, RR, PP, true>(p, pl, st); else ss_go<MTT, RR, PP, false>(p, pl, st); } while (0)
+  // static slice lengths for the headline's two launches (q|k|v: R 4 x 8 blocks; o: R 2 x 14 blocks); everything else reads them
+  // from the arguments
+  const int nkb_static = pl.kb_rem == 0 && ((pl.R == 4 && pl.kb_base == 8 && pl.P == 4) || (pl.R == 2 && pl.kb_base == 14 && pl.P == 4))
+                             ? pl.kb_base : 0;
+#define SS_GO(MTT, RR, PP) ss_go<MTT, RR, PP, 0>(p, pl, st)
 #define SS_CASE(RR)                                                                  \
   case RR:                                                                           \
-    if (two) { if (pl.P == 4) SS_GO(2, RR, 4); else SS_GO(2, RR, 8); }               \
-    else { if (pl.P == 4) SS_GO(1, RR, 4); else SS_GO(1, RR, 8); }                   \
+    if (two) { if (pl.P == 2) SS_GO(2, RR, 2); else if (pl.P == 4) SS_GO(2, RR, 4); else if (pl.P == 6) SS_GO(2, RR, 6); else SS_GO(2, RR, 8); } \
+    else { if (pl.P == 2) SS_GO(1, RR, 2); else if (pl.P == 4) SS_GO(1, RR, 4); else if (pl.P == 6) SS_GO(1, RR, 6); else SS_GO(1, RR, 8); }     \
     break;
+  if (nkb_static == 8) {
+    if (two) ss_go<2, 4, 4, 8>(p, pl, st); else ss_go<1, 4, 4, 8>(p, pl, st);
+    return LL_LAUNCH_CHECK();
+  }
+  if (nkb_static == 14) {
+    if (two) ss_go<2, 2, 4, 14>(p, pl, st); else ss_go<1, 2, 4, 14>(p, pl, st);
+    return LL_LAUNCH_CHECK();
+  }
   switch (pl.R) {
     SS_CASE(1)
     SS_CASE(2)

@@ -196,6 +196,86 @@ def test_partial_sums_and_reducing_norm(M, N, K_):
     assert exact > 0.98, exact
 
 
+def _short_plan(m, n, k, g=128):
+    import ctypes
+    from lite_llama_amd import _lib
+    out = (ctypes.c_int32 * 8)()
+    assert _lib.lib().ll_w4a16_short_plan(m, n, k, g, out) == 0
+    return dict(zip(("takes", "grid", "R", "S", "P", "kb_base", "kb_rem", "lds"), out))
+
+
+def test_short_stream_unpack_bit_exact_at_every_k_position():
+    """Round 6, csrc/gemm_short.hip: x = one-hot rows, scale 1, zero 0 -> the sum of the engine's planes IS the nibble matrix, for
+    every k position of every k-slice (route asserted: the short-stream engine takes the launch)."""
+    n, k = 512, 1024
+    assert _short_plan(64, n, k)["takes"] == 1
+    qw = torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64).to(torch.int32)
+    sc, zr = torch.ones(n, k // 128), torch.zeros(n, k // 128)
+    pw, ps = Q().pack_w4a16_weights(qw.to(DEV)), Q().pack_w4a16_scales(sc.to(DEV), zr.to(DEV))
+    nib = O.unpack_int4(qw).float()
+    for k0 in range(0, k, 64):
+        x = torch.zeros(64, k, dtype=torch.float16)
+        x[torch.arange(64), k0 + torch.arange(64)] = 1.0
+        parts = Q().w4a16_matmul_partials(x.to(DEV), pw, ps)
+        assert parts.parts.shape[0] == _short_plan(64, n, k)["S"]
+        got = parts.parts.sum(0).cpu()
+        assert torch.equal(got, nib[:, k0:k0 + 64].t().contiguous()), k0
+
+
+@pytest.mark.parametrize("M", [1, 17, 32, 33, 64])
+@pytest.mark.parametrize("N,K_,gs", [(4608, 3584, 128), (3584, 3584, 128), (2304, 3584, 128), (3584, 2432, 128), (4736 // 128 * 128, 3584, 128),
+                                     (5120, 2048, 128), (2048, 4096, 256), (1024, 512, 512), (128, 128, 128)])
+def test_short_stream_planes_match_oracle_and_unit_loop(M, N, K_, gs):
+    """The short-stream engine's planes (headline q|k|v / o, TP-shard and other-model shapes, ragged slices, every batch class)
+    against the CPU oracle at 1e-2 (reference tolerance 5e-2, w4a16.py:152-207) and against the unit loop's planes (same
+    dequantiser: only the fp32 summation order differs); rows >= M of the last batch half are never written."""
+    g = torch.Generator().manual_seed(N * 7 + K_ + M)
+    x = (torch.randn(M, K_, generator=g) * 0.5).half()
+    qw = torch.randint(-(2**31), 2**31 - 1, (N, K_ // 8), dtype=torch.int64, generator=g).to(torch.int32)
+    sc = torch.rand(N, K_ // gs, generator=g) * 0.01 + 0.005
+    zr = torch.randint(0, 16, (N, K_ // gs), generator=g).float()
+    pw, ps = Q().pack_w4a16_weights(qw.to(DEV)), Q().pack_w4a16_scales(sc.to(DEV), zr.to(DEV))
+    plan = _short_plan(M, N, K_, gs)
+    a = Q().w4a16_matmul_partials(x.to(DEV), pw, ps, group_size=gs)
+    b = Q().w4a16_matmul_partials(x.to(DEV), pw, ps, group_size=gs, _unit_loop_engine=True)
+    assert a is not None and b is not None
+    if plan["takes"]:
+        assert a.parts.shape == (plan["S"], M, N)
+    sa, sb = a.parts.sum(0), b.parts.sum(0)
+    scale = sb.abs().max().item()
+    assert (sa - sb).abs().max().item() <= 2e-5 * scale + 1e-6
+    if N * K_ <= 4608 * 3584 and M in (17, 64):
+        ref = O.w4a16_matmul(x, qw, sc, zr, group_size=gs).float()
+        close(sa.half(), ref, 1e-2)
+
+
+def test_short_stream_planes_feed_the_reducing_norm():
+    """skip_rmsnorm_partials over the short-stream planes against skip_rmsnorm of their sum in plane order, rounded once (the
+    projection's own epilogue rounding): the residual -- the value the next layer builds on -- bit for bit, the normalised row to
+    the last ulp of the row statistic's summation order -- the consumer contract of epilogue 2, whatever the plane count."""
+    import lite_llama_amd.kernels as K
+    from lite_llama_amd.kernels.norm_act import skip_rmsnorm_partials
+    M, N, K_ = 64, 3584, 3584
+    g = torch.Generator().manual_seed(11)
+    x = (torch.randn(M, K_, generator=g) * 0.5).half().to(DEV)
+    qw = torch.randint(-(2**31), 2**31 - 1, (N, K_ // 8), dtype=torch.int64, generator=g).to(torch.int32).to(DEV)
+    sc = (torch.rand(N, K_ // 128, generator=g) * 0.01 + 0.005).to(DEV)
+    zr = torch.randint(0, 16, (N, K_ // 128), generator=g).float().to(DEV)
+    pw, ps = Q().pack_w4a16_weights(qw), Q().pack_w4a16_scales(sc, zr)
+    parts = Q().w4a16_matmul_partials(x, pw, ps)
+    assert parts.parts.shape[0] == _short_plan(M, N, K_)["S"]
+    acc = torch.zeros(M, N, device=DEV)
+    for s in range(parts.parts.shape[0]):  # the consumer's order: plane 0 first
+        acc = acc + parts.parts[s]
+    res = (torch.randn(M, N, generator=g) * 0.5).half().to(DEV)
+    wn = (1 + 0.1 * torch.randn(N, generator=g)).half().to(DEV)
+    y_ref, r_ref = K.skip_rmsnorm(acc.half(), res.clone(), wn, 1e-6)
+    y, r = skip_rmsnorm_partials(parts, res.clone(), wn, 1e-6)
+    assert torch.equal(r, r_ref)
+    close(y, y_ref, 2e-3)
+    assert (y == y_ref).float().mean().item() > 0.999
+
+
 @pytest.mark.parametrize("dtype_bias", [True, False])
 @pytest.mark.parametrize("ctx", [200, 300, 549, 1000])
 def test_decode_attention_over_qkv_partials(ctx, dtype_bias):
