@@ -248,10 +248,23 @@ static int r16_num_cus() {
   return cus[dev];
 }
 
+// the row-group loop needs R16Lds<MT>::BYTES of LDS per workgroup (160 KB at MT = 1): callers fall back when the device's opt-in
+// limit is smaller
+static bool r16_lds_fits(int64_t m) {
+  static int optin[16] = {0};
+  int dev = 0;
+  if (hipGetDevice(&dev) != hipSuccess || dev < 0 || dev >= 16) return true;  // no device (host-side plan queries): gfx950 assumed
+  if (!optin[dev]) {
+    int v = 0;
+    optin[dev] = hipDeviceGetAttribute(&v, hipDeviceAttributeSharedMemPerBlockOptin, dev) == hipSuccess && v > 0 ? v : 160 * 1024;
+  }
+  return (m <= 32 ? R16Lds<1>::BYTES : R16Lds<2>::BYTES) <= optin[dev];
+}
+
 extern "C" int ll_dense16_rows_supported(int64_t m, int64_t n, int64_t k, int epilogue) {
   if (m < 1 || m > 64 || n < 32 || n % 32 != 0 || k < 128 || k % 128 != 0) return 0;
   if (epilogue != 0 && epilogue != 1) return 0;
-  return 1;
+  return r16_lds_fits(m) ? 1 : 0;
 }
 
 // out [m][n] (epilogue 0, + bias) or [m][n / 2] (epilogue 1: rows of w interleaved (gate_j, up_j)) = x [m][k] @ w [n][k]^T for an
@@ -276,10 +289,12 @@ extern "C" int ll_dense16_rows_matmul(void* out, const void* x, const void* w, c
   hipStream_t st = (hipStream_t)stream;
 #define R16_GO(MT, DT)                                                                                                   \
   {                                                                                                                      \
-    static bool attr_ = false;                                                                                           \
-    if (!attr_) {                                                                                                        \
+    static bool attr_[16] = {false}; /* per device */                                                   \
+    int dev_ = 0;                                                                                                        \
+    (void)hipGetDevice(&dev_);                                                                                           \
+    if (dev_ >= 0 && dev_ < 16 && !attr_[dev_]) {                                                                        \
       (void)hipFuncSetAttribute((const void*)wgemm16_rows_kernel<MT, DT>, hipFuncAttributeMaxDynamicSharedMemorySize, R16Lds<MT>::BYTES); \
-      attr_ = true;                                                                                                      \
+      attr_[dev_] = true;                                                                                                \
     }                                                                                                                    \
     wgemm16_rows_kernel<MT, DT><<<dim3((unsigned)grid), R16_THREADS, R16Lds<MT>::BYTES, st>>>(p);                          \
   }
@@ -297,7 +312,7 @@ extern "C" int ll_dense16_rows_matmul(void* out, const void* x, const void* w, c
 // (kernels/quantization/w8a8.py:118-149), exact int32 sums on mfma_i32_32x32x32_i8; then silu(gate) * up on the rounded outputs
 // (= ll_w8a8_finish_swiglu).  m <= 64, n % 32 == 0, k % 256 == 0, row strides (bytes) % 16 == 0.
 extern "C" int ll_w8a8_rows_supported(int64_t m, int64_t n, int64_t k, int epilogue) {
-  return (m >= 1 && m <= 64 && n >= 32 && n % 32 == 0 && k >= 256 && k % 256 == 0 && (epilogue == 0 || epilogue == 1)) ? 1 : 0;
+  return (m >= 1 && m <= 64 && n >= 32 && n % 32 == 0 && k >= 256 && k % 256 == 0 && (epilogue == 0 || epilogue == 1) && r16_lds_fits(m)) ? 1 : 0;
 }
 
 extern "C" int ll_w8a8_rows_matmul(void* out, const int8_t* qa, const float* a_scale, const int8_t* qw, const float* w_scale,
@@ -324,10 +339,12 @@ extern "C" int ll_w8a8_rows_matmul(void* out, const int8_t* qa, const float* a_s
   hipStream_t st = (hipStream_t)stream;
 #define R16_GO8(MT)                                                                                                      \
   {                                                                                                                      \
-    static bool attr_ = false;                                                                                           \
-    if (!attr_) {                                                                                                        \
+    static bool attr_[16] = {false}; /* per device */                                                   \
+    int dev_ = 0;                                                                                                        \
+    (void)hipGetDevice(&dev_);                                                                                           \
+    if (dev_ >= 0 && dev_ < 16 && !attr_[dev_]) {                                                                        \
       (void)hipFuncSetAttribute((const void*)wgemm16_rows_kernel<MT, R16_I8>, hipFuncAttributeMaxDynamicSharedMemorySize, R16Lds<MT>::BYTES); \
-      attr_ = true;                                                                                                      \
+      attr_[dev_] = true;                                                                                                \
     }                                                                                                                    \
     wgemm16_rows_kernel<MT, R16_I8><<<dim3((unsigned)grid), R16_THREADS, R16Lds<MT>::BYTES, st>>>(p);                      \
   }

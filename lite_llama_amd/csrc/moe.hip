@@ -199,8 +199,12 @@ extern "C" int ll_moe_align_block_size(const void* topk_ids, int ids_width, int6
   const int max_padded = (int)num_slots + num_experts * (block_size - 1);
   const int max_blocks = (max_padded + block_size - 1) / block_size;
   static const bool small_off = getenv("LL_MOE_ALIGN_V1") != nullptr;  // A/B knob, read once
-  if (!small_off && num_slots >= 1 && num_slots <= 1024 && num_experts <= 1024) {
-    int threads = (int)((num_slots > num_experts ? num_slots : num_experts) + 63) / 64 * 64;
+  const int small_threads = (int)((num_slots > num_experts ? num_slots : num_experts) + 63) / 64 * 64;
+  // (per-(wave, expert) counts in dynamic LDS: kept inside the 64 KB a launch gets without an opt-in attribute -- 1024 experts x
+  // 1024 slots would need ~72 KB; such shapes take the general kernel)
+  const size_t small_lds = (size_t)(small_threads / 64 * num_experts + 2 * num_experts) * sizeof(int);
+  if (!small_off && num_slots >= 1 && num_slots <= 1024 && num_experts <= 1024 && small_lds <= 64 * 1024) {
+    int threads = small_threads;
     const int nw = threads / 64;
     moe_align_small_kernel<<<1, threads, (size_t)(nw * num_experts + 2 * num_experts) * sizeof(int), (hipStream_t)stream>>>(
         topk_ids, ids_width, (int)num_slots, num_experts, block_size, sorted_ids, expert_ids, num_post, max_padded, max_blocks);

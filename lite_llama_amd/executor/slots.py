@@ -79,6 +79,7 @@ class StepGraphs:
         self.b_req_idx = torch.zeros(cap, dtype=torch.long, device=device)
         self._meta = AttentionMetadata
         self._graphs: dict[tuple[int, int], tuple] = {}
+        self._epoch = getattr(model, "layout_epoch", 0)  # the weight layouts the cached graphs were captured over
 
     # ------------------------------------------------------------------ selection --- #
     def _pick_bucket(self, current_max_seq_len: int) -> int | None:
@@ -147,6 +148,11 @@ class StepGraphs:
         bucket = self._pick_bucket(atten_info.max_actual_seq_len)
         if bucket is None:
             return None
+        if getattr(self.model, "layout_epoch", 0) != self._epoch:
+            # compact_weights / expand_weights ran since the capture: int4 storage was re-allocated or MoE rows re-ordered
+            # under the recorded launches -- never replay those; the grid is re-captured on demand
+            self._graphs.clear()
+            self._epoch = getattr(self.model, "layout_epoch", 0)
         entry = self._graphs.get((batch_size, bucket))
         if entry is None:
             entry = self.capture(batch_size, bucket)

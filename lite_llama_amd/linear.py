@@ -13,9 +13,31 @@ from .distributed.parallel_state import all_reduce_tp, collective_forced, divide
 from .quantization import QuantConfig, get_linear_method
 
 
+def _export_reference_weight(module, state_dict, prefix, local_metadata):
+    """state_dict post-hook of every linear: a compacted int4 layer's ``weight`` parameter aliases the decode engine's load-time
+    layout (permuted words) -- the EXPORTED entry is the reference-format tensor, rebuilt transiently (bit-exact inverse
+    permutation); the model itself is not touched, so captured graphs keep replaying over the packed storage.
+    Covers ``model.state_dict()`` and any ``submodule.state_dict()`` alike."""
+    if getattr(module, "_w4_compact", False) or getattr(module, "_w4_compact_member", None) is not None:
+        key = prefix + "weight"
+        if key in state_dict:
+            state_dict[key] = module.quant_method.reference_weight(module).detach()
+
+
+def _refuse_load_into_compact(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+    """load_state_dict pre-hook: checkpoint rows copied into a parameter that aliases the load-time layout would be read as
+    permuted words -- silently wrong.  ``CausalLM.load_state_dict`` expands first; a direct submodule load has to."""
+    if (getattr(module, "_w4_compact", False) or getattr(module, "_w4_compact_member", None) is not None) \
+            and (prefix + "weight") in state_dict:
+        raise RuntimeError(f"{prefix}weight aliases the decode engine's load-time layout (compact_weights): call "
+                           "model.expand_weights() before loading a checkpoint into it")
+
+
 class LinearBase(nn.Module):
     def __init__(self, input_size: int, output_size: int, *, bias: bool = False, quant: QuantConfig | None = None):
         super().__init__()
+        self.register_state_dict_post_hook(_export_reference_weight)
+        self.register_load_state_dict_pre_hook(_refuse_load_into_compact)
         self.input_size = input_size
         self.output_size = output_size
         self.quant = quant

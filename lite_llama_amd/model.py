@@ -392,6 +392,8 @@ class SparseMoeBlock(nn.Module):
 
     def __init__(self, geo: ModelGeometry, quant: QuantConfig | None):
         super().__init__()
+        self.register_state_dict_post_hook(SparseMoeBlock._export_stacked_gate_up)
+        self.register_load_state_dict_pre_hook(SparseMoeBlock._refuse_load_into_interleaved)
         tp = get_tp_world_size()
         self.hidden_size = geo.hidden_size
         self.num_experts = geo.num_experts
@@ -444,6 +446,24 @@ class SparseMoeBlock(nn.Module):
         return all_reduce_tp(out).view(shape)
 
     # ---- load-time interleave of the stacked gate|up rows (round 5) ------------------------------------------------------
+    @staticmethod
+    def _export_stacked_gate_up(module, state_dict, prefix, local_metadata):
+        """state_dict post-hook: an interleaved block EXPORTS the checkpoint's stacked order (fresh tensors; the block and the
+        graphs captured over it are not touched -- ADVICE round 5)."""
+        if getattr(module, "_gu_interleaved", False):
+            w, sc = module.stacked_gate_up()
+            for key, val in ((prefix + "experts.gate_up_proj", w), (prefix + "experts.gate_up_proj_scale_inv", sc)):
+                if val is not None and key in state_dict:
+                    state_dict[key] = val.detach()
+
+    @staticmethod
+    def _refuse_load_into_interleaved(module, state_dict, prefix, local_metadata, strict, missing_keys, unexpected_keys, error_msgs):
+        """load_state_dict pre-hook: stacked checkpoint rows copied into interleaved storage (same shapes with per-channel
+        scales) would be multiplied as pairs -- silently wrong.  ``CausalLM.load_state_dict`` expands first."""
+        if getattr(module, "_gu_interleaved", False) and (prefix + "experts.gate_up_proj") in state_dict:
+            raise RuntimeError(f"{prefix}experts.gate_up_proj is row-interleaved (compact_weights): call model.expand_weights() "
+                               "before loading a checkpoint into it")
+
     @torch.no_grad()
     def interleave_gate_up_(self) -> bool:
         """Re-order the rows of ``experts.gate_up_proj`` from the checkpoint's stacked halves ``[gate_0.. | up_0..]`` to pairs
@@ -468,30 +488,45 @@ class SparseMoeBlock(nn.Module):
             if gn > 1:
                 sc = sc.repeat_interleave(gn, dim=1)[:, :two_i]
             sc = torch.stack((sc[:, :i], sc[:, i:]), dim=2).reshape(e, two_i, -1).contiguous()
-            self.experts[key] = type(self.experts[key])(sc) if gn > 1 else self.experts[key]
-            if gn == 1:
+            if gn > 1:
+                # (block scales grow from one value per gn rows to one per row: e.g. 128 x 128 fp8 blocks of Qwen3-30B-A3B,
+                # 4.7 MB -> ~600 MB resident -- the price of pairing rows that sit in different scale blocks)
+                self.experts[key] = nn.Parameter(sc, requires_grad=False)
+            else:
                 self.experts[key].data.copy_(sc)
         self._gu_interleaved = True
         return True
 
-    @torch.no_grad()
-    def deinterleave_gate_up_(self) -> None:
+    def stacked_gate_up(self):
+        """``(gate_up_proj, gate_up_proj_scale_inv or None)`` in the CHECKPOINT's stacked order, as fresh tensors when the
+        block is interleaved (the block itself is not touched) -- what ``state_dict()`` exports."""
+        w = self.experts["gate_up_proj"].data
+        key = "gate_up_proj_scale_inv"
+        sc = self.experts[key].data if key in self.experts else None
         if not getattr(self, "_gu_interleaved", False):
-            return
-        w = self.experts["gate_up_proj"]
+            return w, sc
         e, two_i, h = w.shape
         i = two_i // 2
-        pairs = w.data.view(e, i, 2, h)
-        w.data.copy_(torch.cat((pairs[:, :, 0], pairs[:, :, 1]), dim=1))
-        key = "gate_up_proj_scale_inv"
-        if key in self.experts:
-            sc = self.experts[key].data
+        pairs = w.view(e, i, 2, h)
+        w = torch.cat((pairs[:, :, 0], pairs[:, :, 1]), dim=1)
+        if sc is not None:
             pairs = sc.view(e, i, 2, -1)
             sc = torch.cat((pairs[:, :, 0], pairs[:, :, 1]), dim=1).contiguous()
             gn = getattr(self, "_gu_scale_rows", 1)
             if gn > 1:
                 sc = sc[:, ::gn].contiguous()
-                self.experts[key] = type(self.experts[key])(sc)
+        return w, sc
+
+    @torch.no_grad()
+    def deinterleave_gate_up_(self) -> None:
+        if not getattr(self, "_gu_interleaved", False):
+            return
+        w, sc = self.stacked_gate_up()
+        self.experts["gate_up_proj"].data.copy_(w)
+        key = "gate_up_proj_scale_inv"
+        if sc is not None:
+            if getattr(self, "_gu_scale_rows", 1) > 1:
+                self.experts[key] = nn.Parameter(sc, requires_grad=False)
             else:
                 self.experts[key].data.copy_(sc)
         self._gu_interleaved = False
@@ -538,6 +573,7 @@ class CausalLM(nn.Module):
         super().__init__()
         self.geo = geo
         self.quant = quant
+        self.layout_epoch = 0  # moves with every compact / expand: graphs captured under another epoch are stale
         self.shard_plan = shard_plan(geo, quant)  # None: the reference's equal cuts
         set_active_plan(self.shard_plan, geo.num_heads, geo.num_kv_heads, geo.intermediate_size)
         self.embed_tokens = nn.Embedding(geo.vocab_size, geo.hidden_size, dtype=torch.float16)
@@ -599,8 +635,13 @@ class CausalLM(nn.Module):
         parameter (2 x 0.5 B per weight).  After this call the load-time layout is the only resident copy: the parameters
         alias it (same shapes / dtypes, permuted words), the reference-format tensors are rebuilt on demand for calls of more
         than 64 rows (prefill) -- ``W4A16LinearMethod.reference_weight``.  Call after the weights are final (after loading /
-        quantising; before or after graph capture: the packed storage does not move).  Returns the bytes released.
-        ``expand_weights()`` undoes it (needed before ``state_dict()`` export or another ``load_weights``)."""
+        quantising) and BEFORE any decode step is captured: the int4 storage a captured graph points at does not move, but a MoE
+        block's gate|up rows are re-ordered in place for the fused epilogue, and a graph captured over the stacked rows would
+        replay over pairs -- ``layout_epoch`` moves with every layout change and ``StepGraphs`` drops the graphs it cached under
+        another epoch (``DecodeEngine.decode`` captures per call); a graph the CALLER captured is the caller's to drop.  Returns
+        the bytes released.
+        ``state_dict()`` of a compacted model still exports the reference layouts (rebuilt per entry, nothing is mutated);
+        ``expand_weights()`` undoes the compaction (``load_state_dict`` calls it first)."""
         freed = 0
         members = set()
         for mc in self._merged_linears():
@@ -611,8 +652,10 @@ class CausalLM(nn.Module):
             if isinstance(m, LinearBase) and id(m) not in members and hasattr(m.quant_method, "compact"):
                 freed += m.quant_method.compact(m)
             if isinstance(m, SparseMoeBlock):
-                m.interleave_gate_up_()  # (frees nothing: the same storage, rows re-ordered for the fused epilogue)
+                if m.interleave_gate_up_():  # (frees nothing: rows re-ordered for the fused epilogue; block scales GROW, see there)
+                    self.layout_epoch += 1
         if freed:
+            self.layout_epoch += 1
             torch.cuda.empty_cache()
         return freed
 
@@ -622,15 +665,22 @@ class CausalLM(nn.Module):
                 for m in self.modules() if isinstance(m, LinearBase)) or \
             any(getattr(mc._holder, "_w4_compact", False) for mc in self._merged_linears())
 
-    def state_dict(self, *args, **kwargs):
-        """A compacted model's int4 ``weight`` parameters alias the decode engine's load-time layout (permuted words): exporting
-        them as a checkpoint would be silently corrupt.  The reference-format tensors are restored first."""
+    # (state_dict(): the per-module post-hooks -- linear.py::_export_reference_weight, SparseMoeBlock._export_stacked_gate_up --
+    # export reference layouts from a compacted model without touching it)
+
+    def load_state_dict(self, state_dict, *args, **kwargs):
+        """Checkpoint tensors are in the reference layouts: a compacted model is expanded first (``layout_epoch`` moves, so
+        engines drop the graphs captured over the compacted storage); compact again afterwards."""
         if self.is_compacted():
             self.expand_weights()
-        return super().state_dict(*args, **kwargs)
+        return super().load_state_dict(state_dict, *args, **kwargs)
 
     @torch.no_grad()
     def expand_weights(self) -> None:
+        """Undo ``compact_weights``: fresh reference-format int4 tensors, MoE rows back in the stacked order.  Graphs captured
+        over the compacted storage are stale afterwards (``layout_epoch`` moves; engines re-capture)."""
+        if self.is_compacted():
+            self.layout_epoch += 1
         for mc in self._merged_linears():
             mc.expand()
         for m in self.modules():

@@ -372,8 +372,18 @@ def test_moe_model_with_interleaved_gate_up_equals_the_stacked_layout():
     blocks = [b for b in m.modules() if isinstance(b, SparseMoeBlock)]
     assert blocks and all(getattr(b, "_gu_interleaved", False) for b in blocks) and m.is_compacted()
     assert torch.equal(run(), stacked)
-    after = m.state_dict()  # expands first
-    assert not m.is_compacted() and all(torch.equal(after[k], before[k]) for k in before)
+    epoch = m.layout_epoch
+    after = m.state_dict()  # exports the checkpoint order; the model -- and whatever was captured over it -- is not touched
+    assert m.is_compacted() and m.layout_epoch == epoch and all(torch.equal(after[k], before[k]) for k in before)
+    sub = blocks[0].state_dict()  # ... a submodule's export alike
+    assert torch.equal(sub["experts.gate_up_proj"], before["layers.0.mlp.experts.gate_up_proj"])
+    assert all(not p.requires_grad for p in m.parameters())
+    assert torch.equal(run(), stacked)
+    with pytest.raises(RuntimeError, match="expand_weights"):  # stacked rows must not be copied into interleaved storage
+        blocks[0].load_state_dict(sub)
+    m.load_state_dict(after, strict=True)  # the model-level load expands first
+    assert not m.is_compacted() and m.layout_epoch == epoch + 1
+    assert all(torch.equal(v, before[k]) for k, v in m.state_dict().items())
     assert torch.equal(run(), stacked)
 
 

@@ -442,6 +442,17 @@ def test_compacted_model_keeps_one_copy_of_the_int4_weights_and_the_same_numbers
         assert torch.equal(first1, first0) and torch.equal(toks1, toks0)
     again = eng_before.decode(eng_before.prefill(ids, lens), 6, use_graph=True)   # the engine whose graph was captured BEFORE
     assert torch.equal(again, toks0)
+    # state_dict() of the compacted model exports the reference layouts WITHOUT touching the model: same
+    # storage, same epoch, a submodule's export alike; a submodule-level load into the aliased storage is refused
+    epoch, ptrs = model.layout_epoch, {k: v.data_ptr() for k, v in model.named_parameters()}
+    sd_c = model.state_dict()
+    assert model.is_compacted() and model.layout_epoch == epoch
+    assert all(v.data_ptr() == ptrs[k] for k, v in model.named_parameters())
+    assert all(torch.equal(sd_c[k], ref_params[k]) for k in ref_params)
+    sub = model.layers[0].self_attn.o_proj.state_dict()
+    assert torch.equal(sub["weight"], ref_params["layers.0.self_attn.o_proj.weight"])
+    with pytest.raises(RuntimeError, match="expand_weights"):
+        model.layers[0].self_attn.o_proj.load_state_dict(sub)
     # replacing a parameter of a compacted model is refused loudly (its merged storage holds permuted words) ...
     layer0 = model.layers[0].self_attn
     keep = layer0.q_proj.weight

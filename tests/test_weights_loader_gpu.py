@@ -93,7 +93,7 @@ def _layer_params(model, module):
 @pytest.mark.parametrize("fmt", ["awq", "gptq", "gptq_v2"])
 def test_int4_checkpoint_loads_to_the_oracle_conversion(fmt, tmp_path):
     truth = _write(str(tmp_path), fmt)
-    model = weights.load_pretrained(str(tmp_path), device=DEV)
+    model = weights.load_pretrained(str(tmp_path), device=DEV, compact=False)
     for name, n, k in LINEARS:
         if name.endswith(("k_proj", "v_proj")):
             continue
@@ -114,6 +114,22 @@ def test_int4_checkpoint_loads_to_the_oracle_conversion(fmt, tmp_path):
     assert np.abs(got - want).max() <= 1e-2 * np.abs(want).max() + 1e-2
 
 
+def test_loader_compacts_by_default_and_still_exports_the_checkpoint_layouts(tmp_path):
+    """``load_pretrained`` leaves the configuration ``bench.py`` measures: one resident copy of the int4 words
+    (parameters alias the decode engine's load-time layout), and ``state_dict()`` -- without touching the model -- exports
+    exactly what the uncompacted load holds; both models compute the same rows."""
+    _write(str(tmp_path), "awq")
+    plain = weights.load_pretrained(str(tmp_path), device=DEV, compact=False)
+    model = weights.load_pretrained(str(tmp_path), device=DEV)
+    assert model.is_compacted() and not plain.is_compacted()
+    want, got = plain.state_dict(), model.state_dict()
+    assert model.is_compacted() and want.keys() == got.keys()
+    for k in want:
+        assert torch.equal(want[k], got[k]), k
+    x = (torch.randn(8, I, device=DEV) * 0.5).half()
+    assert torch.equal(model.layers[0].mlp.down_proj(x), plain.layers[0].mlp.down_proj(x))
+
+
 def test_int4_checkpoint_tensor_parallel_cuts(tmp_path, tp_state):
     """Each rank's parameters are the slices of the TP = 1 parameters that the fp16 loader would give it: output rows for
     q / kv / gate / up (kv: [K_r ; V_r]), input columns (words / groups) for o / down."""
@@ -121,7 +137,7 @@ def test_int4_checkpoint_tensor_parallel_cuts(tmp_path, tp_state):
     full = {name: _native(truth, name, "awq") for name, _, _ in LINEARS}
     for rank in (0, 1):
         ps._TP_WORLD_SIZE, ps._TP_RANK = 2, rank
-        model = weights.load_pretrained(str(tmp_path), device=DEV)
+        model = weights.load_pretrained(str(tmp_path), device=DEV, compact=False)
         for name in ("self_attn.q_proj", "mlp.gate_proj", "mlp.up_proj"):
             for got, want in zip(_layer_params(model, name), full[name]):
                 rows = want.shape[0] // 2
@@ -141,7 +157,7 @@ def test_gptq_act_order_checkpoint(tmp_path, tp_state):
     sorted tensor), remembers the permutation, and the layers -- incl. the fused q|k|v and gate|up launches, which need
     ONE input order -- compute (q - z[g_idx]) * s[g_idx]."""
     truth = _write(str(tmp_path), "gptq", act_order=True)
-    model = weights.load_pretrained(str(tmp_path), device=DEV)
+    model = weights.load_pretrained(str(tmp_path), device=DEV, compact=False)
     layer = model.layers[0]
     for name, n, k in LINEARS:
         if name.endswith(("k_proj", "v_proj")):
@@ -176,7 +192,7 @@ def test_gptq_act_order_checkpoint(tmp_path, tp_state):
     # a row-parallel desc_act linear cannot be cut along its input channels
     ps._TP_WORLD_SIZE, ps._TP_RANK = 2, 0
     with pytest.raises(NotImplementedError, match="activation-ordered"):
-        weights.load_pretrained(str(tmp_path), device=DEV)
+        weights.load_pretrained(str(tmp_path), device=DEV, compact=False)
 
 
 def test_fp16_checkpoint_quantised_at_load_time_runs_the_decode_engine(tmp_path):
@@ -198,7 +214,7 @@ def test_fp16_checkpoint_quantised_at_load_time_runs_the_decode_engine(tmp_path)
     del cfg["quantization_config"]
     with open(os.path.join(str(tmp_path), "config.json"), "w") as f:
         json.dump(cfg, f)
-    model = weights.load_pretrained(str(tmp_path), device=DEV, quantization="int4")
+    model = weights.load_pretrained(str(tmp_path), device=DEV, quantization="int4", compact=False)
     down = model.layers[0].mlp.down_proj
     assert down.quant.is_int4 and down.weight.dtype == torch.int32 and down.weight.shape == (H, I // 8)
     outs = []
