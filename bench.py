@@ -76,6 +76,14 @@ def parse():
     ap.add_argument("--keep-reference-weights", action="store_true",
                     help="keep the reference-format int4 tensors next to the decode engine's layout (2 x the int4 payload)")
     ap.add_argument("--cpu-layers", type=int, default=1, help="decoder layers in the CPU oracle sample")
+    ap.add_argument("--shard-sim", default=None,
+                    help="comma list of TP degrees (default for the N = 1 headline line: 2,4,8; 'none' to skip): per degree ONE rank's "
+                         "shard shapes on this GPU with every all-reduce replaced by a same-size local copy -- one rank's compute, no "
+                         "collective: a ceiling of the scaling curve, not a scaling point (\"shard_sim\" in the line)")
+    ap.add_argument("--as-shard-sim", type=int, default=0,
+                    help="(used by --shard-sim) run as rank 0 of this TP degree with simulated collectives; bounded line")
+    ap.add_argument("--no-reference-order", action="store_true",
+                    help="skip the bounded drop-in-route entry (\"reference_order\") of the default N = 1 int4 line")
     return ap.parse_args()
 
 
@@ -231,8 +239,10 @@ def reference_order_step(model, engine, batch, ctx, steps, warmup):
     layers = []
     for layer in model.layers:
         at, mlp = layer.self_attn, layer.mlp
-        lin = lambda m: (m.weight.data.contiguous(), m.weight_scale.data.contiguous(), m.weight_zeros.data.contiguous(),  # noqa: E731
-                         None if m.bias is None else m.bias.data.contiguous())
+        # (a compacted model keeps only the decode engine's load-time layout: the REFERENCE-format tensor the drop-in caller
+        # would hold is rebuilt here, bit-exact, for the duration of this measurement)
+        lin = lambda m: (m.quant_method.reference_weight(m).data.contiguous(), m.weight_scale.data.contiguous(),  # noqa: E731
+                         m.weight_zeros.data.contiguous(), None if m.bias is None else m.bias.data.contiguous())
         layers.append(dict(ln1=layer.input_layernorm_weight.data, ln2=layer.post_attention_layernorm_weight.data,
                            q=lin(at.q_proj), kv=lin(at.kv_proj), o=lin(at.o_proj), gate=lin(mlp.gate_proj), up=lin(mlp.up_proj),
                            down=lin(mlp.down_proj)))
@@ -399,6 +409,37 @@ def secondary_configs(steps: int, timeout_s: float = 240.0):
         except Exception as exc:
             out.append({"config": label, "error": f"{type(exc).__name__}: {exc}"})
     return out
+
+
+def shard_sim_points(args, degrees, timeout_s: float = 200.0):
+    """The compute half of the TP scaling curve, measured on ONE GPU (round-5 review, item 5): for every degree THIS script in a
+    fresh process builds rank 0's shard of the model (the shard plan's shapes, synthetic weights), replaces every all-reduce by a
+    same-size local device copy (parallel_state.simulate_shard) and times the captured decode step.  Labelled for what it is."""
+    import subprocess
+
+    out = []
+    for tp in degrees:
+        cmd = [sys.executable, os.path.abspath(__file__), "--model", args.model, "--quant", args.quant, "--batch", str(args.batch),
+               "--ctx", str(args.ctx), "--dtype", args.dtype, "--steps", str(min(args.steps, 32)), "--warmup", "4",
+               "--as-shard-sim", str(tp), "--as-secondary", "--no-cpu-baseline", "--shard-sim", "none"]
+        try:
+            r = subprocess.run(cmd, capture_output=True, text=True, timeout=timeout_s)
+            line = [l for l in r.stdout.splitlines() if l.startswith("{")]
+            if r.returncode != 0 or not line:
+                out.append({"tp": tp, "error": f"rc {r.returncode}: {(r.stderr or r.stdout)[-300:]}"})
+                continue
+            d = json.loads(line[-1])
+            out.append({"tp": tp, "ms_per_step": d["ms_per_step"], "tokens_per_s_if_collectives_were_free": round(d["value"], 1),
+                        "step_roofline_frac": d["step_roofline"]["frac_of_8TBps"],
+                        "algorithmic_bytes_per_step": d["step_roofline"]["algorithmic_bytes_per_step_per_gpu"],
+                        "shard_plan": d["config"]["shard_plan"], "graph": d["graph"]})
+        except subprocess.TimeoutExpired:
+            out.append({"tp": tp, "error": f"no line within {timeout_s:.0f} s"})
+        except Exception as exc:
+            out.append({"tp": tp, "error": f"{type(exc).__name__}: {exc}"})
+    return {"what": "ONE rank's compute at the TP shard shapes on one GPU, every all-reduce replaced by a same-size local copy, "
+                    "captured step, <= 32 steps: a ceiling of the scaling curve (no collective, no peers), NOT a scaling point",
+            "points": out}
 
 
 def moe_roofline(model, batch, iters=6):
@@ -766,10 +807,26 @@ def main():
         unit = scale_unit(None if args.quant == "none" else QuantConfig.for_runtime_scheme(args.quant), geo.intermediate_size)
         tp = admissible_tp(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, world, unit)  # the model's own rule
         plan_note = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, tp, unit).describe()
-    dp = world // tp
-    ps.init_parallel(rank, tp_size=tp, dp_size=dp, master_port=int(os.environ.get("MASTER_PORT", 29500)))
+    if args.as_shard_sim > 1:
+        if world != 1:
+            raise SystemExit("--as-shard-sim is a one-process mode")
+        tp = args.as_shard_sim
+        if geo.num_experts:
+            plan_note = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, tp * 128, tp).describe() + \
+                f"; experts: {geo.moe_intermediate_size // tp} intermediate channels per rank"
+        else:
+            unit = scale_unit(None if args.quant == "none" else QuantConfig.for_runtime_scheme(args.quant), geo.intermediate_size)
+            plan_note = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, tp, unit).describe()
+        plan_note = f"rank 0 of tp{tp}, collectives simulated by local copies: " + plan_note
+        dp = 1
+        ps.simulate_shard(tp, 0)
+    else:
+        dp = world // tp
+        ps.init_parallel(rank, tp_size=tp, dp_size=dp, master_port=int(os.environ.get("MASTER_PORT", 29500)))
     allreduce_how, allreduce_reason = ("none (tp1)" if tp == 1 else "rccl"), ("" if tp == 1 else "--allreduce rccl")
-    if tp > 1 and args.allreduce != "rccl":
+    if args.as_shard_sim > 1:
+        allreduce_how, allreduce_reason = "simulated: same-size local device copy (no peers)", "--as-shard-sim"
+    elif tp > 1 and args.allreduce != "rccl":
         allreduce_how, allreduce_reason = choose_allreduce(ps, args.batch * geo.hidden_size, dev, strict=args.allreduce == "oneshot")
     if world > 1 and not torch.distributed.is_initialized():  # pure DP: still need the timing barrier
         kw = {"device_id": dev} if ps._backend() == "nccl" else {}
@@ -915,9 +972,14 @@ def main():
             result["roofline_dense_projections"] = rf
             rf = mrf
         result["roofline"] = rf
-        if args.reference_order and world == 1 and args.quant == "int4" and not geo.num_experts:
-            try:
-                result["reference_order"] = reference_order_step(model, engine, args.batch, int(ctx_mid), args.steps, args.warmup)
+        headline_line = (world == 1 and args.model == "qwen2.5-7b" and args.quant == "int4" and not args.as_secondary
+                         and not args.scattered and not args.kv_block_size and not args.as_shard_sim)
+        if (args.reference_order or (headline_line and not args.no_reference_order)) and world == 1 and args.quant == "int4" \
+                and not geo.num_experts and not args.as_shard_sim:
+            try:  # the drop-in route next to the headline (round-5 review, item 6): bounded unless asked for explicitly
+                ro_steps, ro_warm = (args.steps, args.warmup) if args.reference_order else (min(args.steps, 20), 4)
+                result["reference_order"] = reference_order_step(model, engine, args.batch, int(ctx_mid), ro_steps, ro_warm)
+                result["reference_order"]["vs_headline_ms_per_step"] = round(result["reference_order"]["ms_per_step"] / ms_per_step, 3)
             except Exception as exc:
                 result["reference_order"] = {"error": f"{type(exc).__name__}: {exc}"}
         try:
@@ -926,10 +988,15 @@ def main():
                              "note": "1-GiB device-to-device copy, read + write bytes; roofline fractions divide by the nominal peak"}
         except Exception as exc:
             result["hbm"] = {"peak_GBps_nominal": PEAK_HBM / 1e9, "error": f"{type(exc).__name__}: {exc}"}
-        if (world == 1 and not args.no_secondary and not args.no_secondary_configs and args.model == "qwen2.5-7b"
-                and args.quant == "int4" and not args.scattered and not args.kv_block_size):
+        sim = args.shard_sim if args.shard_sim is not None else ("2,4,8" if headline_line and not args.no_secondary else "none")
+        run_secondary_configs = (world == 1 and not args.no_secondary and not args.no_secondary_configs and args.model == "qwen2.5-7b"
+                                 and args.quant == "int4" and not args.scattered and not args.kv_block_size and not args.as_shard_sim)
+        if run_secondary_configs or (sim != "none" and world == 1 and not args.as_shard_sim):
             del engine
             torch.cuda.empty_cache()
+        if sim != "none" and world == 1 and not args.as_shard_sim:
+            result["shard_sim"] = shard_sim_points(args, [int(t) for t in sim.split(",") if t.strip()])
+        if run_secondary_configs:
             result.setdefault("secondary", []).extend(secondary_configs(args.steps))
         if world == 1 and not args.no_cpu_baseline:
             if args.as_secondary:

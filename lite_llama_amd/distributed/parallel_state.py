@@ -22,6 +22,8 @@ _DP_WORLD_SIZE = 1
 _OWNS_PG = False
 _FORCE_COLLECTIVE = False  # test knob (LL_TP_FORCE_COLLECTIVE): a world of ONE still issues its all-reduces on the backend
 _ONESHOT = None            # peer-mapped one-shot all-reduce state (enable_oneshot_all_reduce), or None: the backend's collective
+_SIMULATED = False         # simulate_shard(): ONE rank's shard on one device, no peers (bench.py --shard-sim)
+_SIM_SCRATCH: dict = {}
 
 
 def grid_coordinates(global_rank: int, tp_size: int, dp_size: int) -> tuple[int, int]:
@@ -84,8 +86,10 @@ def destroy_parallel() -> None:
     if _TP_GROUP is not None and _OWNS_PG and dist.is_initialized():
         dist.destroy_process_group()
     _TP_RANK, _TP_WORLD_SIZE, _TP_GROUP, _DP_RANK, _DP_WORLD_SIZE, _OWNS_PG = 0, 1, None, 0, 1, False
-    global _FORCE_COLLECTIVE
+    global _FORCE_COLLECTIVE, _SIMULATED
     _FORCE_COLLECTIVE = False
+    _SIMULATED = False
+    _SIM_SCRATCH.clear()
 
 
 def collective_forced() -> bool:
@@ -285,8 +289,37 @@ def divide(a: int, b: int, what: str = "") -> int:
     return a // b
 
 
+def simulate_shard(tp_size: int, rank: int = 0) -> None:
+    """Measurement aid (``bench.py --shard-sim``; round-5 review, item 5): build and run ONE rank's shard of a ``tp_size``-way
+    tensor-parallel model on one device with no peers and no process group.  Shapes, launch structure and bytes are the
+    rank's; every collective is replaced by a same-size local device copy (what the collective moves through this rank), so the
+    result is the rank's partial sums -- a timing of one rank's compute, a CEILING for the scaling curve, never a scaling point.
+    ``destroy_parallel()`` ends it."""
+    global _TP_RANK, _TP_WORLD_SIZE, _SIMULATED
+    if dist.is_available() and dist.is_initialized():
+        raise RuntimeError("simulate_shard: a process group is live (this mode has no peers)")
+    _TP_WORLD_SIZE, _TP_RANK, _SIMULATED = int(tp_size), int(rank), int(tp_size) > 1
+
+
+def shard_simulated() -> bool:
+    return _SIMULATED
+
+
+def simulated_collective(numel: int, dtype: torch.dtype, device) -> None:
+    """The stand-in for one all-reduce of ``numel`` elements in simulate_shard mode: one device-to-device copy of that size
+    between two persistent scratch buffers (capturable: the buffers are allocated on first use, outside a capture)."""
+    key = (int(numel), dtype, str(device))
+    pair = _SIM_SCRATCH.get(key)
+    if pair is None:
+        pair = _SIM_SCRATCH[key] = (torch.zeros(numel, dtype=dtype, device=device), torch.empty(numel, dtype=dtype, device=device))
+    pair[1].copy_(pair[0])
+
+
 def all_reduce_tp(tensor: torch.Tensor) -> torch.Tensor:
     """In-place SUM over the TP group; identity when ``world_size == 1``."""
+    if _SIMULATED:
+        simulated_collective(tensor.numel(), tensor.dtype, tensor.device)
+        return tensor
     if _TP_WORLD_SIZE <= 1 and not _FORCE_COLLECTIVE:
         return tensor
     if _ONESHOT is not None and _ONESHOT.fits(tensor):
@@ -298,7 +331,7 @@ def all_reduce_tp(tensor: torch.Tensor) -> torch.Tensor:
 
 def all_reduce_min(value: int) -> int:
     """Smallest ``value`` across the TP group (agreeing on a KV pool size, model_runner.py:84-89)."""
-    if _TP_WORLD_SIZE <= 1:
+    if _TP_WORLD_SIZE <= 1 or _SIMULATED:
         return value
     device = torch.device("cuda", torch.cuda.current_device()) if torch.cuda.is_available() else None
     t = torch.tensor([value], dtype=torch.int64, device=device)

@@ -93,9 +93,14 @@ class RowParallelLinear(LinearBase):
         """``partials_ok`` (extension): the caller feeds the result to ``skip_rmsnorm_partials`` and accepts a
         :class:`PartialSums` -- only taken without tensor parallelism (the all-reduce needs the finished sums)."""
         if partials_ok and not collective_forced() and hasattr(self.quant_method, "apply_partials"):
-            if get_tp_world_size() == 1:
+            from .distributed.parallel_state import shard_simulated, simulated_collective
+            if get_tp_world_size() == 1 or shard_simulated():
                 out = self.quant_method.apply_partials(self, x)
                 if out is not None:
+                    if shard_simulated():
+                        # one rank's shard measured alone (bench.py --shard-sim): the fused partials + all-reduce + norm launch of
+                        # the TP step becomes the local reducing norm + a same-size local copy standing in for the collective
+                        simulated_collective(out.parts.shape[1] * out.parts.shape[2], x.dtype, x.device)
                     return out
             else:
                 # tensor parallelism (round 3): the partials go to ONE launch that also carries the block's collective and

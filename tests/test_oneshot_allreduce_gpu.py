@@ -150,9 +150,13 @@ def test_tp2_decode_over_the_oneshot_kernel_matches_the_backend_collective():
     assert np.array_equal(outs[True][0], outs[False][0])
     np.testing.assert_allclose(outs[True][2], outs[False][2], rtol=1e-2, atol=1e-2)
     # round 3: with the kernel enabled the decode step's row-parallel projections leave split-K partials and ONE launch
-    # does partial sums + all-reduce + add-and-normalise; same roundings in the same places as the three-launch form:
-    # tokens and logits are bit-identical
-    assert np.array_equal(outs[True][1], outs["unfused"][1]) and np.array_equal(outs[True][2], outs["unfused"][2])
+    # does partial sums + all-reduce + add-and-normalise; same roundings in the same places as the three-launch form.
+    # Round 6: the partials of short projections come from the short-stream engine (csrc/gemm_short.hip), whose k-split --
+    # i.e. fp32 summation order -- differs from the finished-output epilogue of the unit loop that the three-launch form runs:
+    # the tokens stay identical, the logits agree to the last bits of the fp16 roundings (they were bit-equal while both
+    # forms shared one k-split)
+    assert np.array_equal(outs[True][1], outs["unfused"][1])
+    np.testing.assert_allclose(outs[True][2], outs["unfused"][2], rtol=2e-3, atol=2e-3)
 
 
 def _fused_worker(rank, world, port, q):
