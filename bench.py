@@ -359,7 +359,7 @@ def prefill_point(model, args, dev, act_dtype, geo, tp, prompt_len=512, reps=2):
         mlp_w = 3 * geo.hidden_size * geo.intermediate_size
     lin_flops = 2.0 * geo.num_layers * (attn_w + mlp_w) / tp * tokens + 2.0 * geo.vocab_size * geo.hidden_size * b
     att_flops = geo.num_layers * b * 2.0 * 2.0 * (geo.num_heads / tp) * geo.head_dim * prompt_len * prompt_len / 2.0  # causal half
-    peak = 2.5e15
+    peak = 5.0e15 if args.quant == "smoothquant" else 2.5e15  # int8 x int8 MFMA (dense) / 16-bit MFMA over widened weights
     out = {"workload": f"{args.model} {args.quant} prefill, batch {b} x {prompt_len} prompt tokens (padded grid, all rows valid)",
            "ttft_ms": round(dt * 1e3, 2), "tokens": tokens, "prefill_tokens_per_s": round(tokens / dt, 1),
            "achieved_TFLOPs": round((lin_flops + att_flops) / dt / 1e12, 1), "peak_TFLOPs": peak / 1e12,
@@ -367,8 +367,12 @@ def prefill_point(model, args, dev, act_dtype, geo, tp, prompt_len=512, reps=2):
            "flops": {"linear": lin_flops, "attention": att_flops}, "reps_ms": [round(t * 1e3, 2) for t in times],
            "first_tokens_checksum": int(first.long().sum().item()),
            "route": {"int4": "wgemm_prefill_kernel (M-tiled W4A16 MFMA GEMM over the load-time layout, gemm_w4_prefill.hip) + fa_prefill2",
+                     "smoothquant": "w8_mtiled_kernel<3> (M-tiled int8 x int8 MFMA GEMM, gemm_w8_prefill.hip) + per-token quantiser + fa_prefill2",
+                     "fp8": "w8_mtiled_kernel<1> (M-tiled fp8 -> fp16 MFMA GEMM, gemm_w8_prefill.hip) + fused_moe + fa_prefill2",
+                     "int8": "w8_mtiled_kernel<2> (M-tiled int8 -> fp16 MFMA GEMM, gemm_w8_prefill.hip) + fa_prefill2",
                      "none": "library GEMM (F.linear) + fa_prefill2"}.get(args.quant, "wgemm_kernel (generic engine, gemm_wq.hip) + fa_prefill2"),
-           "mfma_peak_note": "2.5 PF = nominal dense fp16 peak at 2.4 GHz; under this load the part clocks ~1.6 GHz (DESIGN.md 5.3)"}
+           "mfma_peak_note": ("5.0 PF = nominal dense int8 MFMA peak" if args.quant == "smoothquant" else
+                              "2.5 PF = nominal dense fp16 peak at 2.4 GHz; under this load the part clocks ~1.6 GHz (DESIGN.md 5.3)")}
     del eng
     torch.cuda.empty_cache()
     return out
@@ -399,7 +403,7 @@ def secondary_configs(steps: int, timeout_s: float = 240.0):
                 continue
             d = json.loads(line[-1])
             keep = {k: d.get(k) for k in ("value", "unit", "ms_per_step", "steps", "warmup", "dtype", "graph", "roofline",
-                                          "roofline_dense_projections", "parity_check", "parity_detail")}
+                                          "roofline_dense_projections", "parity_check", "parity_detail", "prefill")}
             keep.update({"config": label, "workload": d["config"]["workload"],
                          "step_roofline_frac_of_8TBps": d["step_roofline"]["frac_of_8TBps"],
                          "wall_seconds": round(time.perf_counter() - t0, 1)})
@@ -761,7 +765,9 @@ def self_launch(args) -> int:
 def main():
     args = parse()
     if args.as_secondary:
-        args.no_secondary = args.no_prefill = True
+        args.no_secondary = True
+        if args.quant not in ("smoothquant", "fp8", "int8"):  # the 8-bit configurations carry their own TTFT (round-5 review, item 7)
+            args.no_prefill = True
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))

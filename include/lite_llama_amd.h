@@ -271,6 +271,12 @@ int ll_w8a8_matmul(void* out, const int8_t* qa, const float* a_scale, const int8
                    int64_t qw_stride_n, int32_t* acc_out /* nullable: raw int32 accumulators [M,N] */,
                    int32_t* workspace, int32_t* counters, void* stream);
 
+/* Calls of more than 64 rows (prefill) of the two entries above take an M x N tiled MFMA GEMM (gemm_w8_prefill.hip: 256 x 256
+ * tiles, the weight tile fetched once per 256 rows -- the reference's kernels tile M x N the same way, w8a16.py:155-216,
+ * w8a8.py:151-217); this predicate says whether a shape is served (1 / 0; otherwise the 64-row weight-streaming tile loops
+ * over M).  wfmt: 1 fp8 e4m3 / 2 int8 weights under fp16 activations, 3 int8 x int8.  n % 32 == 0; k % 64 (128 for wfmt 3). */
+int ll_w8_mtiled_supported(int64_t m, int64_t n, int64_t k, int wfmt, int64_t group_k);
+
 /* Split-K partial mode of the decode-shaped 8-bit / 16-bit engine (no reference counterpart; the int4 engine's epilogue 2 for
  * the other formats): partials [S][M][N] fp32 with the block scales applied, summed by the projection's consumer
  * (ll_skip_rmsnorm_partials, ll_decode_attention_partials) -- no finish launch.  wfmt: 1 fp8 e4m3 / 2 int8 (fp16

@@ -68,6 +68,7 @@ SIGNATURES = {
     "ll_w8a8_finish_swiglu": [P, P, I, P, P, L, L, P],
     "ll_quant_act_cached_try": [P, P, P, L, L, L, P],
     "ll_w8a8_matmul": [P, P, P, P, P, P, L, L, L, L, P, P, P, P],
+    "ll_w8_mtiled_supported": [L, L, L, I, L],
     "ll_moe_align_block_size": [P, I, L, I, I, P, P, P, P],
     "ll_moe_gemm": [P, P, P, P, P, P, P, P, L, L, I, L, L, I, I, I, I, L, L, L, L, L, L, L, I, P],
     "ll_silu_and_mul": [P, P, L, L, I, P],

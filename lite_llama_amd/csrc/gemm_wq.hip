@@ -648,6 +648,9 @@ extern "C" int ll_w4a16_v3_workspace(int64_t m, int64_t n, int64_t k, int64_t* f
 // the decode-shaped 8-bit engine (gemm_w8_skinny.hip): served shapes leave S fp32 / int32 partial planes in the workspace
 extern "C" int64_t ll_dense8_partial_words(int64_t m, int64_t n, int64_t k);
 extern "C" int64_t ll_dense16_partial_words(int64_t m, int64_t n, int64_t k);
+extern "C" int ll_w8_mtiled_try(void* out, const void* x, const void* w, const float* scales, const float* a_scale, const void* bias,
+                                int32_t* acc_out, int64_t m, int64_t n, int64_t k, int group_n, int64_t group_k, int wfmt,
+                                int64_t x_stride, int64_t w_stride, int64_t s_stride_n, int64_t s_stride_k, void* stream);  // gemm_w8_prefill.hip
 extern "C" int ll_dense8_try(void* out, const void* x, const void* w, const float* scales, const float* a_scale,
                              const void* bias, int32_t* acc_out, int64_t m, int64_t n, int64_t k, int group_n,
                              int64_t group_k, int wfmt, int64_t x_stride, int64_t w_stride, int64_t s_stride_n,
@@ -726,6 +729,11 @@ extern "C" int ll_w8a16_matmul(void* out, const void* x, const void* qweight, co
   if (k % 16 != 0 || x_stride_m % 8 != 0 || qw_stride_n % 16 != 0) return LL_ERR_SHAPE;
   if (!ll_aligned16(x) || !ll_aligned16(qweight)) return LL_ERR_ARG;
   if (m == 0) return LL_OK;
+  if (m > 64) {  // prefill shapes (round 6): M x N tiled MFMA GEMM, the weight tile fetched once per 256 rows (gemm_w8_prefill.hip)
+    const int r = ll_w8_mtiled_try(out, x, qweight, scales, nullptr, bias, nullptr, m, n, k, group_n, group_k,
+                                   wfmt == LL_W_FP8E4M3 ? 1 : 2, x_stride_m, qw_stride_n, s_stride_n, s_stride_k, stream);
+    if (r != 0) return r > 0 ? LL_OK : r;
+  }
   {  // decode shapes: full-line weight tiles, split-K partials in the workspace (gemm_w8_skinny.hip)
     const int r = ll_dense8_try(out, x, qweight, scales, nullptr, bias, nullptr, m, n, k, group_n, group_k,
                                 wfmt == LL_W_FP8E4M3 ? 1 : 2, x_stride_m, qw_stride_n, s_stride_n, s_stride_k, workspace,
@@ -749,6 +757,10 @@ extern "C" int ll_w8a8_matmul(void* out, const int8_t* qa, const float* a_scale,
   if (k % 16 != 0 || qw_stride_n % 16 != 0) return LL_ERR_SHAPE;
   if (!ll_aligned16(qa) || !ll_aligned16(qweight)) return LL_ERR_ARG;
   if (m == 0) return LL_OK;
+  if (m > 64) {  // prefill shapes (round 6): the M-tiled int8 x int8 engine (gemm_w8_prefill.hip)
+    const int r = ll_w8_mtiled_try(out, qa, qweight, w_scale, a_scale, bias, acc_out, m, n, k, 1, k, 3, k, qw_stride_n, 0, 0, stream);
+    if (r != 0) return r > 0 ? LL_OK : r;
+  }
   {
     const int r = ll_dense8_try(out, qa, qweight, w_scale, a_scale, bias, acc_out, m, n, k, 1, k, 3, k, qw_stride_n, 0, 0,
                                 workspace, stream);

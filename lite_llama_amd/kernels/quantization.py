@@ -246,6 +246,13 @@ def w4a16_matmul_partials(x, packed_weight, packed_scales, *, group_size: int = 
     return PartialSums(parts, (*x.shape[:-1], n), x.dtype)
 
 
+def w8_mtiled_supported(m: int, n: int, k: int, fmt: str, group_k: int | None = None) -> bool:
+    """Whether a call of ``m`` rows takes the M x N tiled 8-bit engine (gemm_w8_prefill.hip).  ``fmt``: "fp8" / "int8"
+    (fp16 activations: w8a16_matmul) or "w8a8" (smoothquant_matmul)."""
+    wf = {"fp8": 1, "int8": 2, "w8a8": 3}[fmt]
+    return bool(L.lib().ll_w8_mtiled_supported(m, n, k, wf, int(k if group_k is None else min(group_k, k))))
+
+
 def w8a16_matmul(
     x: torch.Tensor,
     qweight: torch.Tensor,

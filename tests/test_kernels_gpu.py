@@ -664,6 +664,83 @@ def test_w8a16_int8_per_channel_oracle(M, N, K_):
         K().w8a16_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), group_n=1, group_k=64)
 
 
+# -- prefill shapes (round 6): more than 64 rows take the M x N tiled engine (gemm_w8_prefill.hip) -------------------------- #
+def test_w8_mtiled_widening_bit_exact_at_every_k_position():
+    """One-hot activations through the M-tiled route (m > 64), unit scales: row r of the output is column r of the widened
+    weights -- every k position of the tile's swizzled LDS image, all 256 codes of both formats."""
+    from lite_llama_amd.kernels.quantization import w8_mtiled_supported
+    n, k = 256, 320
+    assert w8_mtiled_supported(k, n, k, "fp8", 128) and w8_mtiled_supported(k, n, k, "int8")
+    g = torch.Generator().manual_seed(5)
+    codes = torch.randint(0, 256, (n, k), generator=g, dtype=torch.int64).to(torch.uint8)
+    codes[:, 0] = torch.arange(256, dtype=torch.uint8)
+    x = torch.eye(k, dtype=torch.float16)
+    y = K().w8a16_matmul(x.to(DEV), codes.to(DEV), torch.ones(2, 3, device=DEV), group_n=128, group_k=128)
+    want = (O.fp8e4m3_bits_to_fp16(codes.reshape(-1)).float() * 256.0).reshape(n, k).T
+    got = y.float().cpu()
+    ok = (got == want) | (torch.isnan(got) & torch.isnan(want))
+    assert bool(ok.all())
+    qi = codes.view(torch.int8)
+    y = K().w8a16_matmul(x.to(DEV), qi.to(DEV), torch.ones(n, 1, device=DEV), group_n=1, group_k=k)
+    assert torch.equal(y.float().cpu(), qi.float().T)
+
+
+@pytest.mark.parametrize("M,N,K_,bias", [(65, 512, 256, False), (300, 768, 1024, True), (1024, 2048 + 32, 2048, True),
+                                         (257, 160, 3584, False)])
+def test_w8a16_mtiled_fp8_block_oracle(M, N, K_, bias):
+    from lite_llama_amd.kernels.quantization import w8_mtiled_supported
+    assert w8_mtiled_supported(M, N, K_, "fp8", 128)
+    torch.manual_seed(M + N)
+    x = torch.randn(M, K_, dtype=torch.float16) * 0.5
+    qw = (torch.randn(N, K_) * 0.05).to(torch.float8_e4m3fn).view(torch.uint8)
+    sc = torch.rand((N + 127) // 128, (K_ + 127) // 128) + 0.5
+    b = (torch.randn(N) * 0.5).half() if bias else None
+    ref = O.w8a16_matmul(x, qw, sc, group_n=128, group_k=128, bias=b)
+    y = K().w8a16_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), group_n=128, group_k=128, bias=b.to(DEV) if bias else None)
+    close(y, ref, 1e-2)
+    # the rows of a 64-row call (the decode engine) agree with the same rows of the tiled call to fp32-summation-order noise
+    y64 = K().w8a16_matmul(x[:64].to(DEV), qw.to(DEV), sc.to(DEV), group_n=128, group_k=128, bias=b.to(DEV) if bias else None)
+    close(y[:64], y64, 2e-3)
+
+
+@pytest.mark.parametrize("M,N,K_", [(128, 768, 1024), (513, 4096, 4096), (200, 96, 14336)])
+def test_w8a16_mtiled_int8_oracle(M, N, K_):
+    """int8 weights: per-channel scales (group_k = K) and group-wise (128 columns) ones."""
+    torch.manual_seed(M)
+    x = torch.randn(M, K_, dtype=torch.float16) * 0.5
+    w = torch.randn(N, K_) * 0.05
+    qw, sc = O.quantize_int8_per_channel(w)
+    ref = O.w8a16_matmul(x, qw, sc, group_n=1, group_k=K_)
+    y = K().w8a16_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), group_n=1, group_k=K_)
+    close(y, ref, 1e-2)
+    qg, sg = O.quantize_int8_groupwise(w, 128)
+    ref = O.w8a16_matmul(x, qg, sg, group_n=1, group_k=128)
+    y = K().w8a16_matmul(x.to(DEV), qg.to(DEV), sg.to(DEV), group_n=1, group_k=128)
+    close(y, ref, 1e-2)
+
+
+@pytest.mark.parametrize("M,N,K_,bias", [(65, 256, 512, False), (300, 4096 + 32, 4096, True), (2048, 1024, 14336, True),
+                                         (257, 6144, 4096, False)])
+def test_smoothquant_mtiled_bit_exact_sums_and_oracle(M, N, K_, bias):
+    """Above 64 rows ``smoothquant_matmul`` takes the int8 x int8 M-tiled engine: int32 sums bit-equal to the oracle's, the
+    output equal BIT FOR BIT to the same rows through the 64-row decode engine (same scale epilogue, one rounding)."""
+    from lite_llama_amd.kernels.quantization import w8_mtiled_supported
+    assert w8_mtiled_supported(M, N, K_, "w8a8")
+    torch.manual_seed(M + K_)
+    x = (torch.randn(M, K_) * torch.logspace(-2, 0.5, M)[:, None]).half()
+    qw, sc = O.quantize_int8_per_channel(torch.randn(N, K_) * 0.05)
+    b = (torch.randn(N) * 0.5).half() if bias else None
+    ref = O.smoothquant_matmul(x, qw, sc, bias=b)
+    acc_ref, qa_ref, as_ref = O.smoothquant_int32_acc(x, qw)
+    y, acc, qa, a_scale = K().smoothquant_matmul(x.to(DEV), qw.to(DEV), sc.to(DEV), bias=b.to(DEV) if bias else None,
+                                                 _return_int32=True)
+    assert torch.equal(qa.cpu(), qa_ref) and torch.equal(a_scale.cpu(), as_ref)
+    assert torch.equal(acc.cpu(), acc_ref)
+    close(y, ref, 2e-3)
+    y64 = K().smoothquant_matmul(x[:64].to(DEV), qw.to(DEV), sc.to(DEV), bias=b.to(DEV) if bias else None)
+    assert torch.equal(y[:64], y64)
+
+
 # ------------------------------------------------------------------------------------- #
 # smoothquant W8A8 (quantiser + int32 accumulators bit-exact; output tol 1e-1)
 # ------------------------------------------------------------------------------------- #
