@@ -14,7 +14,7 @@ from lite_llama_amd import _lib as L
 dev = "cuda"
 M = int(os.environ.get("M", 64))
 ALL = {
-    "qkv": (4608, 3584), "o": (3584, 3584),
+    "qkv": (4608, 3584), "o": (3584, 3584), "down": (3584, 18944), "gateup": (37888, 3584),
     "qkv_tp2": (2304, 3584), "o_tp2": (3584, 1792), "down_tp8": (3584, 2432), "gateup_tp8": (4736 // 128 * 128, 3584),
     "c5_qkv": (5120, 2048), "c5_o": (2048, 4096), "l3_qkv": (6144, 4096), "l3_o": (4096, 4096),
 }
@@ -53,9 +53,12 @@ for name in names:
     torch.manual_seed(1)
     wbytes = n * k // 2 + n * (k // 128) * 8
     copies = max(2, int(700e6 // wbytes)) if TIME else 1
+    if os.environ.get("COPIES"):  # COPIES=1: the same weights every launch -- they stay in the 256-MB Infinity Cache (what a prefetch would buy)
+        copies = int(os.environ["COPIES"])
     pw, ps = [], []
     ref = None
-    x = torch.randn(M, k, device=dev, dtype=torch.float16)
+    xpad = int(os.environ.get("XPAD", 0))  # XPAD=64: activation rows 128 B further apart (row stride no multiple of 2 KB: L2 channel spread)
+    x = torch.randn(M, k + xpad, device=dev, dtype=torch.float16)[:, :k]
     for c in range(copies):
         qw = torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64, device=dev).to(torch.int32)
         sc = torch.rand(n, k // 128, device=dev) * 0.01 + 0.005
@@ -78,6 +81,8 @@ for name in names:
     if TIME:
         ent["us_ss"] = round(timed(lambda i: Q.w4a16_matmul_partials(x, pw[i], ps[i], group_size=128), copies), 2)
         ent["us_unit"] = round(timed(lambda i: Q.w4a16_matmul_partials(x, pw[i], ps[i], group_size=128, _unit_loop_engine=True), copies), 2)
+    if TIME and os.environ.get("FULL") and n % 64 == 0:  # the same weights as a finished-output fused gate|up launch (row-group engine)
+        ent["us_full_swiglu"] = round(timed(lambda i: Q.w4a16_matmul_prepacked(x, pw[i], ps[i], gate_up_swiglu=True), copies), 2)
     res[name] = ent
     print(name, ent, flush=True)
     del pw, ps

@@ -359,6 +359,20 @@ int ll_moe_sum(void* out, const void* x, int64_t tokens, int top_k, int64_t n, i
  * ids_out int64 [tokens, top_k].  experts <= 1024, top_k <= 64. */
 int ll_moe_route_topk(void* weights_out, int64_t* ids_out, const void* logits, int64_t tokens, int experts,
                       int64_t logits_stride, int top_k, int norm_topk_prob, int dtype, void* stream);
+/* The WHOLE router of a decode batch in-tree (models/qwen3_moe.py:102-111: the unquantised fp16 gate linear + the tail above):
+ * x [tokens, hidden] (row stride x_stride) times gate_w [experts, hidden] (row stride w_stride) as ceil(hidden / 512) split-K fp32
+ * planes in `planes` (ll_moe_router_workspace_floats fp32 of scratch, no zeroing), then the tail reading a token's logits as the
+ * planes' sum rounded once to the activation dtype (what the reference's 16-bit GEMM stores).  tokens <= 64, experts % 32 == 0
+ * (<= 1024), hidden % 128 == 0: ll_moe_router_supported says so (1 / 0); other shapes keep GEMM + ll_moe_route_topk. */
+int ll_moe_router_supported(int64_t tokens, int experts, int64_t hidden);
+int64_t ll_moe_router_workspace_floats(int64_t tokens, int experts, int64_t hidden);
+/* align_block > 0: also moe_align_block_size(ids_out, align_block, experts) -> sorted_ids / expert_ids / num_post (sized as for
+ * ll_moe_align_block_size) -- inside the tail's launch (the last workgroup to arrive at `counter`, one int32 that is zero before
+ * the call and left zero) when the decode-sized align body fits a workgroup, as a following launch otherwise.  0: the four
+ * pointers are ignored. */
+int ll_moe_router(void* weights_out, int64_t* ids_out, const void* x, const void* gate_w, float* planes, int64_t tokens,
+                  int experts, int64_t hidden, int64_t x_stride, int64_t w_stride, int top_k, int norm_topk_prob, int dtype,
+                  int align_block, int32_t* sorted_ids, int32_t* expert_ids, int32_t* num_post, int32_t* counter, void* stream);
 
 /* Decode-step bookkeeping in one launch (executor extension; the reference issues these as
  * separate tensor ops, model_runner.py:200-218 + llm_engine.py:173-213): records the sampled

@@ -75,6 +75,9 @@ SIGNATURES = {
     "ll_silu_and_mul_pairs": [P, P, L, L, I, P],
     "ll_moe_sum": [P, P, L, I, L, I, P],
     "ll_moe_route_topk": [P, P, P, L, I, L, I, I, I, P],
+    "ll_moe_router_supported": [L, I, L],
+    "ll_moe_router_workspace_floats": [L, I, L],
+    "ll_moe_router": [P, P, P, P, P, L, I, L, L, L, I, I, I, I, P, P, P, P, P],
     "ll_argmax": [P, P, L, L, L, I, P],
     "ll_decode_advance": [P, L, P, P, P, P, P, P, P, P, L, L, I, P],
     "ll_slot_advance": [P, P, P, P, P, P, P, L, L, I, I, P],
@@ -102,7 +105,7 @@ SIGNATURES = {
     "ll_argmax_split": [P, P, L, L, L, I, P, I, P],
 }
 
-_RETURNS_I64 = {"ll_kv_alloc_scratch_bytes", "ll_tp_oneshot_flag_words"}
+_RETURNS_I64 = {"ll_kv_alloc_scratch_bytes", "ll_tp_oneshot_flag_words", "ll_moe_router_workspace_floats"}
 _lib = None
 
 

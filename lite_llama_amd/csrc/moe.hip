@@ -121,48 +121,50 @@ __global__ __launch_bounds__(1024) void moe_align_kernel(const void* __restrict_
   }
 }
 
-// Decode-sized batches (<= 1024 slots, <= 1024 experts), round 5: one thread per SLOT.  The stable rank of a slot among the
-// earlier slots of its expert = (same-expert slots in earlier waves) + (same-expert lower lanes of its own wave): the second
-// term comes from wave ballots -- one round per DISTINCT expert present in the wave -- the first from per-(wave, expert)
-// counts in LDS that thread e turns into running offsets while it forms the expert's total.  Four barriers, no atomics, no
-// quadratic scan (the kernel above spends ~64 dependent LDS rounds on the last slot of a 512-slot batch: 12 us per call,
-// 48 calls per Qwen3-30B-A3B step).  Same outputs, bit for bit.
-__global__ __launch_bounds__(1024) void moe_align_small_kernel(const void* __restrict__ topk_ids, int ids_w, int num_slots,
-                                                               int num_experts, int block_size, int32_t* __restrict__ sorted_ids,
-                                                               int32_t* __restrict__ expert_ids, int32_t* __restrict__ num_post,
-                                                               int max_padded, int max_blocks) {
-  extern __shared__ int sm[];  // cw[waves][E] | starts[E] | bends[E]
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6;
-  int* cw = sm;
-  int* starts = sm + nw * num_experts;
+// Decode-sized batches (<= 1024 slots, <= 1024 experts): one thread per SLOT.  Round 6: every expert keeps a BITMAP of the slots
+// that chose it (one 32-bit word per half-wave of slots, filled with one LDS atomic OR per thread -- order-independent); the stable
+// rank of a slot among the earlier slots of its expert is the number of bits below it, an expert's total the number of bits.
+// Four barriers, no serial loop over slots or distinct experts (round 5 ranked with one wave-ballot round per DISTINCT expert of
+// a wave -- ~50 rounds at top-8 of 128 experts: 8 us per call, 48 calls per Qwen3-30B-A3B step; the first form scanned
+// quadratically: 12 us).  Same outputs, bit for bit.
+// COHERENT: the ids were written through by OTHER workgroups of this launch (the fused router, below): int64, read with sc1 loads
+template <bool COHERENT>
+__device__ __forceinline__ void moe_align_small_body(const void* __restrict__ topk_ids, int ids_w, int num_slots, int num_experts,
+                                                     int block_size, int32_t* __restrict__ sorted_ids, int32_t* __restrict__ expert_ids,
+                                                     int32_t* __restrict__ num_post, int max_padded, int max_blocks, int* sm) {
+  // sm: bm[E][2 waves] (32-bit words: which slots of half-wave j chose expert e) | starts[E] | bends[E]
+  // (32-bit on purpose: the dynamic LDS region starts wherever the kernel's static objects end -- a 64-bit DS access there faults)
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6, nthreads = blockDim.x, nw = nthreads >> 6, nh = 2 * nw;
+  unsigned* bm = reinterpret_cast<unsigned*>(sm);
+  int* starts = sm + nh * num_experts;
   int* bends = starts + num_experts;
   __shared__ int wave_tot[16];
   for (int i = tid; i < max_padded; i += nthreads) sorted_ids[i] = num_slots;  // sentinel
-  for (int i = tid; i < nw * num_experts; i += nthreads) cw[i] = 0;
+  for (int i = tid; i < nh * num_experts; i += nthreads) bm[i] = 0u;
   __syncthreads();
   const bool has = tid < num_slots;
-  const int e = has ? moe_clamp_id((int)moe_load_idx(topk_ids, tid, ids_w), num_experts) : -1;
-  int rank = 0;
-  unsigned long long todo = __ballot(has);
-  while (todo) {
-    const int leader = __ffsll((long long)todo) - 1;
-    const int e0 = __builtin_amdgcn_readlane(e, leader);
-    const unsigned long long m = __ballot(has && e == e0);
-    if (e == e0) rank = __popcll(m & ((1ull << lane) - 1ull));
-    if (lane == leader) cw[wave * num_experts + e0] = __popcll(m);
-    todo &= ~m;
+  const int half = tid >> 5;  // this slot's half-wave = its bitmap word
+  int e = -1;
+  if (has) {
+    if constexpr (COHERENT)
+      e = moe_clamp_id((int)__hip_atomic_load((const int64_t*)topk_ids + tid, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT), num_experts);
+    else
+      e = moe_clamp_id((int)moe_load_idx(topk_ids, tid, ids_w), num_experts);
+    atomicOr(bm + e * nh + half, 1u << (tid & 31));  // (an OR: the result does not depend on the order of arrival)
   }
   __syncthreads();
-  // thread t owns expert t: per-wave running offsets, the expert's total, then the padded prefix over the experts
+  // the stable rank of a slot among its expert's slots = bits below it in the expert's bitmap; thread t owns expert t: its total,
+  // then the padded prefix over the experts
+  int rank = 0;
+  if (has) {
+    const unsigned* row = bm + e * nh;
+    for (int j = 0; j < half; ++j) rank += __popc(row[j]);
+    rank += __popc(row[half] & ((1u << (tid & 31)) - 1u));
+  }
   const int t = tid;
   int count = 0;
-  if (t < num_experts) {
-    for (int w = 0; w < nw; ++w) {
-      const int c = cw[w * num_experts + t];
-      cw[w * num_experts + t] = count;
-      count += c;
-    }
-  }
+  if (t < num_experts)
+    for (int j = 0; j < nh; ++j) count += __popc(bm[t * nh + j]);
   const int padded = t < num_experts ? (count + block_size - 1) / block_size * block_size : 0;
   int x = padded;
 #pragma unroll
@@ -180,7 +182,7 @@ __global__ __launch_bounds__(1024) void moe_align_small_kernel(const void* __res
   }
   if (tid == nthreads - 1) num_post[0] = before + x;
   __syncthreads();
-  if (has) sorted_ids[starts[e] + cw[wave * num_experts + e] + rank] = tid;
+  if (has) sorted_ids[starts[e] + rank] = tid;
   for (int b = tid; b < max_blocks; b += nthreads) {  // expert_ids[b] = searchsorted(block_ends, b, right=True) clamped to E-1
     int lo = 0, hi = num_experts;
     while (lo < hi) {
@@ -189,6 +191,19 @@ __global__ __launch_bounds__(1024) void moe_align_small_kernel(const void* __res
     }
     expert_ids[b] = lo < num_experts - 1 ? lo : num_experts - 1;
   }
+}
+
+static size_t moe_align_small_lds(int threads, int num_experts) {
+  return (size_t)(threads / 32) * num_experts * sizeof(unsigned) + (size_t)2 * num_experts * sizeof(int);
+}
+
+__global__ __launch_bounds__(1024) void moe_align_small_kernel(const void* __restrict__ topk_ids, int ids_w, int num_slots,
+                                                               int num_experts, int block_size, int32_t* __restrict__ sorted_ids,
+                                                               int32_t* __restrict__ expert_ids, int32_t* __restrict__ num_post,
+                                                               int max_padded, int max_blocks) {
+  extern __shared__ int sm[];
+  moe_align_small_body<false>(topk_ids, ids_w, num_slots, num_experts, block_size, sorted_ids, expert_ids, num_post, max_padded,
+                              max_blocks, sm);
 }
 
 extern "C" int ll_moe_align_block_size(const void* topk_ids, int ids_width, int64_t num_slots, int num_experts,
@@ -200,13 +215,12 @@ extern "C" int ll_moe_align_block_size(const void* topk_ids, int ids_width, int6
   const int max_blocks = (max_padded + block_size - 1) / block_size;
   static const bool small_off = getenv("LL_MOE_ALIGN_V1") != nullptr;  // A/B knob, read once
   const int small_threads = (int)((num_slots > num_experts ? num_slots : num_experts) + 63) / 64 * 64;
-  // (per-(wave, expert) counts in dynamic LDS: kept inside the 64 KB a launch gets without an opt-in attribute -- 1024 experts x
-  // 1024 slots would need ~72 KB; such shapes take the general kernel)
-  const size_t small_lds = (size_t)(small_threads / 64 * num_experts + 2 * num_experts) * sizeof(int);
+  // (per-(expert, wave) bitmaps in dynamic LDS: kept inside the 64 KB a launch gets without an opt-in attribute; larger shapes
+  // take the general kernel)
+  const size_t small_lds = moe_align_small_lds(small_threads, num_experts);
   if (!small_off && num_slots >= 1 && num_slots <= 1024 && num_experts <= 1024 && small_lds <= 64 * 1024) {
     int threads = small_threads;
-    const int nw = threads / 64;
-    moe_align_small_kernel<<<1, threads, (size_t)(nw * num_experts + 2 * num_experts) * sizeof(int), (hipStream_t)stream>>>(
+    moe_align_small_kernel<<<1, threads, small_lds, (hipStream_t)stream>>>(
         topk_ids, ids_width, (int)num_slots, num_experts, block_size, sorted_ids, expert_ids, num_post, max_padded, max_blocks);
     return LL_LAUNCH_CHECK();
   }
@@ -628,17 +642,14 @@ RT_WAVE_REDUCE(rt_wave_fsum, float, RT_FADD, __float_as_uint, __uint_as_float)
 // The router tail for ONE token on one wave: fp32 softmax over the row, k rounds of (largest remaining probability, lowest
 // expert index among equals), optional renormalisation, cast.  Probabilities are non-negative floats: their bit patterns
 // order like the values; a NaN orders above every finite value (as torch.topk orders it) and still yields a valid index.
-template <int DT, int PER>  // PER = ceil(experts / 64)
-__device__ __forceinline__ void moe_topk_wave(uint16_t* __restrict__ w_out, int64_t* __restrict__ ids_out,
-                                              const uint16_t* __restrict__ logits, int experts, int top_k, int norm, int lane) {
-  float v[PER];
+// v[j] = the logit of expert j * 64 + lane as fp32 (-inf past `experts`)
+// WT: the ids are stored write-through (sc1) -- another workgroup of the same launch reads them (the fused router + align)
+template <int DT, int PER, bool WT = false>  // PER = ceil(experts / 64)
+__device__ __forceinline__ void moe_topk_wave_vals(uint16_t* __restrict__ w_out, int64_t* __restrict__ ids_out, float (&v)[PER],
+                                                   int experts, int top_k, int norm, int lane) {
   float mx = -INFINITY;
 #pragma unroll
-  for (int j = 0; j < PER; ++j) {
-    const int e = j * 64 + lane;
-    v[j] = e < experts ? to_f32<DT>(logits[e]) : -INFINITY;
-    mx = fmaxf(mx, v[j]);
-  }
+  for (int j = 0; j < PER; ++j) mx = fmaxf(mx, v[j]);
   mx = rt_wave_fmax(mx);
   float sum = 0.f;
 #pragma unroll
@@ -676,8 +687,21 @@ __device__ __forceinline__ void moe_topk_wave(uint16_t* __restrict__ w_out, int6
   }
   if (lane < top_k) {
     w_out[lane] = from_f32<DT>(norm ? picked_w / top_sum : picked_w);
-    ids_out[lane] = picked_e;
+    if constexpr (WT) __hip_atomic_store(ids_out + lane, (int64_t)picked_e, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    else ids_out[lane] = picked_e;
   }
+}
+
+template <int DT, int PER>
+__device__ __forceinline__ void moe_topk_wave(uint16_t* __restrict__ w_out, int64_t* __restrict__ ids_out,
+                                              const uint16_t* __restrict__ logits, int experts, int top_k, int norm, int lane) {
+  float v[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int e = j * 64 + lane;
+    v[j] = e < experts ? to_f32<DT>(logits[e]) : -INFINITY;
+  }
+  moe_topk_wave_vals<DT, PER>(w_out, ids_out, v, experts, top_k, norm, lane);
 }
 
 template <int DT, int PER>
@@ -710,3 +734,230 @@ extern "C" int ll_moe_route_topk(void* weights_out, int64_t* ids_out, const void
   return LL_LAUNCH_CHECK();
 }
 
+// ---------------------------------------------------------------------------------- //
+// Router gate in-tree (round 6): lite_llama/models/qwen3_moe.py:102-111 runs ``self.gate(hidden_states)`` -- an unquantised
+// fp16 linear [experts, hidden] -- as a library GEMM (Cijk_* in the step's trace: 10.9 us per layer for 64 x 2048 -> 128 on
+// Qwen3-30B-A3B, 48 layers).  The gate matrix is 0.5 MB: ONE workgroup cannot pull it through its CU in less than ~12 us (the
+// two one-launch routers of round 4), but split along K it is a few KB per workgroup.  Two launches:
+//   (1) moe_gate_partials_kernel: grid (experts / 32, ceil(K / 512)), four waves each: a wave multiplies 32 gate rows x 128 k (the
+//       MFMA A operand) by the <= 64 token rows (B), both straight from global memory in fragment layout (16 bytes per lane and
+//       k-step; a row's eight k-steps are 256 contiguous bytes), 8 x MT MFMA 32x32x16; the four waves meet in LDS in chunk order
+//       and the fp32 tile leaves as plane [slice][token][expert];
+//   (2) the router tail above, reading a token's logits as the sum of the planes in slice order, rounded ONCE to the
+//       activation dtype -- the value the reference's fp16 GEMM stores -- before the fp32 softmax.
+// ---------------------------------------------------------------------------------- //
+typedef __bf16 moe_bf16x8 __attribute__((ext_vector_type(8)));
+template <int DT>
+__device__ __forceinline__ f32x16 moe_mfma32(const Q4& a, const Q4& b, f32x16 c) {
+  if constexpr (DT == LL_F16)
+    return __builtin_amdgcn_mfma_f32_32x32x16_f16(__builtin_bit_cast(f16x8, a), __builtin_bit_cast(f16x8, b), c, 0, 0, 0);
+  else
+    return __builtin_amdgcn_mfma_f32_32x32x16_bf16(__builtin_bit_cast(moe_bf16x8, a), __builtin_bit_cast(moe_bf16x8, b), c, 0, 0, 0);
+}
+
+template <int DT, int MT>
+__global__ __launch_bounds__(256) void moe_gate_partials_kernel(float* __restrict__ planes, const uint16_t* __restrict__ x,
+                                                                const uint16_t* __restrict__ w, int tokens, int experts, int chunks,
+                                                                int64_t x_stride, int64_t w_stride) {
+  __shared__ __attribute__((aligned(16))) f32x4 red[3][MT][4][64];
+  const int rg = (int)blockIdx.x, s = (int)blockIdx.y;
+  const int lane = (int)(threadIdx.x & 63), nl = lane & 31, h = lane >> 5;
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const int c = s * 4 + wv;  // this wave's 128-k chunk of the workgroup's 512-k slice
+  f32x16 acc[MT];
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[mt][e] = 0.f;
+  if (c < chunks) {
+    const uint16_t* wrow = w + (int64_t)(rg * 32 + nl) * w_stride + c * 128 + 8 * h;
+    Q4 a[8], b[MT][8];
+#pragma unroll
+    for (int j = 0; j < 8; ++j) a[j] = *reinterpret_cast<const Q4*>(wrow + 16 * j);
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt) {
+      int tok = mt * 32 + nl;
+      if (tok >= tokens) tok = tokens - 1;  // rows >= tokens feed only unstored outputs
+      const uint16_t* xrow = x + (int64_t)tok * x_stride + c * 128 + 8 * h;
+#pragma unroll
+      for (int j = 0; j < 8; ++j) b[mt][j] = *reinterpret_cast<const Q4*>(xrow + 16 * j);
+    }
+#pragma unroll
+    for (int j = 0; j < 8; ++j)
+#pragma unroll
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = moe_mfma32<DT>(a[j], b[mt][j], acc[mt]);
+  }
+  if (wv > 0) {
+#pragma unroll
+    for (int mt = 0; mt < MT; ++mt)
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        red[wv - 1][mt][g][lane] = f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+  }
+  __syncthreads();
+  if (wv > 0) return;
+  // the four chunks of the slice meet in chunk order; a lane holds, for token nl (+ 32 mt), the gate rows 8 g + 4 h .. + 3 of the 32
+#pragma unroll
+  for (int mt = 0; mt < MT; ++mt) {
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      const f32x4 r0 = red[0][mt][g][lane], r1 = red[1][mt][g][lane], r2 = red[2][mt][g][lane];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[mt][4 * g + e] = ((acc[mt][4 * g + e] + r0[e]) + r1[e]) + r2[e];
+    }
+    const int tok = mt * 32 + nl;
+    if (tok < tokens) {
+      float* dst = planes + ((int64_t)s * tokens + tok) * experts + rg * 32 + 4 * h;
+#pragma unroll
+      for (int g = 0; g < 4; ++g)
+        *reinterpret_cast<f32x4*>(dst + 8 * g) = f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
+    }
+  }
+}
+
+// the tail over planes: logits[e] = DT(sum_s planes[s][tok][e]) (slice order), then moe_topk_wave's arithmetic
+template <int DT, int PER>
+__global__ __launch_bounds__(256) void moe_route_topk_planes_kernel(uint16_t* __restrict__ w_out, int64_t* __restrict__ ids_out,
+                                                                    const float* __restrict__ planes, int slices, int64_t tokens,
+                                                                    int experts, int top_k, int norm) {
+  const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63);
+  const int64_t tok = (int64_t)blockIdx.x * 4 + wv;  // one wave per token
+  if (tok >= tokens) return;
+  float v[PER];
+#pragma unroll
+  for (int j = 0; j < PER; ++j) {
+    const int e = j * 64 + lane;
+    float acc = 0.f;
+    if (e < experts) {
+      const float* src = planes + tok * experts + e;
+      for (int s0 = 0; s0 < slices; s0 += 8) {  // eight loads in flight, summed in slice order (absent slices add an exact zero)
+        float part[8];
+#pragma unroll
+        for (int i = 0; i < 8; ++i) part[i] = s0 + i < slices ? src[(int64_t)(s0 + i) * tokens * experts] : 0.f;
+#pragma unroll
+        for (int i = 0; i < 8; ++i) acc += part[i];
+      }
+    }
+    v[j] = e < experts ? to_f32<DT>(from_f32<DT>(acc)) : -INFINITY;  // the 16-bit logit the reference's GEMM stores
+  }
+  moe_topk_wave_vals<DT, PER>(w_out + tok * top_k, ids_out + tok * top_k, v, experts, top_k, norm, lane);
+}
+
+// The tail over planes AND moe_align_block_size in one launch: one wave per token as above (blockDim / 64 tokens per workgroup), ids
+// written through; the workgroup that arrives LAST at the launch's counter (relaxed agent-scope fetch-add after its own stores have
+// drained; it leaves the counter at zero for the next launch) runs the decode-sized align body over all tokens' ids with coherent
+// loads.  No workgroup waits for another one (no residency assumption).  blockDim >= max(slots, experts).
+template <int DT, int PER>
+__global__ __launch_bounds__(1024) void moe_route_align_kernel(uint16_t* __restrict__ w_out, int64_t* __restrict__ ids_out,
+                                                               const float* __restrict__ planes, int slices, int tokens, int experts,
+                                                               int top_k, int norm, int block_size, int32_t* __restrict__ sorted_ids,
+                                                               int32_t* __restrict__ expert_ids, int32_t* __restrict__ num_post,
+                                                               int max_padded, int max_blocks, int32_t* __restrict__ counter) {
+  extern __shared__ int sm[];
+  __shared__ int is_last;
+  const int wv = (int)(threadIdx.x >> 6), lane = (int)(threadIdx.x & 63), nw = (int)(blockDim.x >> 6);
+  const int tok = (int)blockIdx.x * nw + wv;
+  if (tok < tokens) {
+    float v[PER];
+#pragma unroll
+    for (int j = 0; j < PER; ++j) {
+      const int e = j * 64 + lane;
+      float acc = 0.f;
+      if (e < experts) {
+        const float* src = planes + (int64_t)tok * experts + e;
+        for (int s0 = 0; s0 < slices; s0 += 8) {
+          float part[8];
+#pragma unroll
+          for (int i = 0; i < 8; ++i) part[i] = s0 + i < slices ? src[(int64_t)(s0 + i) * tokens * experts] : 0.f;
+#pragma unroll
+          for (int i = 0; i < 8; ++i) acc += part[i];
+        }
+      }
+      v[j] = e < experts ? to_f32<DT>(from_f32<DT>(acc)) : -INFINITY;
+    }
+    moe_topk_wave_vals<DT, PER, true>(w_out + (int64_t)tok * top_k, ids_out + (int64_t)tok * top_k, v, experts, top_k, norm, lane);
+  }
+  asm volatile("s_waitcnt vmcnt(0)" ::: "memory");  // this wave's ids are out before the counter moves
+  __syncthreads();
+  if (threadIdx.x == 0) {
+    const int old = __hip_atomic_fetch_add(counter, 1, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);
+    is_last = old == (int)gridDim.x - 1;
+    if (is_last) __hip_atomic_store(counter, 0, __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT);  // ready for the next launch
+  }
+  __syncthreads();
+  if (!is_last) return;
+  moe_align_small_body<true>(ids_out, LL_I64, tokens * top_k, experts, block_size, sorted_ids, expert_ids, num_post, max_padded,
+                             max_blocks, sm);
+}
+
+// Shapes the in-tree router serves: decode batches (<= 64 tokens), experts a multiple of 32 (<= 1024), hidden a multiple of 128
+// with at most 64 slices.  1 / 0.
+extern "C" int ll_moe_router_supported(int64_t tokens, int experts, int64_t hidden) {
+  return tokens >= 1 && tokens <= 64 && experts >= 32 && experts <= 1024 && experts % 32 == 0 && hidden >= 128 && hidden % 128 == 0 &&
+                 hidden / 512 <= 64 ? 1 : 0;
+}
+extern "C" int64_t ll_moe_router_workspace_floats(int64_t tokens, int experts, int64_t hidden) {
+  return ll_moe_router_supported(tokens, experts, hidden) ? ((hidden + 511) / 512) * tokens * experts : 0;
+}
+
+// gate GEMM + softmax + top-k + renormalise + cast; planes: ll_moe_router_workspace_floats fp32 of scratch (no zeroing needed)
+extern "C" int ll_moe_router(void* weights_out, int64_t* ids_out, const void* x, const void* gate_w, float* planes, int64_t tokens,
+                             int experts, int64_t hidden, int64_t x_stride, int64_t w_stride, int top_k, int norm_topk_prob,
+                             int dtype, int align_block, int32_t* sorted_ids, int32_t* expert_ids, int32_t* num_post,
+                             int32_t* counter, void* stream) {
+  if (dtype != LL_F16 && dtype != LL_BF16) return LL_ERR_DTYPE;
+  if (!ll_moe_router_supported(tokens, experts, hidden) || top_k < 1 || top_k > 64 || top_k > experts || x_stride < hidden ||
+      w_stride < hidden || x_stride % 8 != 0 || w_stride % 8 != 0)
+    return LL_ERR_SHAPE;
+  if (!weights_out || !ids_out || !x || !gate_w || !planes || !ll_aligned16(x) || !ll_aligned16(gate_w) || !ll_aligned16(planes))
+    return LL_ERR_ARG;
+  hipStream_t st = (hipStream_t)stream;
+  const int slices = (int)((hidden + 511) / 512);
+  const dim3 g1((unsigned)(experts / 32), (unsigned)slices);
+#define LL_GP(DT, MT)                                                                                                        \
+  moe_gate_partials_kernel<DT, MT><<<g1, 256, 0, st>>>(planes, (const uint16_t*)x, (const uint16_t*)gate_w, (int)tokens, experts, \
+                                                       (int)(hidden / 128), x_stride, w_stride)
+  if (dtype == LL_F16) { if (tokens > 32) LL_GP(LL_F16, 2); else LL_GP(LL_F16, 1); }
+  else { if (tokens > 32) LL_GP(LL_BF16, 2); else LL_GP(LL_BF16, 1); }
+#undef LL_GP
+  if (hipGetLastError() != hipSuccess) return LL_ERR_LAUNCH;
+  if (align_block > 0) {
+    // + moe_align_block_size(ids, align_block, experts) of the same launch when the decode-sized align body fits one workgroup
+    if (!sorted_ids || !expert_ids || !num_post || !counter) return LL_ERR_ARG;
+    const int64_t slots = tokens * top_k;
+    const int max_padded = (int)slots + experts * (align_block - 1);
+    const int max_blocks = (max_padded + align_block - 1) / align_block;
+    int threads = (int)((slots > experts ? slots : experts) + 63) / 64 * 64;
+    if (threads < 256) threads = 256;
+    const size_t lds = moe_align_small_lds(threads, experts);
+    static const bool fuse_off = getenv("LL_MOE_ROUTER_NO_FUSED_ALIGN") != nullptr;  // A/B knob, read once
+    if (!fuse_off && threads <= 1024 && lds <= 48 * 1024) {
+      const dim3 g3((unsigned)((tokens + threads / 64 - 1) / (threads / 64)));
+#define LL_RA(DT, PER)                                                                                                             \
+  moe_route_align_kernel<DT, PER><<<g3, threads, lds, st>>>((uint16_t*)weights_out, ids_out, planes, slices, (int)tokens, experts, \
+                                                            top_k, norm_topk_prob, align_block, sorted_ids, expert_ids, num_post,  \
+                                                            max_padded, max_blocks, counter)
+#define LL_RA_P(DT)                                                                   \
+  if (experts <= 64) LL_RA(DT, 1); else if (experts <= 128) LL_RA(DT, 2);             \
+  else if (experts <= 256) LL_RA(DT, 4); else if (experts <= 512) LL_RA(DT, 8); else LL_RA(DT, 16)
+      if (dtype == LL_F16) { LL_RA_P(LL_F16); } else { LL_RA_P(LL_BF16); }
+#undef LL_RA_P
+#undef LL_RA
+      return LL_LAUNCH_CHECK();
+    }
+  }
+  const dim3 g2((unsigned)((tokens + 3) / 4));
+#define LL_TKP(DT, PER)                                                                                                        \
+  moe_route_topk_planes_kernel<DT, PER><<<g2, 256, 0, st>>>((uint16_t*)weights_out, ids_out, planes, slices, tokens, experts, top_k, \
+                                                            norm_topk_prob)
+#define LL_TKP_P(DT)                                                                    \
+  if (experts <= 64) LL_TKP(DT, 1); else if (experts <= 128) LL_TKP(DT, 2);             \
+  else if (experts <= 256) LL_TKP(DT, 4); else if (experts <= 512) LL_TKP(DT, 8); else LL_TKP(DT, 16)
+  if (dtype == LL_F16) { LL_TKP_P(LL_F16); } else { LL_TKP_P(LL_BF16); }
+#undef LL_TKP_P
+#undef LL_TKP
+  if (hipGetLastError() != hipSuccess) return LL_ERR_LAUNCH;
+  if (align_block > 0)
+    return ll_moe_align_block_size(ids_out, LL_I64, tokens * top_k, experts, align_block, sorted_ids, expert_ids, num_post, stream);
+  return LL_OK;
+}

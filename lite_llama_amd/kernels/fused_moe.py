@@ -45,6 +45,11 @@ def _block_m(num_tokens: int) -> int:
     return 64
 
 
+def fused_moe_block_m(num_tokens: int) -> int:
+    """The row-block size :func:`fused_moe` aligns ``num_tokens`` tokens to."""
+    return _block_m(num_tokens)
+
+
 def _wfmt(weight: torch.Tensor, scale) -> int:
     if scale is None:
         return L.LL_W_F16
@@ -91,6 +96,7 @@ def fused_moe(
     w2_group: tuple | None = None,
     slots_ok: bool = False,
     w1_interleaved: bool = False,
+    aligned: tuple | None = None,
 ) -> torch.Tensor:
     """``sum_k w_k * (silu(x W1g^T) * (x W1u^T)) W2^T`` over each token's top-k experts.
 
@@ -100,6 +106,9 @@ def fused_moe(
 
     ``slots_ok`` (extension): return the per-slot rows as a ``SlotSums`` for ``skip_rmsnorm_partials`` instead of running
     ``moe_sum`` (the same values, one launch less).
+
+    ``aligned`` (extension): ``(sorted_token_ids, expert_ids, num_tokens_post_padded, block_m)`` of ``topk_ids`` when the router
+    already produced them (:func:`moe_router` with ``align_block=fused_moe_block_m(num_tokens)``); ignored if ``block_m`` differs.
 
     ``w1_interleaved`` (extension): the rows of ``w1`` (and of its scales) were interleaved at load time -- row ``2j`` =
     ``gate_j``, row ``2j + 1`` = ``up_j`` instead of the stacked halves -- so that ``silu(gate) * up`` runs in the first grouped
@@ -132,7 +141,10 @@ def fused_moe(
     flat_weights = topk_weights.reshape(-1).to(dtype).contiguous()
 
     block_m = _block_m(num_tokens)
-    sorted_ids, expert_ids, num_post = moe_align_block_size(topk_ids, block_m, num_experts)
+    if aligned is not None and aligned[3] == block_m:  # (extension) moe_align_block_size already ran inside the router's launch
+        sorted_ids, expert_ids, num_post = aligned[:3]
+    else:
+        sorted_ids, expert_ids, num_post = moe_align_block_size(topk_ids, block_m, num_experts)
 
     act = torch.empty((num_tokens * top_k, intermediate), device=device, dtype=dtype)
     if w1_interleaved:
@@ -185,3 +197,40 @@ def moe_route_topk(router_logits: torch.Tensor, top_k: int, norm_topk_prob: bool
                                       L.stream_ptr()), "moe_route_topk")
     return w, ids
 
+
+@torch.no_grad()
+def moe_router(x: torch.Tensor, gate_weight: torch.Tensor, top_k: int, norm_topk_prob: bool = True, align_block: int = 0):
+    """Extension (round 6): the WHOLE router of a decode batch without a library GEMM -- ``F.linear(x, gate_weight)`` (the
+    reference's unquantised fp16 gate, models/qwen3_moe.py:102-111) as split-K fp32 planes from a grid of one-wave MFMA
+    workgroups, then :func:`moe_route_topk`'s arithmetic over the planes' sum rounded once to the activation dtype.
+    ``x [tokens, hidden]``, ``gate_weight [experts, hidden]`` of the same 16-bit dtype -> ``(weights [tokens, top_k], ids int64)``;
+    ``None`` when the shape is not served (more than 64 tokens, experts % 32, hidden % 128: the caller keeps GEMM + tail).
+    ``align_block > 0``: a third result ``(sorted_token_ids, expert_ids, num_tokens_post_padded, align_block)`` =
+    ``moe_align_block_size(ids, align_block, experts)`` computed inside the tail's launch (``fused_moe(..., aligned=...)``)."""
+    if (not x.is_cuda or x.dim() != 2 or gate_weight.dim() != 2 or x.dtype not in (torch.float16, torch.bfloat16)
+            or gate_weight.dtype != x.dtype or x.shape[1] != gate_weight.shape[1]):
+        return None
+    t, h = x.shape
+    e = gate_weight.shape[0]
+    if not L.lib().ll_moe_router_supported(t, e, h) or top_k > e or top_k > 64:
+        return None
+    if x.stride(1) != 1 or x.stride(0) % 8 or x.data_ptr() % 16:
+        x = x.contiguous()
+    if gate_weight.stride(1) != 1 or gate_weight.stride(0) % 8 or gate_weight.data_ptr() % 16:
+        return None
+    planes = torch.empty(L.lib().ll_moe_router_workspace_floats(t, e, h), dtype=torch.float32, device=x.device)
+    w = torch.empty((t, top_k), dtype=x.dtype, device=x.device)
+    ids = torch.empty((t, top_k), dtype=torch.int64, device=x.device)
+    aligned, ptrs = None, (None, None, None, None)
+    if align_block > 0:
+        max_padded = t * top_k + e * (align_block - 1)
+        sorted_ids = torch.empty((max_padded,), dtype=torch.int32, device=x.device)
+        expert_ids = torch.empty(((max_padded + align_block - 1) // align_block,), dtype=torch.int32, device=x.device)
+        num_post = torch.empty((1,), dtype=torch.int32, device=x.device)
+        _, counters = L.gemm_workspace(x.device, t, e, h)  # zeroed int32 words every kernel leaves at zero
+        aligned = (sorted_ids, expert_ids, num_post, int(align_block))
+        ptrs = (sorted_ids.data_ptr(), expert_ids.data_ptr(), num_post.data_ptr(), counters.data_ptr())
+    L.check(L.lib().ll_moe_router(w.data_ptr(), ids.data_ptr(), x.data_ptr(), gate_weight.data_ptr(), planes.data_ptr(), t, e, h,
+                                  x.stride(0), gate_weight.stride(0), int(top_k), 1 if norm_topk_prob else 0, L.dtype_code(x.dtype),
+                                  int(align_block), *ptrs, L.stream_ptr()), "moe_router")
+    return (w, ids, aligned) if align_block > 0 else (w, ids)

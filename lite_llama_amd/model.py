@@ -422,6 +422,16 @@ class SparseMoeBlock(nn.Module):
         self.experts = nn.ParameterDict(self.quant_method.create_weights(self))
 
     def _route(self, x):
+        """``(weights, ids, aligned)``: ``aligned`` is ``moe_align_block_size`` of the ids when the router's launch produced it
+        (decode batches: gate GEMM + tail + align in-tree, round 6), else ``None``."""
+        if x.is_cuda and x.shape[0] <= 64 and self.top_k <= 64 and not os.environ.get("LL_MOE_LIBRARY_GATE"):
+            from .kernels.fused_moe import fused_moe_block_m, moe_router
+            routed = moe_router(x, self.gate_weight, self.top_k, self.norm_topk_prob, align_block=fused_moe_block_m(x.shape[0]))
+            if routed is not None:
+                return routed
+        return (*self._route_library_gate(x), None)
+
+    def _route_library_gate(self, x):
         logits = F.linear(x, self.gate_weight)
         if logits.is_cuda and self.num_experts <= 1024 and self.top_k <= 64 and not os.environ.get("LL_MOE_TORCH_ROUTER"):
             from .kernels.fused_moe import moe_route_topk
@@ -437,9 +447,9 @@ class SparseMoeBlock(nn.Module):
         ``SlotSums`` and the ``moe_sum`` launch is skipped."""
         shape = x.shape
         x2 = x.reshape(-1, self.hidden_size)
-        w, ids = self._route(x2)
+        w, ids, aligned = self._route(x2)
         slots = (partials_ok and get_tp_world_size() == 1 and x2.is_cuda and not os.environ.get("LL_MOE_NO_SLOTS"))
-        out = self.quant_method.apply(self, x2, w, ids, slots_ok=True) if slots else self.quant_method.apply(self, x2, w, ids)
+        out = self.quant_method.apply(self, x2, w, ids, slots_ok=bool(slots), aligned=aligned)
         if isinstance(out, PartialSums):
             out.shape = tuple(shape)
             return out

@@ -49,7 +49,7 @@ class MoeQuantMethod(ABC):
     def create_weights(self, block: nn.Module) -> dict: ...
 
     @abstractmethod
-    def apply(self, block, x, topk_weights, topk_ids, slots_ok: bool = False) -> torch.Tensor: ...
+    def apply(self, block, x, topk_weights, topk_ids, slots_ok: bool = False, aligned=None) -> torch.Tensor: ...
 
     def convert_from_fp16(self, block: nn.Module, quant: QuantConfig) -> None:
         raise NotImplementedError(f"{type(self).__name__} cannot be computed from fp16 weights at load time")
@@ -356,9 +356,9 @@ class UnquantizedMoeMethod(MoeQuantMethod):
                                                   block.moe_intermediate_size, dtype=torch.float16), requires_grad=False),
         }
 
-    def apply(self, block, x, topk_weights, topk_ids, slots_ok: bool = False):
+    def apply(self, block, x, topk_weights, topk_ids, slots_ok: bool = False, aligned=None):
         return fused_moe(x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids,
-                         slots_ok=slots_ok, w1_interleaved=getattr(block, "_gu_interleaved", False))
+                         slots_ok=slots_ok, w1_interleaved=getattr(block, "_gu_interleaved", False), aligned=aligned)
 
 
 class W8A16MoeMethod(MoeQuantMethod):
@@ -388,7 +388,7 @@ class W8A16MoeMethod(MoeQuantMethod):
             "down_proj_scale_inv": RawParameter(torch.empty(e, cdiv(d_n, g2n), cdiv(d_k, g2k), dtype=torch.float32)),
         }
 
-    def apply(self, block, x, topk_weights, topk_ids, slots_ok: bool = False):
+    def apply(self, block, x, topk_weights, topk_ids, slots_ok: bool = False, aligned=None):
         q = block.quant
         inter = getattr(block, "_gu_interleaved", False)  # rows paired (gate_j, up_j) at load time: scales are per row then
         if getattr(block, "scale_cut", 0) or (inter and getattr(block, "_gu_scale_rows", 1) > 1):
@@ -399,12 +399,12 @@ class W8A16MoeMethod(MoeQuantMethod):
                 w1_scale=block.experts["gate_up_proj_scale_inv"], w2_scale=block.experts["down_proj_scale_inv"],
                 group_n=q.group_n, group_k=q.group_k, w1_group=(g1n, min(g1[1], block.hidden_size)),
                 w2_group=(g2[0], min(g2[1], block.moe_intermediate_size)) if not getattr(block, "scale_cut", 0) else g2,
-                slots_ok=slots_ok, w1_interleaved=inter,
+                slots_ok=slots_ok, w1_interleaved=inter, aligned=aligned,
             )
         return fused_moe(
             x, block.experts["gate_up_proj"], block.experts["down_proj"], topk_weights, topk_ids,
             w1_scale=block.experts["gate_up_proj_scale_inv"], w2_scale=block.experts["down_proj_scale_inv"],
-            group_n=q.group_n, group_k=min(q.group_k, block.hidden_size), slots_ok=slots_ok, w1_interleaved=inter,
+            group_n=q.group_n, group_k=min(q.group_k, block.hidden_size), slots_ok=slots_ok, w1_interleaved=inter, aligned=aligned,
         )
 
     def convert_from_fp16(self, block, quant):

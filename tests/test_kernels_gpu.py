@@ -1325,6 +1325,58 @@ def test_moe_route_topk_matches_the_reference_router_tail(T, E, k, norm, dt):
     assert sorted(placed[placed < k].tolist()) == list(range(k)) and int(expert_ids.max()) < E
 
 
+@pytest.mark.parametrize("T,E,H,k,norm,dt", [(64, 128, 2048, 8, True, torch.float16), (5, 128, 2048, 8, False, torch.float16),
+                                             (33, 64, 512, 4, True, torch.bfloat16), (1, 32, 128, 2, True, torch.float16),
+                                             (48, 256, 4096, 8, True, torch.float16)])
+def test_moe_router_in_tree_gate_matches_linear_plus_tail(T, E, H, k, norm, dt):
+    """The whole router without a library GEMM (models/qwen3_moe.py:102-111): gate logits from split-K MFMA planes, rounded once
+    to the activation dtype, then the router tail.  Against (a) the fp32 product of the same 16-bit values -> fp32 softmax ->
+    top-k (ids equal wherever the rounded logits leave no near-tie among the selected / first unselected experts, weights within
+    the 16-bit tolerance) and (b) ``F.linear`` + ``moe_route_topk`` on the device."""
+    from lite_llama_amd.kernels.fused_moe import moe_route_topk, moe_router
+
+    g = torch.Generator().manual_seed(T * 31 + E + H)
+    x = (torch.randn(T, H, generator=g) * 0.5).to(dt)
+    gw = (torch.randn(E, H, generator=g) * 0.05).to(dt)
+    out = moe_router(x.to(DEV), gw.to(DEV), k, norm)
+    assert out is not None
+    w, ids = out
+    assert w.dtype == dt and ids.dtype == torch.int64 and w.shape == (T, k)
+    logits = (x.float() @ gw.float().T).to(dt)   # the 16-bit logits the reference's GEMM stores (one rounding of the fp32 sum)
+    probs = torch.softmax(logits.float(), dim=-1)
+    w_ref, id_ref = torch.topk(probs, k, dim=-1)
+    if norm:
+        w_ref = w_ref / w_ref.sum(-1, keepdim=True)
+    # a 16-bit logit may round the other way when the fp32 sum lands near a rounding boundary (summation order): rows whose k + 1
+    # largest probabilities are separated by more than one logit ulp must agree exactly
+    srt = logits.float().sort(-1, descending=True).values
+    ulp = (2.0 ** -10 if dt == torch.float16 else 2.0 ** -7) * srt[:, :1].abs().clamp_min(1.0)
+    clear = ((srt[:, :k] - srt[:, 1:k + 1]).min(-1, keepdim=True).values > 2 * ulp).squeeze(-1)
+    assert int(clear.sum()) >= max(1, T // 2)
+    assert torch.equal(ids.cpu()[clear], id_ref[clear])
+    close(w.float()[clear.to(DEV)], w_ref[clear].to(dt).float(), 4e-3 if dt == torch.float16 else 3.2e-2)
+    ids_c = ids.cpu()
+    assert int(ids_c.min()) >= 0 and int(ids_c.max()) < E and all(len(set(r.tolist())) == k for r in ids_c)
+    w_lib, ids_lib = moe_route_topk(torch.nn.functional.linear(x.to(DEV), gw.to(DEV)), k, norm)
+    assert torch.equal(ids.cpu()[clear], ids_lib.cpu()[clear])
+    # deterministic, and shapes off the grid decline
+    w2, ids2 = moe_router(x.to(DEV), gw.to(DEV), k, norm)
+    assert torch.equal(w2, w) and torch.equal(ids2, ids)
+    # + moe_align_block_size inside the tail's launch (the last workgroup to arrive): the stand-alone kernel's outputs bit for bit,
+    # twice in a row (the launch leaves its counter at zero)
+    from lite_llama_amd.kernels.fused_moe import moe_align_block_size
+    for block in (16, 32):
+        for _ in range(2):
+            w3, ids3, (sorted_ids, expert_ids, n_post, blk) = moe_router(x.to(DEV), gw.to(DEV), k, norm, align_block=block)
+            assert blk == block and torch.equal(w3, w) and torch.equal(ids3, ids)
+            s_ref, e_ref, n_ref = moe_align_block_size(ids, block, E)
+            assert torch.equal(n_post, n_ref) and torch.equal(sorted_ids, s_ref)
+            nb = (int(n_ref) + block - 1) // block
+            assert torch.equal(expert_ids[:nb], e_ref[:nb])
+    assert moe_router(torch.zeros(65, H, dtype=dt, device=DEV), gw.to(DEV), k, norm) is None
+    assert moe_router(x[:, : H - 64].contiguous().to(DEV), gw[:, : H - 64].contiguous().to(DEV), k, norm) is None
+
+
 @pytest.mark.parametrize("M,N,K_", [(1, 128, 64), (7, 516, 192), (32, 1536, 8960), (32, 4100, 1536), (64, 2048, 1536),
                                     (33, 132, 4096), (64, 151936 // 8, 1536)])
 @pytest.mark.parametrize("dt", [torch.float16, torch.bfloat16])
