@@ -19,6 +19,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_debug.h"  // SS_TL / SS_TLC: in-kernel stamps of -DSS_TIMELINE builds (empty in the product build)
 #include "gemm_w4_common.h"
 
 #define SS_CONSUMERS 8
@@ -52,19 +53,6 @@ struct SSParams {
                 float* __restrict__ p_out, int p_x_stride, unsigned long long* p_tl
 #define SS_PASS(P) P.wp, P.sp, P.n, P.chunks, P.gshift, P.kb_base, P.kb_rem, P.RB, P.rb_magic, P.total, P.cap, P.m, P.x, P.out, P.x_stride, P.tl
 
-// debug / timing builds only (tools/build_variant.py): -DSS_TIMELINE stamps, -DSS_ABLATE=bits removes parts of the work
-#ifdef SS_TIMELINE
-#define SS_TL(IDX) if (p_tl && lane == 0) p_tl[((size_t)blockIdx.x * 12 + wv) * 16 + (IDX)] = __builtin_amdgcn_s_memrealtime();
-#define SS_TLC(IDX) if (p_tl && lane == 0) p_tl[((size_t)blockIdx.x * 12 + wv) * 16 + (IDX)] = __builtin_amdgcn_s_memtime();
-#else
-#define SS_TL(IDX)
-#define SS_TLC(IDX)
-#endif
-#ifdef SS_ABLATE
-#define SS_ABL(B) ((SS_ABLATE & (B)) != 0)  // 1: no activation DMA, 2: no weight loads, 4: no dequantisation / MFMA, 8: no exchange / stores
-#else
-#define SS_ABL(B) false
-#endif
 
 __device__ __forceinline__ void ss_barrier() { asm volatile("s_barrier" ::: "memory"); }
 
@@ -125,17 +113,15 @@ __global__ __launch_bounds__(SS_THREADS) void wss_kernel(SS_ARGS) {
       voff[j] = (uint32_t)(row * p_x_stride * 2 + slot * 16);
     }
     const char* xb = (const char*)p_x + (size_t)c_lo * 256;
-    if (!SS_ABL(1)) {
-      if constexpr (EXACT) {
+    if constexpr (EXACT) {
 #pragma unroll
-        for (int c = 0; c < SNC; ++c)
+      for (int c = 0; c < SNC; ++c)
 #pragma unroll
-          for (int j = 0; j < PPL; ++j) v3_dma16<false>((uint32_t)(c * XT + (L * PPL + j) * 1024), xb + (size_t)c * 256, voff[j]);
-      } else {
-        for (int c = 0; c < nC; ++c) {
+        for (int j = 0; j < PPL; ++j) v3_dma16<false>((uint32_t)(c * XT + (L * PPL + j) * 1024), xb + (size_t)c * 256, voff[j]);
+    } else {
+      for (int c = 0; c < nC; ++c) {
 #pragma unroll
-          for (int j = 0; j < PPL; ++j) v3_dma16<false>((uint32_t)(c * XT + (L * PPL + j) * 1024), xb + (size_t)c * 256, voff[j]);
-        }
+        for (int j = 0; j < PPL; ++j) v3_dma16<false>((uint32_t)(c * XT + (L * PPL + j) * 1024), xb + (size_t)c * 256, voff[j]);
       }
     }
     SS_TL(1)
@@ -166,13 +152,8 @@ __global__ __launch_bounds__(SS_THREADS) void wss_kernel(SS_ARGS) {
       const int kk = i * KQ + q;
       const bool valid = (EXACT && i * KQ + KQ - 1 < NKB) || kk < nkb;  // (static for every round but the last)
       const int kb = kb_lo + (valid ? kk : 0);  // pieces past the slice re-read its first one (multiplied by zero)
-      if (SS_ABL(2)) {
-        w[i] = u32x4{0x12345678u + (uint32_t)lane, 0x9abcdef0u, 0x0f1e2d3cu, 0x4b5a6978u};
-        sc[i] = u32x2{0x1c001c00u, 0xa400a400u};
-      } else {
-        w[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (size_t)(uint32_t)kb * 4096 + wl));
-        sc[i] = *reinterpret_cast<const u32x2*>(srow + (size_t)(uint32_t)((kb >> 1) >> p_gshift) * (uint32_t)p_n * 8 + sl);
-      }
+      w[i] = __builtin_nontemporal_load(reinterpret_cast<const u32x4*>(wrow + (size_t)(uint32_t)kb * 4096 + wl));
+      sc[i] = *reinterpret_cast<const u32x2*>(srow + (size_t)(uint32_t)((kb >> 1) >> p_gshift) * (uint32_t)p_n * 8 + sl);
     }
   }
   SS_TL(1)
@@ -207,29 +188,15 @@ __global__ __launch_bounds__(SS_THREADS) void wss_kernel(SS_ARGS) {
       s0 &= keep;
       s1 &= keep;
     }
-#ifdef SS_TIMELINE
-    if (i < 4) {
-      asm volatile("" : "+v"(w[i].x), "+v"(s0));  // piece i has landed
-      SS_TL(3 + 2 * i)
-    }
-#endif
-    if (SS_ABL(4)) {
-      asm volatile("" ::"v"(a[0][0]), "v"(a[3][MT - 1]), "v"(a[1][0]), "v"(a[2][MT - 1]), "v"(w[i]), "v"(s0), "v"(s1));
-    } else {
+    SS_TL_PIECE_LANDED(i, w[i].x, s0)
 #pragma unroll
-      for (int j = 0; j < 4; ++j) {
-        const uint32_t word = j == 0 ? w[i].x : j == 1 ? w[i].y : j == 2 ? w[i].z : w[i].w;
-        const f16x8 wfrag = v3_dequant(word, s0, s1, magic);
+    for (int j = 0; j < 4; ++j) {
+      const uint32_t word = j == 0 ? w[i].x : j == 1 ? w[i].y : j == 2 ? w[i].z : w[i].w;
+      const f16x8 wfrag = v3_dequant(word, s0, s1, magic);
 #pragma unroll
-        for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, a[j][mt], acc[mt], 0, 0, 0);
-      }
+      for (int mt = 0; mt < MT; ++mt) acc[mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, a[j][mt], acc[mt], 0, 0, 0);
     }
-#ifdef SS_TIMELINE
-    if (i < 4) {
-      asm volatile("v_mov_b32 %0, %0" : "+v"(acc[MT - 1][15]));  // ... and has been multiplied
-      SS_TL(4 + 2 * i)
-    }
-#endif
+    SS_TL_PIECE_DONE(i, acc[MT - 1][15])
   };
   f16x8 a0[4][MT], a1[4][MT];
   ss_barrier();  // A
@@ -251,7 +218,7 @@ __global__ __launch_bounds__(SS_THREADS) void wss_kernel(SS_ARGS) {
   // 16-byte slot j of batch row m stored at j ^ ((m >> 1) & 7) (the MFMA-layout writes and the line-layout reads are both
   // conflict-free), summed in wave order, stored as whole 128-byte lines of the plane.
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");  // every consumer has read its last activation fragment
-  if (!SS_ABL(8)) {
+  {
     unsigned char* mine = lds + (size_t)wv * (MT * 32 * 128);
 #pragma unroll
     for (int mt = 0; mt < MT; ++mt) {
@@ -263,15 +230,10 @@ __global__ __launch_bounds__(SS_THREADS) void wss_kernel(SS_ARGS) {
             f32x4{acc[mt][4 * g], acc[mt][4 * g + 1], acc[mt][4 * g + 2], acc[mt][4 * g + 3]};
       }
     }
-  } else {
-    // (operands of at most 128 bits: the host pass of hipcc checks "v" against x86 vector registers and silently drops the kernel's
-    // stub when one does not fit)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) asm volatile("" ::"v"(acc[0][e]), "v"(acc[MT - 1][e]));
   }
   asm volatile("s_waitcnt lgkmcnt(0)\n\ts_barrier" ::: "memory");
   SS_TL(12)
-  if (!SS_ABL(8)) {
+  {
     constexpr int QW = MT * 256 / KQ;  // 16-byte quads of the row group's [MT * 32][32] fp32 output this wave finishes
     float* plane = p_out + (size_t)s * p_m * p_n + (size_t)rg * 32;
 #pragma unroll
@@ -430,9 +392,7 @@ int ss_launch(void* out, const void* x, const void* wpacked, const void* spacked
   p.kb_base = pl.kb_base; p.kb_rem = pl.kb_rem; p.RB = pl.RB; p.total = pl.total; p.cap = pl.cap;
   p.rb_magic = pl.RB > 1 ? (uint32_t)(((1ull << 32) + (uint64_t)pl.RB - 1) / (uint64_t)pl.RB) : 0u;  // exact for item * RB < 2^32
   p.tl = nullptr;
-#ifdef SS_TIMELINE
-  p.tl = getenv("LL_GEMM_SS_TIMELINE") ? (unsigned long long*)strtoull(getenv("LL_GEMM_SS_TIMELINE"), nullptr, 16) : nullptr;
-#endif
+  SS_DEBUG_SET(p)
   hipStream_t st = (hipStream_t)stream;
   const bool two = m > 32;
   // static slice lengths for the headline's two launches (q|k|v: R 4 x 8 blocks; o: R 2 x 14 blocks); everything else reads them

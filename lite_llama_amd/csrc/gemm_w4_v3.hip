@@ -31,6 +31,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_debug.h"  // V3_TL / V3_TLC / V3_TL_FENCE: in-kernel stamps of -DV3_TIMELINE builds (empty in the product build)
 #include "gemm_w4_common.h"
 
 #define V3_BN 128
@@ -62,11 +63,6 @@ struct V3Lds {
   static_assert(BYTES <= 160 * 1024, "LDS");
 };
 #define V3_SPIN_LIMIT (1 << 24)  // ~10 s of polling, then the launch aborts (never a silent partial sum)
-#ifdef V3_ABLATE
-#define V3_ABL(B) ((V3_ABLATE & (B)) != 0)  // debug / timing builds only
-#else
-#define V3_ABL(B) false
-#endif
 
 struct V3Params {
   uint16_t* out;
@@ -89,25 +85,9 @@ struct V3Params {
   uint32_t chunks_magic, gt_magic, upw_magic;  // ceil(2^32 / d): x / d = umulhi(x, magic) for the unit / workgroup indices of a launch (< 2^20)
   int gshift;                  // log2(group_size / 128)
   int epi;                     // 0: out[m, n];  1: rows are (gate_j, up_j) pairs -> out[m, n/2] = swiglu;  2: fp32 split-K partials [slot][m][n]
-#ifdef V3_TIMELINE
-  unsigned long long* tl;  // debug: [workgroup][64] s_memrealtime stamps of wave LL_GEMM3_TL_WAVE (benchmarks/gemm3_timeline.py)
-  int tlwave;
-#endif
+  V3_DEBUG_FIELDS
 };
 
-// debug timeline (-DV3_TIMELINE): 0 entry, 1 ranges decoded, 2 prologue loads issued, 3 first x tile staged + barrier,
-// 4 + u: barrier that ends unit u (u < 40), 50..55 last segment end: begin / exchanged / counter seen / slabs added /
-// stores issued / -, 60 wave done
-#ifdef V3_TIMELINE
-#define V3_TL(IDX) if (p.tl && lane == 0 && wv == p.tlwave) p.tl[(size_t)blockIdx.x * 64 + (IDX)] = __builtin_amdgcn_s_memrealtime();
-#define V3_TLC(IDX) if (p.tl && lane == 0 && wv == p.tlwave) p.tl[(size_t)blockIdx.x * 64 + (IDX)] = __builtin_amdgcn_s_memtime();
-// (timeline builds) pin the step's MFMAs BEFORE the stamp that follows: the accumulators are made opaque to the scheduler
-#define V3_TL_FENCE(CUR) asm volatile("" : "+v"(acc0), "+v"(acc1));
-#else
-#define V3_TL(IDX)
-#define V3_TLC(IDX)
-#define V3_TL_FENCE(CUR)
-#endif
 
 // The workgroup's unit sequence: up to three segments (tail of the last tile, the full tiles, head of the
 // first tile), each a run of consecutive chunks that wraps into the next tile.  A walker keeps (tile, chunk)
@@ -170,10 +150,8 @@ __device__ __forceinline__ void v3_dma_w(uint32_t dw, uint32_t ds, const void* w
       "s_mov_b32 m0, %2\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %8, %13" V3_W_POLICY "\n\t"
       "s_mov_b32 m0, %3\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %9, %13" V3_W_POLICY "\n\t"
       "s_mov_b32 m0, %4\n\ts_nop 0\n\tglobal_load_lds_dwordx4 %10, %13" V3_W_POLICY "\n\t"
-#if !(defined(V3_ABLATE) && (V3_ABLATE & 512))  /* debug: no scale loads */
       "s_mov_b32 m0, %5\n\ts_nop 0\n\tglobal_load_lds_dword %11, %14" V3_S_POLICY "\n\t"
       "s_mov_b32 m0, %6\n\ts_nop 0\n\tglobal_load_lds_dword %12, %14" V3_S_POLICY "\n\t"
-#endif
       "s_mov_b32 m0, %0"
       : "=&s"(keep)
       : "s"(dw), "s"(dw + 1024), "s"(dw + 2048), "s"(dw + 3072), "s"(ds), "s"(ds + 256), "v"(voff[0]), "v"(voff[1]), "v"(voff[2]),
@@ -214,11 +192,7 @@ __device__ __forceinline__ void v3_wait_units(int k) {
   else if (k == 3 || 4 * OPS > 63) v3_vmcnt<3 * OPS>();
   else v3_vmcnt<(4 * OPS > 63 ? 3 : 4) * OPS>();
 }
-#if defined(V3_ABLATE) && (V3_ABLATE & 64)
-__device__ __forceinline__ void v3_barrier() { asm volatile("" ::: "memory"); }  // debug: no unit barriers
-#else
 __device__ __forceinline__ void v3_barrier() { asm volatile("s_barrier" ::: "memory"); }
-#endif
 
 // One loader wave.  KIND 0: weight pieces 4L..4L+3 (1 KB each) + scale quarters 2L, 2L+1 (256 B each) of every
 // unit, V3_DW units ahead into a V3_RW-slot ring.  KIND 1: activation pieces 8L..8L+7 (4 rows x 256 B each),
@@ -227,7 +201,7 @@ template <int KIND, int NF>
 __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int cnt, int lane, int L) {
   using RG = V3Ring<NF>;
   using LD = V3Lds<NF>;
-  constexpr int OPS = KIND == 0 ? (V3_ABL(512) ? 4 : 6) * NF : 8;
+  constexpr int OPS = KIND == 0 ? 6 * NF : 8;
   constexpr int D = KIND == 0 ? RG::DW : RG::DX;
   constexpr int R = KIND == 0 ? RG::RW : RG::RX;
   constexpr int AHEAD = 1 + RG::RA;  // after barrier u the consumers may touch units <= u + AHEAD
@@ -253,7 +227,6 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
   uint32_t dst = KIND == 0 ? LD::OFF_W : LD::OFF_X;  // ring slot the next unit goes to
   auto issue = [&]() {
     if constexpr (KIND == 0) {
-#if !(defined(V3_ABLATE) && (V3_ABLATE & 2))
 #pragma unroll
       for (int f = 0; f < NF; ++f) {  // the tile's 128-row blocks lc.t * NF + f
         const int blk = lc.t * NF + f;
@@ -261,14 +234,11 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
         const char* sb = (const char*)p.sp + (size_t)(uint32_t)(((lc.c >> p.gshift) * (int)p.n + blk * V3_BN) * 8);
         v3_dma_w(dst + f * V3_W_BLOCK + 4 * L * 1024, dst + f * V3_W_BLOCK + 8192 + 2 * L * 256, wb, sb, voff);
       }
-#endif
     } else {
       const char* xb = (const char*)p.x + (size_t)((uint32_t)lc.c * p.x_cstride);
-#if !(defined(V3_ABLATE) && (V3_ABLATE & 1))
       v3_dma_x(dst + 8 * L * 1024, xb, voff);
-#endif
     }
-    if (!V3_ABL(256)) v3_walk_next(lc, q);
+    v3_walk_next(lc, q);
     ++issued;
     if constexpr (KIND == 0) dst = dst + LD::W_SLOT == LD::OFF_W + R * LD::W_SLOT ? LD::OFF_W : dst + LD::W_SLOT;
     else dst = dst + V3_X_SLOT == LD::OFF_X + R * V3_X_SLOT ? LD::OFF_X : dst + V3_X_SLOT;
@@ -295,8 +265,8 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
     const int need = cnt < 1 + AHEAD ? cnt : 1 + AHEAD;
     v3_wait_units<OPS>(issued - need);
     v3_barrier();  // B0
-    if (V3_ABL(128) ? (1 == cnt) : v3_walk_ends(cc)) v3_barrier();  // k-half exchange (128-row tiles: one barrier)
-    if (!V3_ABL(128)) v3_walk_next(cc, q);
+    if (v3_walk_ends(cc)) v3_barrier();  // k-half exchange (128-row tiles: one barrier)
+    v3_walk_next(cc, q);
     u0 = 1;
   }
   for (int u = u0; u < cnt; ++u) {
@@ -309,11 +279,11 @@ __device__ __forceinline__ void v3_loader(const V3Params& p, const V3Seq& q, int
     if (u < 12) { V3_TL(5 + 3 * u) }
     v3_barrier();
     if (u < 12) { V3_TL(6 + 3 * u) }
-    if (V3_ABL(128) ? (u + 1 == cnt) : v3_walk_ends(cc)) {  // the consumers' k-half exchange: 1 barrier, or 3 for 256-row tiles with two batch halves
+    if (v3_walk_ends(cc)) {  // the consumers' k-half exchange: 1 barrier, or 3 for 256-row tiles with two batch halves
       const int nb = NF == 1 ? 1 : (p.m > 32 ? 3 : 1);
       for (int f = 0; f < nb; ++f) v3_barrier();
     }
-    if (!V3_ABL(128)) v3_walk_next(cc, q);
+    v3_walk_next(cc, q);
   }
 }
 
@@ -696,32 +666,18 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       o.w[f] = *reinterpret_cast<const u32x4*>(wb + f * V3_W_BLOCK + w_off);
       o.s[f] = *reinterpret_cast<const u32x2*>(wb + f * V3_W_BLOCK + s_off);
     }
-#if defined(V3_ABLATE) && (V3_ABLATE & 32)
-    if (done > 0) return;  // debug: fragments read once
-#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j)
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) o.a[j][mt] = *reinterpret_cast<const f16x8*>(xb + x_off[j] + mt * 32 * 256);
   };
   auto compute = [&](const V3Ops<MT, NF>& o) {
-#if defined(V3_ABLATE) && (V3_ABLATE & 4)
-    asm volatile("" ::"v"(o.a[0][0]), "v"(o.a[3][MT - 1]), "v"(o.w[0]), "v"(o.s[0]), "v"(o.w[NF - 1]));
-    return;
-#endif
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
 #pragma unroll
       for (int f = 0; f < NF; ++f) {
         const uint32_t word = j == 0 ? o.w[f].x : j == 1 ? o.w[f].y : j == 2 ? o.w[f].z : o.w[f].w;
-#if defined(V3_ABLATE) && (V3_ABLATE & 8)
-        const f16x8 wfrag = __builtin_bit_cast(f16x8, u32x4{word, word ^ o.s[f].x, word ^ o.s[f].y, word + magic});  // debug: no dequant
-#else
         const f16x8 wfrag = v3_dequant(word, o.s[f].x, o.s[f].y, magic);
-#endif
-#if defined(V3_ABLATE) && (V3_ABLATE & 16)
-        asm volatile("" ::"v"(wfrag), "v"(o.a[j][0]), "v"(o.a[j][MT - 1]));  // debug: no MFMA
-#else
         if (f == 0) {
           acc0 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, o.a[j][0], acc0, 0, 0, 0);
           if constexpr (MT == 2) acc1 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, o.a[j][1], acc1, 0, 0, 0);
@@ -729,7 +685,6 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
           acc2 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, o.a[j][0], acc2, 0, 0, 0);
           if constexpr (MT == 2) acc3 = __builtin_amdgcn_mfma_f32_32x32x16_f16(wfrag, o.a[j][1], acc3, 0, 0, 0);
         }
-#endif
       }
     }
   };
@@ -747,9 +702,9 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     compute(opA);
     v3_barrier();  // B0
     V3_TL(4)
-    const bool se0 = V3_ABL(128) ? (1 == cnt) : v3_walk_ends(cc);
+    const bool se0 = v3_walk_ends(cc);
     if (se0) segment_end(cc.t, seg_lo, cc.c);
-    if (!V3_ABL(128)) v3_walk_next(cc, q);
+    v3_walk_next(cc, q);
     if (se0) seg_lo = cc.c;
     done = 1;
     if (done < cnt) {
@@ -779,9 +734,9 @@ __global__ __launch_bounds__(V3_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     if (done == 5) { V3_TLC(47) }                                                           \
     if (done < 40) { V3_TL(4 + done) }                                                      \
     if (pending) post_pending(); /* the previous segment's slab stores are a unit old */    \
-    const bool se_ = V3_ABL(128) ? (done + 1 == cnt) : v3_walk_ends(cc);                    \
+    const bool se_ = v3_walk_ends(cc);                                                      \
     if (se_) segment_end(cc.t, seg_lo, cc.c);                                               \
-    if (!V3_ABL(128)) v3_walk_next(cc, q);                                                  \
+    v3_walk_next(cc, q);                                                  \
     if (se_) seg_lo = cc.c;                                                                 \
     if (done == 5) { V3_TLC(48) }                                                           \
     ++done;                                                                                 \
@@ -1117,10 +1072,7 @@ static int v3_launch(void* out, const void* x, const void* wpacked, const void* 
   p.chunks_magic = magic(pl.chunks);
   p.gt_magic = magic(pl.gt);
   p.upw_magic = magic(pl.upw);
-#ifdef V3_TIMELINE
-  p.tlwave = getenv("LL_GEMM3_TL_WAVE") ? atoi(getenv("LL_GEMM3_TL_WAVE")) : 0;
-  p.tl = getenv("LL_GEMM3_TIMELINE") ? (unsigned long long*)strtoull(getenv("LL_GEMM3_TIMELINE"), nullptr, 16) : nullptr;
-#endif
+  V3_DEBUG_SET(p)
   int sh = 0;
   while ((128 << sh) < group_size) ++sh;
   p.gshift = sh;

@@ -20,6 +20,7 @@
 #include <stdlib.h>
 
 #include "common.h"
+#include "gemm_debug.h"  // V4_TL: in-kernel stamps of -DV4_TIMELINE builds (empty in the product build)
 #include "gemm_w4_common.h"
 
 #define V4_THREADS 768
@@ -47,17 +48,6 @@
 #define V4_AHEAD 2  // after the barrier that ends unit u the consumers may touch units <= u + V4_AHEAD
 #endif
 
-#ifdef V4_ABLATE  // debug / timing builds only: 1 no dequant + MFMA, 2 no operand reads either, 4 no weight DMA, 8 no activation DMA,
-                  // 16 no dequantisation (MFMA on raw words), 32 no MFMA (dequantisation kept)
-#define V4_ABL(B) ((V4_ABLATE & (B)) != 0)
-#else
-#define V4_ABL(B) false
-#endif
-#ifdef V4_TIMELINE  // debug: p.tl[(workgroup * 8 + wave) * 64 + idx] = s_memtime (shader clock); benchmarks/gemm4_timeline.py
-#define V4_TL(IDX) if (p.tl && lane == 0) p.tl[((size_t)blockIdx.x * 12 + wv) * 64 + (IDX)] = __builtin_amdgcn_s_memtime();
-#else
-#define V4_TL(IDX)
-#endif
 
 template <int NRGT>
 struct V4Lds {
@@ -88,9 +78,7 @@ struct V4Params {
   int rbase, rrem;  // tile t owns row groups [t * rbase + min(t, rrem), + rbase + (t < rrem))
   int cbase, crem;  // slice j owns chunks likewise
   int xw_peers;     // > 0: workgroups per XCD that share a k-slice of the activations (L2 warm-up reads at entry); 0: none
-#ifdef V4_TIMELINE
-  unsigned long long* tl;
-#endif
+  V4_DEBUG_FIELDS
 };
 
 __device__ __forceinline__ void v4_barrier() { asm volatile("s_barrier" ::: "memory"); }
@@ -127,9 +115,7 @@ __global__ __launch_bounds__(V4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   const int cnt = p.cbase + (slice < p.crem ? 1 : 0);
   if (cnt <= 0 || nrg <= 0) return;
   V4_TL(0)
-#ifdef V4_TIMELINE
-  if (p.tl && lane == 0) p.tl[((size_t)blockIdx.x * 12 + wv) * 64 + 62] = __builtin_amdgcn_s_memrealtime();
-#endif
+  V4_TL_REAL(62)
 
   if (wv >= 8) {
     // ======================================== loaders ======================================== //
@@ -188,8 +174,8 @@ __global__ __launch_bounds__(V4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       if (wl) {
 #pragma unroll
         for (int r = 0; r < NRGT; ++r)
-          if (r < nrg && !V4_ABL(4)) v3_dma16<(V3_NT_W & 1) != 0>(dst + (L * NRGT + r) * 1024, base, voff[r]);
-        if (L && !V4_ABL(4)) {
+          if (r < nrg) v3_dma16<(V3_NT_W & 1) != 0>(dst + (L * NRGT + r) * 1024, base, voff[r]);
+        if (L) {
           sbase = (const char*)p.sp + ((size_t)(c >> p.gshift) * (size_t)p.n + (size_t)rg0 * 32) * 8;
           if (nrg >= 4) {
             v3_dma16<false>(dst + LD::W_BYTES, sbase, (uint32_t)(lane * 16));
@@ -207,7 +193,7 @@ __global__ __launch_bounds__(V4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
         constexpr int XP = 4 * MT;
 #pragma unroll
         for (int j = 0; j < XP; ++j)
-          if (!V4_ABL(8)) v3_dma16<false>(dst + (XP * L + j) * 1024, base, voff[j]);
+          v3_dma16<false>(dst + (XP * L + j) * 1024, base, voff[j]);
         base += 256;
       }
       ++c;
@@ -278,7 +264,6 @@ __global__ __launch_bounds__(V4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       u32x2 s[NR];
     };
     auto read_ws = [&](Ops& o, int wslot) {
-      if (V4_ABL(2)) return;
 #pragma unroll
       for (int r = 0; r < NR; ++r) {
         o.w[r] = *reinterpret_cast<const u32x2*>(lds + wslot + w_off + r * 1024);
@@ -286,27 +271,17 @@ __global__ __launch_bounds__(V4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       }
     };
     auto read_x = [&](f16x8 (&xf)[MT], int xslot, int jj) {
-      if (V4_ABL(2)) return;
 #pragma unroll
       for (int mt = 0; mt < MT; ++mt) xf[mt] = *reinterpret_cast<const f16x8*>(lds + xslot + x_off[jj] + mt * 32 * 256);
     };
     auto dq = [&](const Ops& o, int i) -> f16x8 {  // item i = jj * NR + r
       const int jj = i / NR, r = i % NR;
       const uint32_t word = jj == 0 ? o.w[r].x : o.w[r].y;
-      if (V4_ABL(16)) return __builtin_bit_cast(f16x8, u32x4{word, word ^ o.s[r].x, word ^ o.s[r].y, word + magic});
       return v3_dequant(word, o.s[r].x, o.s[r].y, magic);
     };
     int ws_cur = LD::OFF_W, xs_cur = LD::OFF_X;
     Ops opA, opB;
     f16x8 x0[MT], x1[MT];
-    if (V4_ABL(2)) {
-#pragma unroll
-      for (int r = 0; r < NR; ++r) opA.w[r] = opA.s[r] = opB.w[r] = opB.s[r] = u32x2{0u, 0u};
-#pragma unroll
-      for (int mt = 0; mt < MT; ++mt)
-#pragma unroll
-        for (int e = 0; e < 8; ++e) x0[mt][e] = x1[mt][e] = (f16)0.f;
-    }
     v4_barrier();  // P0: units 0 and 1 have landed
     V4_TL(1)
     read_ws(opA, ws_cur);
@@ -322,29 +297,19 @@ __global__ __launch_bounds__(V4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
       read_x(x1, xs_cur, 1);                                                                                \
       read_ws(NXT, ws_n);                                                                                   \
       f16x8 wf[2];                                                                                          \
-      if (!V4_ABL(1 | 2)) wf[0] = dq(CUR, 0);                                                               \
+      wf[0] = dq(CUR, 0);                                                                                   \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
       _Pragma("unroll") for (int i = 0; i < NI; ++i) {                                                      \
-        if (V4_ABL(1 | 2)) break;                                                                           \
         if (i + 1 < NI) wf[(i + 1) & 1] = dq(CUR, i + 1);                                                   \
         if (i == NR) read_x(x0, xs_n, 0); /* the next unit's first fragments: k-step 0's last use of x0 was item NR - 1 */   \
-        if (!V4_ABL(32)) {                                                                                  \
-          _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                 \
-            acc[i % NR][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i & 1], i < NR ? x0[mt] : x1[mt], acc[i % NR][mt], 0, 0, 0); \
-        } else {                                                                                            \
-          asm volatile("" ::"v"(wf[i & 1]), "v"(x0[0]), "v"(x1[MT - 1]));                                   \
-        }                                                                                                   \
+        _Pragma("unroll") for (int mt = 0; mt < MT; ++mt)                                                   \
+          acc[i % NR][mt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf[i & 1], i < NR ? x0[mt] : x1[mt], acc[i % NR][mt], 0, 0, 0); \
         if (i + 1 < NI) {                                                                                   \
           _Pragma("unroll") for (int mt = 0; mt < MT; ++mt) {                                               \
             __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);      /* one MFMA of item i */                \
             __builtin_amdgcn_sched_group_barrier(0x002, 14 / MT, 0); /* its share of item i + 1's dequantisation */ \
           }                                                                                                 \
         }                                                                                                   \
-      }                                                                                                     \
-      if (V4_ABL(1 | 2) && !V4_ABL(2)) {                                                                    \
-        _Pragma("unroll") for (int r = 0; r < NR; ++r) asm volatile("" ::"v"(CUR.w[r]), "v"(CUR.s[r]));     \
-        asm volatile("" ::"v"(x0[0]), "v"(x1[0]));                                                          \
-        read_x(x0, xs_n, 0);                                                                                \
       }                                                                                                     \
       __builtin_amdgcn_sched_barrier(0);                                                                    \
       v4_barrier();                                                                                         \
@@ -467,9 +432,7 @@ __global__ __launch_bounds__(V4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
     }
   }
   V4_TL(61)
-#ifdef V4_TIMELINE
-  if (p.tl && lane == 0) p.tl[((size_t)blockIdx.x * 12 + wv) * 64 + 63] = __builtin_amdgcn_s_memrealtime();
-#endif
+  V4_TL_REAL(63)
 }
 
 // ---------------------------------------------------------------------------------- //
@@ -580,9 +543,7 @@ int v4_launch(void* out, const void* x, const void* wpacked, const void* spacked
   }
   if (p.ks < 1 || p.ks > p.chunks) return LL_ERR_SHAPE;
   p.cbase = p.chunks / p.ks; p.crem = p.chunks % p.ks;
-#ifdef V4_TIMELINE
-  p.tl = getenv("LL_GEMM4_TIMELINE") ? (unsigned long long*)strtoull(getenv("LL_GEMM4_TIMELINE"), nullptr, 16) : nullptr;
-#endif
+  V4_DEBUG_SET(p)
   const int grid = ntiles * p.ks;
   p.xw_peers = (p.ks == 1 || p.ks == 2 || p.ks == 4 || p.ks == 8) && grid % 8 == 0 ? grid / 8 : 0;
   hipStream_t st = (hipStream_t)stream;
