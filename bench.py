@@ -372,7 +372,7 @@ def prefill_point(model, args, dev, act_dtype, geo, tp, prompt_len=512, reps=2):
                      "int8": "w8_mtiled_kernel<2> (M-tiled int8 -> fp16 MFMA GEMM, gemm_w8_prefill.hip) + fa_prefill2",
                      "none": "library GEMM (F.linear) + fa_prefill2"}.get(args.quant, "wgemm_kernel (generic engine, gemm_wq.hip) + fa_prefill2"),
            "mfma_peak_note": ("5.0 PF = nominal dense int8 MFMA peak" if args.quant == "smoothquant" else
-                              "2.5 PF = nominal dense fp16 peak at 2.4 GHz; under this load the part clocks ~1.6 GHz (DESIGN.md 5.3)")}
+                              "2.5 PF = nominal dense fp16 peak at 2.4 GHz; under this load the part clocks ~1.6 GHz (DESIGN_NOTEBOOK.md 5.3)")}
     del eng
     torch.cuda.empty_cache()
     return out

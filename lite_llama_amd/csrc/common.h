@@ -118,7 +118,7 @@ __device__ __forceinline__ float wave_max(float v) {
 // Round 4: the hardware exp2 and reciprocal (v_exp_f32, v_rcp_f32: 1 ulp each -- an order below the fp16 rounding of the
 // product that follows; swiglu.py:45-65 computes tl.sigmoid in fp32 and Triton lowers it to the same two approximations)
 // instead of libm expf + an IEEE division: ~35 dependent VALU operations per value, 2.6 us of the fused gate|up launch's
-// tail (in-kernel stamps).  Saturates correctly: exp2(+big) = inf -> 0, exp2(-big) = 0 -> 1; NaN stays NaN.
+// tail (in-kernel stamps, DESIGN_NOTEBOOK.md 4.3).  Saturates correctly: exp2(+big) = inf -> 0, exp2(-big) = 0 -> 1; NaN stays NaN.
 __device__ __forceinline__ float ll_sigmoidf(float v) {
   return __builtin_amdgcn_rcpf(1.0f + __builtin_amdgcn_exp2f(v * -1.44269504088896341f));
 }

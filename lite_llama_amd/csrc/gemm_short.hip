@@ -303,7 +303,7 @@ static int ss_max_chunks(int kbs, int S) {
 }
 
 // The plan: (R row groups per item, S k-slices) that minimises a three-term estimate -- a CU's share of the weight stream at the
-// chip's HBM rate, its k-slice of the activation matrix at the L2 -> CU rate (the two add: one path into the CU),
+// chip's HBM rate, its k-slice of the activation matrix at the L2 -> CU rate (the two add: one path into the CU, DESIGN_NOTEBOOK.md 4.2),
 // and the S planes the consumer launch reads back.  One workgroup per CU, one round of workgroups.
 static SSPlan ss_plan(int64_t m, int64_t n, int64_t k, int group_size) {
   SSPlan best;
@@ -327,7 +327,7 @@ static SSPlan ss_plan(int64_t m, int64_t n, int64_t k, int group_size) {
       if (pw > 8) continue;
       const int mc = ss_max_chunks(kbs, S);
       if (mc > SS_MAX_CHUNKS) continue;
-      // Measured on MI355X (benchmarks/gemm_short.py): a CU's share of the weight stream arrives at the chip's
+      // Measured on MI355X (benchmarks/gemm_short.py, DESIGN_NOTEBOOK.md 4.6): a CU's share of the weight stream arrives at the chip's
       // HBM rate (~27 KB / us / CU), its activation slice at ~100 KB / us, its planes leave at ~25 KB / us (the dirty bytes are
       // written back at the kernel boundary), and every plane costs the consumer launch ~0.15 us.
       const int slots = ((pw + 1) / 2) * 2 * KQ;                        // pieces multiplied per row group (incl. zeroed ones)
@@ -355,7 +355,7 @@ int ss_partials_slices(int64_t m, int64_t n, int64_t k, int group_size) {
   return pl.ok ? pl.S : 0;
 }
 
-// Host-side introspection (tests; no device work): [0] 1 if the engine takes the split-K partial launch, [1] grid,
+// Host-side introspection (tests, DESIGN_NOTEBOOK.md; no device work): [0] 1 if the engine takes the split-K partial launch, [1] grid,
 // [2] R, [3] S, [4] pieces per wave (template bound), [5] k-blocks per slice (base), [6] slices with one more, [7] LDS bytes.
 extern "C" int ll_w4a16_short_plan(int64_t m, int64_t n, int64_t k, int group_size, int32_t* out8) {
   if (!out8) return LL_ERR_ARG;

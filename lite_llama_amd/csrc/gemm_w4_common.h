@@ -25,7 +25,7 @@ __device__ __forceinline__ uint32_t v3_and_or(uint32_t w, uint32_t mask, uint32_
 // position i and nibble 2i+1 at position 4+i).  Exact unpack: (w & 0x000F000F) | 0x6400 = (1024 + q_i,
 // 1024 + q_{4+i}); the offset is removed exactly, then ONE fp16 fma with (s, -z*s): the same arithmetic as
 // gemm_wq.hip.  Error against the reference's fp16(fp32((q - z) * s)): <= 3 fp16 ulps of the
-// weight (roundings of s, of z*s and of the fma), stated in DESIGN.md.
+// weight (roundings of s, of z*s and of the fma), stated in DESIGN_NOTEBOOK.md.
 __device__ __forceinline__ f16x8 v3_dequant(uint32_t w, uint32_t s, uint32_t nzs, uint32_t magic) {
   const uint32_t w2 = w >> 8;
   uint32_t a = v3_and_or(w, 0x000F000Fu, magic);

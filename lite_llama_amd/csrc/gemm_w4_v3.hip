@@ -3,7 +3,7 @@
 // lite_llama/models/quantization/_layout/__init__.py:1-6.  Semantics: lite_llama/kernels/quantization/w4a16.py:28-207
 // (out[m, n] = sum_k x[m, k] * (nib(n, k) - z[n, k/g]) * s[n, k/g] (+ bias), fp32 accumulation, fp16 out).
 //
-// Structure (what round 2 measured is in DESIGN.md 4.1; short form):
+// Structure (what round 2 measured is in DESIGN_NOTEBOOK.md 4.1; short form):
 //   * unit = 128 weight rows x 128 k; stream-K / tile-group split with static tile ownership (tail segment
 //     first, head segment last; write-through slabs + counters; waits only point at lower-numbered
 //     workgroups);
@@ -179,7 +179,7 @@ __device__ __forceinline__ void v3_dma_x(uint32_t dx, const void* xb, const uint
       : "memory");
 }
 // Units a loader may request between the prologue barrier P0 and the barrier that ends unit 0 (the consumers wait there for
-// the loaders' ISSUE of these requests, ~0.65 us per unit and loader wave): A/B knob, see DESIGN.md 4.3
+// the loaders' ISSUE of these requests, ~0.65 us per unit and loader wave): A/B knob, see DESIGN_NOTEBOOK.md 4.3
 #ifndef V3_START_FILL
 #define V3_START_FILL 8
 #endif
@@ -881,7 +881,7 @@ struct V3Knobs {
   int fill = 85;  // ... when the launch still fills this percentage of the CUs (LL_GEMM3_FILL)
   int short_k_xcd = 8;   // LL_GEMM3_SHORTK_XCD: the same cap for projections with a SHORT contraction (<= 32 chunks) and <= 32 tiles
                          // (the attention output projection): fewer k-slices = fewer fp32 planes for the add-and-normalise that
-                         // follows, at a GEMM that fills fewer CUs -- A/B knob of the round-4 review's "4-plane o" 
+                         // follows, at a GEMM that fills fewer CUs -- A/B knob of the round-4 review's "4-plane o" (DESIGN_NOTEBOOK.md 4.5)
   V3Knobs() {
     if (const char* e = getenv("LL_GEMM3_XCD")) xcd = atoi(e);
     if (const char* e = getenv("LL_GEMM3_FILL")) fill = atoi(e);
@@ -1005,7 +1005,7 @@ extern "C" int ll_w4a16_partials_count(int64_t m, int64_t n, int64_t k, int grou
 }
 
 // The launch plan of ll_w4a16_matmul_prepacked for (n, k, epilogue) as 16 ints -- host-side introspection for tests and
-// DESIGN.md (no device work): [0] grid, [1] 128-row blocks per tile, [2] tiles, [3] chunks, [4] slab slots, [5] gt, [6] gbase,
+// DESIGN_NOTEBOOK.md (no device work): [0] grid, [1] 128-row blocks per tile, [2] tiles, [3] chunks, [4] slab slots, [5] gt, [6] gbase,
 // [7] grem, [8] glead, [9] xcd_shift, [10] upw, [11..14] 0 (reserved), [15] compute units assumed.
 extern "C" int ll_w4a16_v3_plan(int64_t m, int64_t n, int64_t k, int group_size, int epilogue, int32_t* out16) {
   if (!out16) return LL_ERR_ARG;

@@ -2,7 +2,7 @@
 // (ll_w4a16_pack_weights / ll_w4a16_pack_scales) and the same C entry (ll_w4a16_matmul_prepacked) as gemm_w4_v3.hip;
 // reference: lite_llama/kernels/quantization/w4a16.py:28-207, fused epilogue kernels/swiglu.py:45-65.
 //
-// What changed against the third generation, and why:
+// What changed against the third generation, and why (DESIGN_NOTEBOOK.md 4.5):
 //   * DECOMPOSITION.  A workgroup owns NRG consecutive 32-row groups of the weight matrix (4 or 5 for the fused gate|up:
 //     1184 groups over 256 CUs) and a contiguous range of 128-k chunks -- ALL of K for the launches that write finished
 //     outputs.  No stream-K: no fp32 slabs written and read back (128 KB per CU and launch), no merge counters, no owner
@@ -14,7 +14,7 @@
 //     43 KB per 160-row unit here).  The accumulators stay in their wave for the whole launch; the four k-quarters meet once,
 //     at the end, through the LDS the rings no longer need.  (A first form with FOUR consumer waves, one per SIMD, all row groups
 //     each -- no redundancy at all -- measured compute-bound: one wave issues ~200 instructions per unit at ~5 cycles each
-//     and nothing covers its dequantisation VALU)
+//     and nothing covers its dequantisation VALU; DESIGN_NOTEBOOK.md 4.5.)
 //   * LOADERS.  Four loader waves (two for weights + scale pairs, two for the activation tile), LDS-DMA only, R-slot rings
 //     filled R - 1 units ahead; one s_barrier per unit for the twelve waves.
 #include <stdlib.h>
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(V4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
   // whole unit is one scheduling region, and the dequantisation of item i + 1 (14 VALU) is interleaved under the MT MFMAs of item i
   // (`sched_group_barrier`).  Measured against the first form of this file (a branch per row group, each group's VALU block in front
   // of its MFMAs): +-0.3 us per launch -- the compute-only build stays at 19.8 us, because its cost is ADDITIVE in three parts that
-  // interleaving inside a wave does not overlap: operand reads + barriers alone 13 us, + MFMAs 3.7, + dequantisation 3.2.
+  // interleaving inside a wave does not overlap: operand reads + barriers alone 13 us, + MFMAs 3.7, + dequantisation 3.2 (DESIGN_NOTEBOOK.md 4.5).
   auto consume = [&](auto nr_tag) {
     constexpr int NR = decltype(nr_tag)::value;
     constexpr int NI = 2 * NR;  // items of a unit: (k-step jj, row group r)
@@ -441,7 +441,7 @@ __global__ __launch_bounds__(V4_THREADS) __attribute__((amdgpu_waves_per_eu(3, 3
 struct V4Knobs {
   int on = 1;       // LL_GEMM4: bit 0 = launches that write finished outputs (epilogues 0 / 1), bit 1 = split-K partial launches
                     // (default 1: same box, the fused gate|up 32.1 -> 28.3 us; the 3.5 - 18-unit partial launches are fixed cost and
-                    // measure +-0 / +0.5 us on this body)
+                    // measure +-0 / +0.5 us on this body, DESIGN_NOTEBOOK.md 4.5)
   int rg_part = 4;  // LL_GEMM4_RGP: row groups per tile of a split-K partial launch (2 or 4)
   int min_fill = 3; // finished-output launches take this engine from min_fill row groups per CU on
   V4Knobs() {
@@ -484,7 +484,7 @@ int v4_wants(int64_t m, int64_t n, int64_t k, int group_size, int epilogue) {
   return (kn.on & 1) && v4_full_nrgt(n) ? 1 : 0;
 }
 
-// Host-side introspection (tests; no device work): the row-group engine's plan for a finished-output launch
+// Host-side introspection (tests, DESIGN_NOTEBOOK.md; no device work): the row-group engine's plan for a finished-output launch
 // (epilogue 0 / 1) of n weight rows as 8 ints -- [0] 1 if the engine takes the launch (else the unit loop does), [1] grid, [2] row
 // groups per workgroup (template bound), [3] rbase, [4] rrem (workgroup t owns groups [t * rbase + min(t, rrem), + rbase + (t < rrem))),
 // [5] compute units assumed, [6] LDS bytes, [7] 0.

@@ -20,7 +20,7 @@
 //     ranges to ~2 persistent workgroups per CU, so any N/K shape fills 256 CUs with no
 //     tail wave; a tile split across workgroups is combined by its last-arriving wave
 //     (per-wave slabs + agent-scope release/acquire, no workgroup barrier, no extra launch).
-// hipcc rules learnt the hard way: no control flow around loads in the
+// hipcc rules learnt the hard way (see DESIGN_NOTEBOOK.md): no control flow around loads in the
 // steady-state loop and no use of a loaded value before it is needed -- either makes the
 // waitcnt pass drain vmcnt(0) every unit.
 #include <stdlib.h>

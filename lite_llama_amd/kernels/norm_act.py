@@ -196,7 +196,7 @@ def skip_rmsnorm_partials(X: PartialSums, residual, weight, eps=1e-5):
     """:func:`skip_rmsnorm` over a :class:`PartialSums` input: ``x = fp16(sum of the partials)`` -- the value the
     projection itself would have stored -- then the same add-and-normalise.  ``residual`` is required.
     (Round 3's in-launch form -- the consuming projection normalising inside its own launch -- measured 10 us slower per
-    pair and was removed in round 4: DESIGN.md 4.2.)"""
+    pair and was removed in round 4: DESIGN_NOTEBOOK.md 4.2.)"""
     if residual is None:
         raise ValueError("skip_rmsnorm_partials needs a residual (the projection follows a normalised block)")
     L.require_cuda(X.parts, residual, weight)

@@ -8,13 +8,17 @@ uncalibrated.  bench.py prints `roofline.traffic` = fetch + write from this file
 import json, os, sqlite3, sys
 
 
-def per_kernel(path, counter, sub):
+def per_kernel(path, counter, subs):
+    """{kernel name: (launches, mean counter value)} of the kernels whose name contains one of ``subs``."""
     db = sqlite3.connect(path)
     cols = [r[1] for r in db.execute("pragma table_info(counters_collection)")]
     name_col = "kernel_name" if "kernel_name" in cols else "name"
-    rows = db.execute(f"select {name_col}, count(*), avg(value) from counters_collection where counter_name = ? and {name_col} like ? "
-                      f"group by {name_col}", (counter, f"%{sub}%")).fetchall()
-    return {r[0]: (r[1], r[2]) for r in rows}
+    out = {}
+    for sub in ([subs] if isinstance(subs, str) else subs):
+        rows = db.execute(f"select {name_col}, count(*), avg(value) from counters_collection where counter_name = ? and {name_col} like ? "
+                          f"group by {name_col}", (counter, f"%{sub}%")).fetchall()
+        out.update({r[0]: (r[1], r[2]) for r in rows})
+    return out
 
 
 def weighted(d):
@@ -24,7 +28,8 @@ def weighted(d):
 
 def main():
     fetch_db, write_db, tag = sys.argv[1], sys.argv[2], sys.argv[3]
-    gf, gw = per_kernel(fetch_db, "FETCH_SIZE", "wgemm"), per_kernel(write_db, "WRITE_SIZE", "wgemm")
+    gemms = ["wgemm", "wss_kernel"]  # row-group / unit-loop engines and the short-stream engine (round 6: q|k|v and o)
+    gf, gw = per_kernel(fetch_db, "FETCH_SIZE", gemms), per_kernel(write_db, "WRITE_SIZE", gemms)
     af, aw = per_kernel(fetch_db, "FETCH_SIZE", "fd_stage1"), per_kernel(write_db, "WRITE_SIZE", "fd_stage1")
     f_kb, n_f = weighted(gf)
     w_kb, _ = weighted(gw)
