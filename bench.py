@@ -189,7 +189,8 @@ def gemm_roofline(model, batch, quant, iters=6):
     if os.path.exists(spath) and quant in ("int4", "smoothquant"):
         try:  # north_star's "MFMA-utilisation counters": stored values of the last tools/pmc_round.sh pass, not live counters
             sj = json.load(open(spath))
-            pick = {"int4": ["wgemm4_kernel<5, 2>", "wgemm3_kernel<2, 1>"], "smoothquant": ["dense8_kernel<3, 1>"]}[quant]
+            pick = {"int4": ["wgemm4_kernel<5, 2>", "wgemm3_kernel<2, 1>", "wss_kernel<2, 4, 4, 8>", "wss_kernel<2, 2, 4, 14>"],
+                    "smoothquant": ["dense8_kernel<3, 1>", "wgemm16_rows_kernel<1, 2>"]}[quant]
             mfma_util = {"source": "stored profile values (profiles/pmc_sq.json <- tools/pmc_round.sh: SQ_VALU_MFMA_BUSY_CYCLES / "
                                    "(1024 SIMDs x SQ_BUSY_CYCLES / 32), separate --pmc passes over the step's eager launches)",
                          "kernels": {k: {"mfma_util": v.get("mfma_util"), "lds_busy": v.get("lds_busy"),
@@ -199,10 +200,12 @@ def gemm_roofline(model, batch, quant, iters=6):
             mfma_util = None
     kernel = {
         "int4": "wgemm4_kernel (row-group engine, the fused gate|up + swiglu launch; gemm_w4_v4.hip) + wgemm3_kernel (unit-loop engine, "
-                "the q|k|v / o / down split-K partial launches; gemm_w4_v3.hip) -- w4a16 dequant-GEMM over pre-packed weights",
+                "the down split-K partial launch; gemm_w4_v3.hip) + wss_kernel (short-stream engine, the q|k|v / o split-K partial "
+                "launches; gemm_short.hip) -- w4a16 dequant-GEMM over pre-packed weights",
         "int8": "dense8_kernel + dense8_finish (w8a16 int8, split-K weight streaming; gemm_w8_skinny.hip)",
         "fp8": "dense8_kernel + dense8_finish (w8a16 fp8-e4m3, split-K weight streaming; gemm_w8_skinny.hip)",
-        "smoothquant": "dense8_kernel (int8 x int8 MFMA, split-K planes; gemm_w8_skinny.hip) with the per-token quantiser / scale "
+        "smoothquant": "dense8_kernel (int8 x int8 MFMA, split-K planes; gemm_w8_skinny.hip) / wgemm16_rows_kernel<1, 2> (the fused gate|up "
+                       "row-group loop incl. scale epilogue + swiglu; gemm_w16_rows.hip) with the per-token quantiser / scale "
                        "epilogue fused into the neighbouring launches where the step fuses them (w8a8_fused.hip): as timed here, "
                        "q|k|v = quantiser + GEMM + finish, gate|up = quantiser + GEMM + finish-swiglu, o / down = quantiser + GEMM",
         "none": "dense8_kernel 16-bit form in split-K partial mode for q|k|v, o, down (gemm_w8_skinny.hip; planes summed by the "

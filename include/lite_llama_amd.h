@@ -249,7 +249,7 @@ int ll_w4a16_mtiled_supported(int64_t m, int64_t n, int64_t k, int group_size); 
 int ll_w4a16_matmul_prepacked_mtiled(void* out, const void* x, const void* wpacked, const void* spacked, const void* bias,
                                      int64_t m, int64_t n, int64_t k, int group_size, int64_t x_stride_m, int epilogue,
                                      void* stream);
-/* Host-side introspection (tests; no device work): the launch plan ll_w4a16_matmul_prepacked uses for (n, k,
+/* Host-side introspection (tests, DESIGN_NOTEBOOK.md; no device work): the launch plan ll_w4a16_matmul_prepacked uses for (n, k,
  * epilogue) as 16 ints -- grid, 128-row blocks per tile, tiles, chunks, slab slots, tile-group split (gt, gbase, grem, lead,
  * xcd_shift), stream-K units per workgroup, four reserved zeros, compute units assumed.  tests/test_host_cpu.py restates the
  * kernel's per-workgroup decode on it. */

@@ -387,9 +387,16 @@ extern "C" int ll_dense16_matmul(void* out, const void* x, const void* w, const 
 // ll_skip_rmsnorm_q8, ll_w8a8_finish_swiglu (w8a8_fused.hip).  Returns the number of planes written (>= 1), 0 when the
 // shape is not served, < 0 on error.
 // ---------------------------------------------------------------------------------------------------------------- //
+// the short-stream form of this mode (gemm_short_dense.hip): launches of a few tens of KB per CU
+int sd_partials_slices(int64_t m, int64_t n, int64_t k, int wfmt, int max_splits);
+int sd_launch(float* out, const void* x, const void* w, const float* scales, int64_t m, int64_t n, int64_t k, int group_n,
+              int64_t group_k, int wfmt, int64_t x_stride, int64_t w_stride_bytes, int64_t s_stride_n, int64_t s_stride_k,
+              int max_splits, void* stream);
+
 extern "C" int ll_dense_partials_count(int64_t m, int64_t n, int64_t k, int wfmt, int max_splits) {
   const bool w16 = wfmt == D8_F16 || wfmt == D8_BF16;
   if (wfmt != D8_FP8 && wfmt != D8_I8 && wfmt != D8_I8I8 && !w16) return 0;
+  if (const int s = sd_partials_slices(m, n, k, wfmt, max_splits)) return s;
   const int kch = w16 ? 64 : 128;
   if (m < 1 || m > 64 || n < 4 || n % 4 != 0 || k < kch || k % kch != 0 || max_splits < 1) return 0;
   const int chunks = (int)(k / kch);
@@ -407,6 +414,9 @@ extern "C" int ll_dense_partials(float* partials, const void* x, const void* w, 
   const bool i8a = wfmt == D8_I8I8;
   if (!partials || !x || !w || (!w16 && !i8a && !scales)) return LL_ERR_ARG;
   const int eb = w16 ? 2 : 1;
+  if (sd_partials_slices(m, n, k, wfmt, max_splits))  // (declines -- 0 -- exactly where the streaming engine below would)
+    return sd_launch(partials, x, w, scales, m, n, k, group_n, group_k, wfmt, x_stride, w_stride * eb, s_stride_n, s_stride_k,
+                     max_splits, stream);
   if ((w_stride * eb) % 16 != 0 || x_stride % (i8a ? 16 : 8) != 0 || !ll_aligned16(w) || !ll_aligned16(x) || !ll_aligned16(partials))
     return 0;
   if (!w16 && !i8a && group_k < k && group_k % 64 != 0) return 0;

@@ -1405,11 +1405,13 @@ def test_dense16_linear_matches_fp32_reference(M, N, K_, dt, with_bias):
 
 
 @pytest.mark.parametrize("fmt", ["f16", "bf16", "fp8_block", "int8_channel", "int8_group"])
-@pytest.mark.parametrize("M,N,K_,cap", [(64, 2048, 1536, 8), (32, 1536, 8960, 12), (7, 5120, 2048, 8), (64, 2048, 4096, 12), (1, 128, 128, 12)])
+@pytest.mark.parametrize("M,N,K_,cap", [(64, 2048, 1536, 8), (32, 1536, 8960, 12), (7, 5120, 2048, 8), (64, 2048, 4096, 12), (1, 128, 128, 12),
+                                        (64, 5120, 2048, 8), (33, 1536, 1536, 8), (32, 2048, 1536, 4), (64, 1024, 3584, 8)])
 def test_dense_partials_sum_to_the_finished_projection(fmt, M, N, K_, cap):
-    """Split-K partial mode of the 8-bit / 16-bit decode engine (round 4): the fp32 planes add up to what the finished
-    projection stores (same kernel, same split order: equal after the one rounding), their count respects the consumer's
-    cap, and the add-and-normalise over the planes equals skip_rmsnorm over the finished projection."""
+    """Split-K partial mode of the 8-bit / 16-bit decode engines (round 4; round 6: launches of a few tens of KB per CU -- the
+    Qwen3-30B-A3B dense projections 5120 x 2048 / 2048 x 4096, the 1.5B model's 2048 / 1536 x 1536 -- take the short-stream form,
+    gemm_short_dense.hip): the fp32 planes add up to what the finished projection stores (equal after the one rounding), their
+    count respects the consumer's cap, and the add-and-normalise over the planes equals skip_rmsnorm over the finished projection."""
     from lite_llama_amd.kernels.norm_act import skip_rmsnorm_partials
     from lite_llama_amd.kernels.quantization import dense16_linear, dense_matmul_partials
 
