@@ -259,7 +259,9 @@ static int sd_max_chunks(int kbs, int S) {  // most activation chunks any slice 
 // (16-bit: 64 VGPRs); R in {1, 2, 4}.
 static SDPlan sd_plan(int64_t m, int64_t n, int64_t k, int wfmt, int max_splits) {
   SDPlan best;
-  static const bool off = getenv("LL_DENSE_SS") != nullptr && atoi(getenv("LL_DENSE_SS")) == 0;  // A/B knob, read once
+  static const bool off = getenv("LL_DENSE_SS") != nullptr && atoi(getenv("LL_DENSE_SS")) == 0;  // A/B knobs, read once
+  static const int force_r = getenv("LL_DENSE_SS_R") ? atoi(getenv("LL_DENSE_SS_R")) : 0;
+  static const int force_s = getenv("LL_DENSE_SS_S") ? atoi(getenv("LL_DENSE_SS_S")) : 0;
   const bool w16 = wfmt == 4 || wfmt == 5;
   if (off || (wfmt != 1 && wfmt != 2 && !w16) || m < 1 || m > 64 || n < 32 || n % 32 != 0 || k < 64 || k % 64 != 0) return best;
   if (n * k * (w16 ? 2 : 1) >= (1ll << 31) || (int64_t)(m - 1) * k * 2 + k * 2 >= (1ll << 31)) return best;  // 32-bit offsets
@@ -270,10 +272,11 @@ static SDPlan sd_plan(int64_t m, int64_t n, int64_t k, int wfmt, int max_splits)
   const int pmax = w16 ? 4 : 8;
   double best_cost = 1e30;
   for (int R = 1; R <= 4; R *= 2) {
-    if (rgs % R) continue;
+    if (rgs % R || (force_r && R != force_r)) continue;
     const int KQ = 8 / R, RB = rgs / R;
     for (int S = 1; S <= SD_MAX_SLICES && S <= max_splits; ++S) {
       if (S > kbs) break;
+      if (force_s && S != force_s) continue;
       const int total = RB * S;
       if (total > cus) continue;
       const int nkb = (kbs + S - 1) / S;
@@ -300,6 +303,12 @@ static SDPlan sd_plan(int64_t m, int64_t n, int64_t k, int wfmt, int max_splits)
   }
   // a launch that would leave more than a third of the CUs idle stays on the streaming engine
   if (best.ok && best.total * 3 < cus * 2) best.ok = 0;
+  // Measured (benchmarks/gemm_short_dense.py, same box, us per launch short-stream / streaming engine; DESIGN_NOTEBOOK.md 8.7):
+  // fp8 2048 x 4096 7.4 / 11.2, int8 4096 x 1024 5.4 / 6.6 -- but fp8 5120 x 2048 (10.5 MB) 10.6 / 10.1 under every plan, and
+  // the 16-bit formats 7.2 - 8.1 / 6.0 - 6.5: a lane's 32 - 64 contiguous bytes per row make every load instruction touch 32+ cache
+  // lines (the int4 engine's pre-packed pieces are 1 KB contiguous).  Default: 8-bit weights of at most 9 MB; LL_DENSE_SS=2 lifts it.
+  static const bool all = getenv("LL_DENSE_SS") != nullptr && atoi(getenv("LL_DENSE_SS")) == 2;
+  if (best.ok && !all && (w16 || n * k > 9000000)) best.ok = 0;
   return best;
 }
 
