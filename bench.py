@@ -544,8 +544,16 @@ def parity_check(geo, quant_name, sample):
         tie = margin < 4e-3
         tie_note = {"rows_failing": int((~row_ok).sum()), "of_which_router_near_ties": int((~row_ok & tie).sum()),
                     "near_tie_rows_total": int(tie.sum()), "near_tie_rule": "relative gap between the k-th and (k+1)-th router probability < 4e-3 in the oracle"}
-        row_ok = row_ok | tie
+        excused = int((~row_ok & tie).sum())
+        tie_note["excused_cap"] = max(1, got.shape[0] // 16)   #  more excused rows than this is a FAILURE, not a tie
+        if excused <= tie_note["excused_cap"]:
+            row_ok = row_ok | tie
     ok = bool(row_ok.all())
+    strict = None
+    if quant_name == "smoothquant":  # second verdict at the reference's single-projection tolerance (reported, not the gate)
+        strict = {"tolerance": "1e-1 + 1e-1 |ref|", "rows_passing": int(torch.all((err <= 1e-1 + 1e-1 * ref.abs()).flatten(1), dim=1).sum()),
+                  "rows": int(got.shape[0]), "note": "the reference's 1e-1 is its tolerance for ONE W8A8 projection; the layer chains four behind a "
+                                                     "truncating per-token quantiser (whole-code flips from 1-ulp input differences)"}
     rel_rms = float(((got - ref).flatten(1).pow(2).mean(1).sqrt() / ref.flatten(1).pow(2).mean(1).sqrt().clamp_min(1e-9)).max())
     rows = info_c.cur_select_index.long()
     kv_got, kv_ref = kv[0][rows.cuda()].float().cpu(), sample["kv_after"][0][rows].float()
@@ -555,7 +563,7 @@ def parity_check(geo, quant_name, sample):
     del m
     torch.cuda.empty_cache()
     return {"ok": ok and kv_ok, "tolerance": f"|got - ref| <= {tol} + {tol} |ref| (logits), 2e-2 + 2e-2 |ref| (new K/V rows)", "max_abs_err_logits": round(float(err.max()), 5),
-            "max_row_relative_rms_err_logits": round(rel_rms, 5), "router_ties": tie_note,
+            "max_row_relative_rms_err_logits": round(rel_rms, 5), "router_ties": tie_note, "at_reference_projection_tolerance": strict,
             "max_abs_err_new_kv_rows": round(kv_err, 5), "argmax_agree": f"{same_tok}/{got.shape[0]}",
             "what": f"{layers} decoder layer(s) + final norm + lm_head at the headline shape (batch {got.shape[0]}, ctx {ctx}), "
                     "HIP step vs CPU oracle on identical weights / K,V / tokens"}
