@@ -115,6 +115,10 @@ int ll_update_kv_index(int32_t* table, const void* b_req_idx, const void* b_seq_
  * 32 floats per (row, head, partition) -- batch * hq * nparts * 32 -- one cache line per record.
  * Same values either way. */
 int ll_flash_decoding_num_partitions(int64_t max_len);
+/* Waves of the one-workgroup-per-(row, KV head) decode form for contexts of up to max_len tokens launched as `workgroups` = batch x
+ * KV heads (x head groups) workgroups (2 .. 8 partitions: a wave per partition; more: 8 waves that walk the partitions, when the
+ * launch has >= 128 workgroups); 0: the form does not apply -- ll_decode_attention_partials needs it. */
+int ll_flash_decoding_group_waves(int64_t max_len, int64_t workgroups);
 int ll_flash_decoding(void* out, const void* q, const void* k_cache, const void* v_cache,
                       const int32_t* table, const void* b_req_idx, const void* b_seq_len,
                       float* mid_o, float* mid_lse, int batch, int hq, int hkv, int d,

@@ -33,6 +33,7 @@ SIGNATURES = {
     "ll_update_kv_buffer": [P, P, P, L, I, I, L, L, L, L, I, P],
     "ll_update_kv_index": [P, P, P, P, L, L, L, I, I, I, P],
     "ll_flash_decoding_num_partitions": [L],
+    "ll_flash_decoding_group_waves": [L, L],
     "ll_flash_decoding": [P, P, P, P, P, P, P, P, P, I, I, I, I, L, F, L, L, L, L, L, L, L, L, L, I, I, I, P, P],
     "ll_decode_attention": [P, P, P, L, P, P, L, P, P, I, P, P, P, P, P, P, P, I, I, I, I, L, F, L, L, L, L, L, L, L, L, L,
                             I, I, I, P, P, P, F, P],

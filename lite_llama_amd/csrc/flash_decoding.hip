@@ -341,7 +341,7 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
   // (requested together: the table row address needs req, the partition bounds need seq_len -- one round trip, not two)
   const int64_t req = fd_load_idx(b_req_idx, b, req_w);
   const int64_t seq_len = fd_load_idx(b_seq_len, b, seq_w);
-  const int64_t start = (int64_t)part * FD_PART;
+  int64_t start = (int64_t)part * FD_PART;  // (GROUPED: the wave's FIRST partition; it walks part, part + waves, ... below)
   if (start >= seq_len) {  // empty partition stores nothing (flashdecoding.py:141-161)
     publish_q();
     if constexpr (FUSE) {
@@ -355,15 +355,15 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     if constexpr (GROUPED) __syncthreads();  // the workgroup's one barrier (the waves with tokens meet here before the merge)
     return;
   }
-  const int64_t end = seq_len < start + FD_PART ? seq_len : start + FD_PART;
+  int64_t end = seq_len < start + FD_PART ? seq_len : start + FD_PART;
   const int32_t* trow = table + req * t_sb;
   // Pool rows of the whole partition, requested now (the K/V gathers depend on them; everything up to the first
   // gather overlaps this round trip)
   const int64_t lastt = end - 1;
   const int64_t tk0 = start + lane < lastt ? start + lane : lastt;
   const int64_t tk1 = start + 64 + lane < lastt ? start + 64 + lane : lastt;
-  const int r0 = trow[tk0];
-  const int r1 = FD_PART == 128 ? trow[tk1] : r0;
+  int r0 = trow[tk0];
+  int r1 = FD_PART == 128 ? trow[tk1] : r0;
   publish_q();
 
   // Q^T fragments (MFMA B operand): lane (head t, group c) holds q[head][s*32 + c*8 .. +8] -- the
@@ -401,7 +401,8 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     // the new token lives in the last non-empty partition; head group 0 owns the write
     // (clamped to the launched partitions: a stale / too small max length then still stores the row)
     const int wpart = (int)((seq_len - 1) / FD_PART) < nparts - 1 ? (int)((seq_len - 1) / FD_PART) : nparts - 1;
-    if (hg == 0 && part == wpart) {
+    // (GROUPED with more partitions than waves: the wave that WILL gather partition wpart -- it is its only reader -- writes now)
+    if (hg == 0 && (GROUPED ? wave == wpart % (int)(blockDim.x >> 6) : part == wpart)) {
       const int64_t dstrow = fd_load_idx(rp.sel, b, rp.sel_w);
       const uint16_t* kn = qpart ? q_lds + groups * D : rp.kv_new + b * rp.kv_rs + (int64_t)kvh * D;
       const uint16_t* vn = qpart ? q_lds + groups * D + D : rp.kv_new + b * rp.kv_rs + (int64_t)(hkv + kvh) * D;
@@ -679,13 +680,41 @@ __global__ __launch_bounds__(GROUPED ? 64 * FD_GROUP_MAX : 64) void fd_stage1(
     if (start + 64 < end) FD_COMPUTE(A, 2)
     if (start + 96 < end) FD_COMPUTE(B, 3)
   }
+  if constexpr (GROUPED) {
+    // Contexts of more partitions than waves (round 6): the wave walks partitions part + W, part + 2 W, ... with the SAME running
+    // maximum / denominator / accumulators -- the online softmax does not care where a partition ends -- so the one-workgroup form
+    // (partials of the q|k|v projection summed in the prologue, merge through LDS, no global round trip) serves any context.
+    const int W_ = (int)(blockDim.x >> 6);
+    for (int pn = part + W_; pn < nparts; pn += W_) {
+      const int64_t st_ = (int64_t)pn * FD_PART;
+      if (st_ >= seq_len) break;
+      start = st_;
+      end = seq_len < start + FD_PART ? seq_len : start + FD_PART;
+      const int64_t last_ = end - 1;
+      const int64_t t0_ = start + lane < last_ ? start + lane : last_;
+      const int64_t t1_ = start + 64 + lane < last_ ? start + 64 + lane : last_;
+      r0 = trow[t0_];
+      r1 = FD_PART == 128 ? trow[t1_] : r0;
+      FD_LOAD(A, 0)
+      FD_LOAD(B, 1)
+      FD_COMPUTE(A, 0)
+      if constexpr (FD_PART == 128) FD_LOAD(A, 2)
+      if (start + 32 < end) FD_COMPUTE(B, 1)
+      if constexpr (FD_PART == 128) {
+        FD_LOAD(B, 3)
+        if (start + 64 < end) FD_COMPUTE(A, 2)
+        if (start + 96 < end) FD_COMPUTE(B, 3)
+      }
+    }
+  }
 #undef FD_LOAD
 #undef FD_COMPUTE
 #undef FD_WAVE_SYNC
 
   if constexpr (GROUPED) {
-    int np = (int)((seq_len + FD_PART - 1) / FD_PART);
+    int np = (int)((seq_len + FD_PART - 1) / FD_PART);  // records = waves with tokens
     if (np > nparts) np = nparts;
+    if (np > (int)(blockDim.x >> 6)) np = (int)(blockDim.x >> 6);
     constexpr int REC = 32 * VSTR / 2;  // floats per wave record: [16 heads][D] normalised partial + [16] log-sum-exp
     if (np > 1 && head_ok) {
       asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory");  // the last tile's V reads are done: the tile becomes the record
@@ -922,6 +951,19 @@ __global__ void fd_stage2(uint16_t* __restrict__ out, const float* __restrict__ 
 extern "C" int ll_flash_decoding_num_partitions(int64_t max_len) {
   return (int)((max_len + FD_PART - 1) / FD_PART);
 }
+// Waves of the one-workgroup-per-(row, KV head group) decode form for contexts of up to max_len tokens, launched as `workgroups`
+// = batch x KV heads x head groups workgroups; 0: the form does not apply.  Up to FD_GROUP_MAX partitions: a wave per partition
+// (whatever the batch: round 2's measurement).  More (round 6): FD_GROUP_MAX waves that walk the partitions -- taken when the
+// launch alone fills half the chip (128 workgroups); smaller batches keep a workgroup per partition + the counter merge, which
+// spreads ONE row's context over many CUs.
+#define FD_LOOP_MAX 256  // partitions (32 768 tokens)
+extern "C" int ll_flash_decoding_group_waves(int64_t max_len, int64_t workgroups) {
+  static const bool no_loop = getenv("LL_FD_NO_LOOP") != nullptr;  // A/B knob, read once
+  const int64_t np = (max_len + FD_PART - 1) / FD_PART;
+  if (np < 2) return 0;
+  if (np <= FD_GROUP_MAX) return (int)np;
+  return (!no_loop && np <= FD_LOOP_MAX && workgroups >= 128) ? FD_GROUP_MAX : 0;
+}
 
 template <int DT>
 static int launch_fd(void* out, const void* q, const void* kc, const void* vc, const int32_t* table,
@@ -942,10 +984,11 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
   rp.v_scale = v_scale;
   const bool qkn = rope && (rp.qnw || rp.knw);
   if (qkn && (!rp.qnw || !rp.knw || d != 128 || kv8 || !(rp.nrm_eps >= 0.f))) return LL_ERR_SHAPE;
-  const bool grouped_ok = fuse && nparts >= 2 && nparts <= FD_GROUP_MAX;
-  // split-K partial inputs need the grouped form and two float4 slots per lane: (groups + 2) * d / 4 <= 2 * 64 * nparts
+  const int gw = ll_flash_decoding_group_waves(max_len, (int64_t)batch * hkv * hgroups);  // waves of a grouped workgroup; 0: not grouped
+  const bool grouped_ok = fuse && gw >= 2;
+  // split-K partial inputs need the grouped form and two float4 slots per lane: (groups + 2) * d / 4 <= 2 * 64 * waves
   static const bool ungrouped_env = getenv("LL_FD_UNGROUPED") != nullptr;  // A/B knob, read once
-  if (rope && rp.qp && (!grouped_ok || rp.qs < 1 || rp.qs > FD_QS_MAX || (groups + 2) * d / 4 > 128 * nparts || ungrouped_env))
+  if (rope && rp.qp && (!grouped_ok || rp.qs < 1 || rp.qs > FD_QS_MAX || (groups + 2) * d / 4 > 128 * gw || ungrouped_env))
     return LL_ERR_SHAPE;
   // one workgroup per (row, KV head group) with a wave per partition while the context fits FD_GROUP_MAX partitions
   const bool grouped = grouped_ok && !ungrouped_env;
@@ -961,8 +1004,8 @@ static int launch_fd(void* out, const void* q, const void* kc, const void* vc, c
         attr_ = true;                                                                                \
       }                                                                                              \
     }                                                                                                \
-    fd_stage1<DT, DD, FU, RO, GG, GR, K8, QN, QI><<<(GR) ? dim3(1, grid.y, grid.z) : grid, (GR) ? 64 * nparts : 64, \
-                                        ((GR) ? nparts : 1) * tile_bytes_ + ((GR) ? 18 * DD * 2 : 0), st>>>( \
+    fd_stage1<DT, DD, FU, RO, GG, GR, K8, QN, QI><<<(GR) ? dim3(1, grid.y, grid.z) : grid, (GR) ? 64 * gw : 64, \
+                                        ((GR) ? gw : 1) * tile_bytes_ + ((GR) ? 18 * DD * 2 : 0), st>>>( \
         (const uint16_t*)q, (const uint16_t*)kc, (const uint16_t*)vc, table, req, seq, mid_o, mid_lse, hq, hkv, nparts, \
         scale, q_sb, q_sh, k_st, k_sh, v_st, v_sh, t_sb, req_w, seq_w, (uint16_t*)out, o_sb, o_sh, counters, rp); \
   }

@@ -187,11 +187,13 @@ def decode_attention(q, kv, cos_table, sin_table, positions, select_index, kv_bu
     return out
 
 
-def decode_attention_partials_supported(max_actual_seq_len, num_heads: int, num_kv_heads: int, head_dim: int) -> bool:
-    """Whether :func:`decode_attention_partials` serves this step (known before the projection is launched)."""
-    nparts = L.lib().ll_flash_decoding_num_partitions(int(max_actual_seq_len))
-    return (2 <= nparts <= 8 and head_dim >= 64 and head_dim % 32 == 0 and num_heads % num_kv_heads == 0
-            and num_heads // num_kv_heads <= 16 and (num_heads // num_kv_heads + 2) * head_dim // 4 <= 128 * nparts)
+def decode_attention_partials_supported(max_actual_seq_len, num_heads: int, num_kv_heads: int, head_dim: int, batch: int = 1) -> bool:
+    """Whether :func:`decode_attention_partials` serves this step (known before the projection is launched): the
+    one-workgroup-per-(row, KV head) form -- contexts of 129 .. 1024 tokens at any batch, longer ones (round 6: the waves walk the
+    partitions) when ``batch x KV heads`` alone fills half the chip."""
+    waves = L.lib().ll_flash_decoding_group_waves(int(max_actual_seq_len), int(batch) * int(num_kv_heads))
+    return (waves >= 2 and head_dim >= 64 and head_dim % 32 == 0 and num_heads % num_kv_heads == 0
+            and num_heads // num_kv_heads <= 16 and (num_heads // num_kv_heads + 2) * head_dim // 4 <= 128 * waves)
 
 
 @torch.no_grad()
@@ -203,7 +205,8 @@ def decode_attention_partials(parts, bias, num_heads: int, num_kv_heads: int, he
     partials of its (row, KV head) -- plus bias, one rounding to the pool dtype: the value the projection itself would
     have stored -- and continues as ``decode_attention`` (``qk_norm`` as there).  ``parts`` may also be the
     ``ScaledInt32Partials`` of a smoothquant projection (fp16, head_dim 128): the launch applies the scale epilogue.  Returns ``None`` when the shape is not served (contexts of
-    129..1024 tokens, head_dim >= 64, <= 16 query heads per KV head): finish the sums and call ``decode_attention``."""
+    129..1024 tokens -- any longer one when batch x KV heads >= 128 workgroups --, head_dim >= 64, <= 16 query heads per KV head):
+    finish the sums and call ``decode_attention``."""
     p = parts.parts
     scaled = p.dtype == torch.int32  # smoothquant: exact int32 planes + per-token / per-channel scales (ScaledInt32Partials)
     if scaled and (qk_norm is not None or head_dim != 128 or kv_buffer.dtype != torch.float16
@@ -224,8 +227,8 @@ def decode_attention_partials(parts, bias, num_heads: int, num_kv_heads: int, he
             or not _head_norm_ok(qk_norm, head_dim, dt)):
         return None
     max_len = int(max_actual_seq_len)
-    nparts = L.lib().ll_flash_decoding_num_partitions(max_len)
-    if nparts < 2 or nparts > 8 or (num_heads // num_kv_heads + 2) * head_dim // 4 > 128 * nparts:
+    waves = L.lib().ll_flash_decoding_group_waves(max_len, batchs * num_kv_heads)  # the one-workgroup form (0: not applicable)
+    if waves < 2 or (num_heads // num_kv_heads + 2) * head_dim // 4 > 128 * waves:
         return None
     k_cache, v_cache = kv_buffer[:, :num_kv_heads], kv_buffer[:, num_kv_heads:]
     out = torch.empty((batchs, num_heads, head_dim), dtype=dt, device=p.device)

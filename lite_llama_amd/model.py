@@ -273,7 +273,7 @@ class Attention(nn.Module):
         if (seq_len == 1 and norm_fused and not _TWO_CALL_ATTENTION and isinstance(position_embeddings, RopeTables)
                 and not fp8_pool and int32_planes_ok and self._qkv.refresh() and not os.environ.get("LL_NO_QKV_PARTIALS")
                 and decode_attention_partials_supported(atten_info.max_actual_seq_len, self.num_heads, self.num_kv_heads,
-                                                        self.head_dim)):
+                                                        self.head_dim, batch=x2.shape[0])):
             # decode, int4, TP = 1: the fused q|k|v projection leaves fp32 split-K partials and the one-launch attention
             # adds them up (+ bias) while its first K/V gathers are in flight -- the GEMM has no merge at all
             pq = self._qkv.partials(x2)

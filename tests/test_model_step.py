@@ -296,7 +296,7 @@ def test_quantisers_on_the_device_equal_the_cpu_quantisers_bit_for_bit():
 
 
 @pytest.mark.gpu
-@pytest.mark.parametrize("B,CTX,expect_partials", [(64, 549, True), (64, 1000, True), (128, 549, False), (64, 2048, "long")])
+@pytest.mark.parametrize("B,CTX,expect_partials", [(64, 549, True), (64, 1000, True), (128, 549, False), (64, 2048, True), (8, 2048, "long")])
 def test_headline_shape_decode_layer_matches_oracle(B, CTX, expect_partials, monkeypatch):
     """The ASSEMBLED layer of the headline workload (round-2 review, "what's weak" 1): Qwen2.5-7B widths, int4 g128,
     batch 64 at a context of 549 / 1000 tokens -- the launch sequence bench.py times (fused q|k|v left as split-K
@@ -363,9 +363,10 @@ def test_headline_shape_decode_layer_matches_oracle(B, CTX, expect_partials, mon
     with torch.no_grad():
         got = m(ids.cuda(), pos.cuda(), info_on("cuda", kv_gpu))
     if expect_partials == "long":
-        # 17 partitions (round-3 review: the second bench point, prompt 2048): beyond the grouped one-workgroup merge of the
-        # attention kernel -- q|k|v is finished by the projection itself (pre-packed stream, ordinary epilogue), the attention
-        # runs the global-merge form; o and down stay split-K partials into the two norms
+        # 17 partitions at a SMALL batch (8 rows x 4 KV heads = 32 workgroups): the attention keeps a workgroup per partition +
+        # the global merge (one row's context spread over many CUs) -- q|k|v is finished by the projection itself (pre-packed
+        # stream, ordinary epilogue); o and down stay split-K partials into the two norms.  At batch 64 (round 6) the
+        # one-workgroup form walks the 17 partitions with its 8 waves and takes the planes: the ordinary partial route above
         assert calls == {"attn_partials": 0, "norm_partials": 2, "gemm_partials": 2, "prepacked": 2}, calls
     elif expect_partials:
         # q|k|v, o and down as split-K partials; the attention and both norms consume them; gate|up on the pre-packed stream
