@@ -342,6 +342,15 @@ int ll_w8a8_rows_matmul(void* out, const int8_t* qa, const float* a_scale, const
 int ll_moe_align_block_size(const void* topk_ids, int ids_width, int64_t num_slots, int num_experts,
                             int block_size, int32_t* sorted_ids, int32_t* expert_ids,
                             int32_t* num_post, void* stream);
+/* The same outputs, bit for bit, for prefill-sized inputs (more than 1024 slots): three launches -- per-chunk counts, prefix
+ * over chunks and experts, stable placement -- over `workspace` (int32 words, ll_moe_align_workspace_ints of them; contents
+ * undefined before and after).  ll_moe_align_workspace_ints returns 0 for inputs the one-workgroup kernels serve;
+ * ll_moe_align_block_size_ws falls back to ll_moe_align_block_size when the workspace is null or too small
+ * (kernels/fused_moe.py:45-99: the reference sorts on the host side of Triton with torch ops at any size). */
+int64_t ll_moe_align_workspace_ints(int64_t num_slots, int num_experts);
+int ll_moe_align_block_size_ws(const void* topk_ids, int ids_width, int64_t num_slots, int num_experts, int block_size,
+                               int32_t* sorted_ids, int32_t* expert_ids, int32_t* num_post, int32_t* workspace,
+                               int64_t workspace_ints, void* stream);
 /* c[slot, :] = (a[slot / top_k, :] @ w[expert(slot)].T) (* topk_w[slot]).  mul_routed_weight: bit 0 = multiply by topk_w[slot]
  * (fp32, fused_moe.py:203-205); bit 1 (extension) = the rows of w are (gate_j, up_j) pairs -- a load-time interleave of the
  * stacked gate|up matrix -- and c is [num_slots, n / 2] = silu(gate) * up on the fp16-rounded GEMM outputs: the values of

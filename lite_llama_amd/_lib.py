@@ -71,6 +71,8 @@ SIGNATURES = {
     "ll_w8a8_matmul": [P, P, P, P, P, P, L, L, L, L, P, P, P, P],
     "ll_w8_mtiled_supported": [L, L, L, I, L],
     "ll_moe_align_block_size": [P, I, L, I, I, P, P, P, P],
+    "ll_moe_align_workspace_ints": [L, I],
+    "ll_moe_align_block_size_ws": [P, I, L, I, I, P, P, P, P, L, P],
     "ll_moe_gemm": [P, P, P, P, P, P, P, P, L, L, I, L, L, I, I, I, I, L, L, L, L, L, L, L, I, P],
     "ll_silu_and_mul": [P, P, L, L, I, P],
     "ll_silu_and_mul_pairs": [P, P, L, L, I, P],
@@ -106,7 +108,7 @@ SIGNATURES = {
     "ll_argmax_split": [P, P, L, L, L, I, P, I, P],
 }
 
-_RETURNS_I64 = {"ll_kv_alloc_scratch_bytes", "ll_tp_oneshot_flag_words", "ll_moe_router_workspace_floats"}
+_RETURNS_I64 = {"ll_kv_alloc_scratch_bytes", "ll_tp_oneshot_flag_words", "ll_moe_router_workspace_floats", "ll_moe_align_workspace_ints"}
 _lib = None
 
 

@@ -206,6 +206,193 @@ __global__ __launch_bounds__(1024) void moe_align_small_kernel(const void* __res
                               max_blocks, sm);
 }
 
+// ---------------------------------------------------------------------------------- //
+// Prefill-sized inputs (round 6: thousands to hundreds of thousands of slots).  The one-workgroup kernel above walks ALL slots
+// once per expert thread: 21.9 ms per call at 32 768 tokens x top-8 of 128 experts -- 60 % of the Qwen3-30B-A3B prefill pass.
+// Three launches over a caller-provided workspace instead, same outputs bit for bit:
+//   count    one workgroup per chunk of 1024 slots: the bitmap ranking of the small kernel inside the chunk (one LDS atomic OR per
+//            slot), per-(chunk, expert) counts -> workspace[chunk][expert]; sentinel fill of sorted_ids by all workgroups;
+//   offsets  one workgroup: exclusive prefix of the counts over the chunks (per expert, in place), the padded prefix over the
+//            experts (-> workspace[chunks * E + e]), expert_ids, num_tokens_post_padded;
+//   place    one workgroup per chunk: bitmaps again (the ids are 1 - 2 MB), sorted_ids[start[e] + before[chunk][e] + rank] = slot.
+// Stable by construction: chunks are consecutive slot ranges, ranks inside a chunk count the earlier slots of the same expert.
+// ---------------------------------------------------------------------------------- //
+#define MOE_ALIGN_CHUNK 1024
+// bitmaps of one chunk: bm[E][32 half-waves]; returns this thread's expert (-1: no slot) and its rank among the chunk's earlier
+// slots of that expert
+__device__ __forceinline__ int moe_align_chunk_bitmaps(const void* __restrict__ topk_ids, int ids_w, int num_slots, int num_experts,
+                                                       unsigned* bm, int& rank) {
+  const int tid = threadIdx.x, slot = (int)blockIdx.x * MOE_ALIGN_CHUNK + tid;
+  constexpr int NH = MOE_ALIGN_CHUNK / 32;
+  for (int i = tid; i < NH * num_experts; i += MOE_ALIGN_CHUNK) bm[i] = 0u;
+  __syncthreads();
+  const int half = tid >> 5;
+  int e = -1;
+  if (slot < num_slots) {
+    e = moe_clamp_id((int)moe_load_idx(topk_ids, slot, ids_w), num_experts);
+    atomicOr(bm + e * NH + half, 1u << (tid & 31));
+  }
+  __syncthreads();
+  rank = 0;
+  if (e >= 0) {
+    const unsigned* row = bm + e * NH;
+    for (int j = 0; j < half; ++j) rank += __popc(row[j]);
+    rank += __popc(row[half] & ((1u << (tid & 31)) - 1u));
+  }
+  return e;
+}
+
+__global__ __launch_bounds__(MOE_ALIGN_CHUNK) void moe_align_count_kernel(const void* __restrict__ topk_ids, int ids_w, int num_slots,
+                                                                          int num_experts, int32_t* __restrict__ sorted_ids,
+                                                                          int max_padded, int32_t* __restrict__ ws) {
+  extern __shared__ int sm[];
+  unsigned* bm = reinterpret_cast<unsigned*>(sm);
+  constexpr int NH = MOE_ALIGN_CHUNK / 32;
+  for (int i = (int)blockIdx.x * MOE_ALIGN_CHUNK + threadIdx.x; i < max_padded; i += (int)gridDim.x * MOE_ALIGN_CHUNK)
+    sorted_ids[i] = num_slots;  // sentinel
+  int rank;
+  (void)moe_align_chunk_bitmaps(topk_ids, ids_w, num_slots, num_experts, bm, rank);
+  for (int e = threadIdx.x; e < num_experts; e += MOE_ALIGN_CHUNK) {
+    int c = 0;
+    for (int j = 0; j < NH; ++j) c += __popc(bm[e * NH + j]);
+    ws[(size_t)blockIdx.x * num_experts + e] = c;
+  }
+}
+
+__global__ __launch_bounds__(1024) void moe_align_offsets_kernel(int num_experts, int block_size, int chunks, int32_t* __restrict__ ws,
+                                                                 int32_t* __restrict__ expert_ids, int32_t* __restrict__ num_post,
+                                                                 int max_blocks) {
+  extern __shared__ int sm[];  // part_tot[P][E] | bends[E]
+  const int tid = threadIdx.x;
+  // thread (part, e): chunks [part * per, ...) of expert e -- P = 1024 / E parts walk the chunk axis side by side
+  const int P = num_experts <= 1024 ? 1024 / num_experts : 1;
+  const int per = (chunks + P - 1) / P;
+  int* part_tot = sm;
+  int* bends = sm + P * num_experts;
+  __shared__ int wave_tot[16], carry_s;
+  if (tid == 0) carry_s = 0;
+  for (int base = 0; base < num_experts; base += 1024) {  // (one round unless E > 1024: then P = 1)
+    const int part = num_experts <= 1024 ? tid / num_experts : 0;
+    const int e = num_experts <= 1024 ? tid - part * num_experts : base + tid;
+    const bool live = e < num_experts && part < P;
+    const int c_lo = part * per, c_hi = c_lo + per < chunks ? c_lo + per : chunks;
+    int tot = 0;
+    if (live) {
+      int c = c_lo;
+      for (; c + 8 <= c_hi; c += 8) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(c + u) * num_experts + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) tot += v[u];
+      }
+      for (; c < c_hi; ++c) tot += ws[(size_t)c * num_experts + e];
+      part_tot[part * num_experts + e] = tot;
+    }
+    __syncthreads();
+    int before_parts = 0, count = 0;
+    if (live) {
+      for (int q = 0; q < P; ++q) {
+        const int t = part_tot[q * num_experts + e];
+        if (q < part) before_parts += t;
+        count += t;
+      }
+      // exclusive prefix over this part's chunks, in place
+      int run = before_parts, c = c_lo;
+      for (; c + 8 <= c_hi; c += 8) {
+        int v[8];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) v[u] = ws[(size_t)(c + u) * num_experts + e];
+#pragma unroll
+        for (int u = 0; u < 8; ++u) {
+          ws[(size_t)(c + u) * num_experts + e] = run;
+          run += v[u];
+        }
+      }
+      for (; c < c_hi; ++c) {
+        const int v = ws[(size_t)c * num_experts + e];
+        ws[(size_t)c * num_experts + e] = run;
+        run += v;
+      }
+    }
+    // padded prefix over the experts (threads of part 0 carry the counts; every other thread contributes 0)
+    const int padded = (live && part == 0) ? (count + block_size - 1) / block_size * block_size : 0;
+    int x = padded;
+    const int lane = tid & 63, wave = tid >> 6;
+#pragma unroll
+    for (int off = 1; off < 64; off <<= 1) {
+      const int y = __shfl_up(x, off, 64);
+      if (lane >= off) x += y;
+    }
+    if (lane == 63) wave_tot[wave] = x;
+    __syncthreads();
+    int before = carry_s;
+    for (int w = 0; w < wave; ++w) before += wave_tot[w];
+    if (live && part == 0) {
+      ws[(size_t)chunks * num_experts + e] = before + x - padded;  // start of expert e's run
+      bends[e] = (before + x) / block_size;
+    }
+    __syncthreads();
+    if (tid == 1023) carry_s = before + x;
+    __syncthreads();
+  }
+  if (tid == 0) num_post[0] = carry_s;
+  for (int b = tid; b < max_blocks; b += 1024) {  // expert_ids[b] = searchsorted(block_ends, b, right=True) clamped to E-1
+    int lo = 0, hi = num_experts;
+    while (lo < hi) {
+      const int mid = (lo + hi) >> 1;
+      if (bends[mid] <= b) lo = mid + 1; else hi = mid;
+    }
+    expert_ids[b] = lo < num_experts - 1 ? lo : num_experts - 1;
+  }
+}
+
+__global__ __launch_bounds__(MOE_ALIGN_CHUNK) void moe_align_place_kernel(const void* __restrict__ topk_ids, int ids_w, int num_slots,
+                                                                          int num_experts, int chunks, int32_t* __restrict__ sorted_ids,
+                                                                          const int32_t* __restrict__ ws) {
+  extern __shared__ int sm[];
+  int rank;
+  const int e = moe_align_chunk_bitmaps(topk_ids, ids_w, num_slots, num_experts, reinterpret_cast<unsigned*>(sm), rank);
+  if (e >= 0)
+    sorted_ids[ws[(size_t)chunks * num_experts + e] + ws[(size_t)blockIdx.x * num_experts + e] + rank] =
+        (int)blockIdx.x * MOE_ALIGN_CHUNK + threadIdx.x;
+}
+
+// int32 words of workspace the multi-workgroup form wants for this input; 0: the one-workgroup kernels serve it (decode-sized
+// inputs, or more experts than a chunk's bitmaps fit in 64 KB of LDS for)
+extern "C" int64_t ll_moe_align_workspace_ints(int64_t num_slots, int num_experts) {
+  static const bool off = getenv("LL_MOE_ALIGN_ONE_WG") != nullptr;  // A/B knob, read once
+  if (off || num_slots <= 1024 || num_experts <= 0 || (size_t)num_experts * (MOE_ALIGN_CHUNK / 32) * 4 > 64 * 1024) return 0;
+  if (num_experts > 1024 && (size_t)num_experts * 8 > 64 * 1024) return 0;
+  const int64_t chunks = (num_slots + MOE_ALIGN_CHUNK - 1) / MOE_ALIGN_CHUNK;
+  return chunks * num_experts + num_experts;
+}
+
+extern "C" int ll_moe_align_block_size(const void* topk_ids, int ids_width, int64_t num_slots, int num_experts, int block_size,
+                                       int32_t* sorted_ids, int32_t* expert_ids, int32_t* num_post, void* stream);
+
+extern "C" int ll_moe_align_block_size_ws(const void* topk_ids, int ids_width, int64_t num_slots, int num_experts, int block_size,
+                                          int32_t* sorted_ids, int32_t* expert_ids, int32_t* num_post, int32_t* workspace,
+                                          int64_t workspace_ints, void* stream) {
+  const int64_t want = ll_moe_align_workspace_ints(num_slots, num_experts);
+  if (want == 0 || !workspace || workspace_ints < want || ids_width < 0 || (ids_width != LL_I32 && ids_width != LL_I64) ||
+      block_size <= 0 || num_slots + (int64_t)num_experts * (block_size - 1) >= (1ll << 31))
+    return ll_moe_align_block_size(topk_ids, ids_width, num_slots, num_experts, block_size, sorted_ids, expert_ids, num_post, stream);
+  const int max_padded = (int)num_slots + num_experts * (block_size - 1);
+  const int max_blocks = (max_padded + block_size - 1) / block_size;
+  const int chunks = (int)((num_slots + MOE_ALIGN_CHUNK - 1) / MOE_ALIGN_CHUNK);
+  const size_t bm_bytes = (size_t)num_experts * (MOE_ALIGN_CHUNK / 32) * sizeof(unsigned);
+  const int P = num_experts <= 1024 ? 1024 / num_experts : 1;
+  hipStream_t st = (hipStream_t)stream;
+  moe_align_count_kernel<<<chunks, MOE_ALIGN_CHUNK, bm_bytes, st>>>(topk_ids, ids_width, (int)num_slots, num_experts, sorted_ids,
+                                                                    max_padded, workspace);
+  moe_align_offsets_kernel<<<1, 1024, (size_t)(P + 1) * num_experts * sizeof(int), st>>>(num_experts, block_size, chunks, workspace,
+                                                                                         expert_ids, num_post, max_blocks);
+  moe_align_place_kernel<<<chunks, MOE_ALIGN_CHUNK, bm_bytes, st>>>(topk_ids, ids_width, (int)num_slots, num_experts, chunks,
+                                                                    sorted_ids, workspace);
+  return LL_LAUNCH_CHECK();
+}
+
 extern "C" int ll_moe_align_block_size(const void* topk_ids, int ids_width, int64_t num_slots, int num_experts,
                                        int block_size, int32_t* sorted_ids, int32_t* expert_ids,
                                        int32_t* num_post, void* stream) {

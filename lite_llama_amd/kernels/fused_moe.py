@@ -26,10 +26,14 @@ def moe_align_block_size(
     sorted_ids = torch.empty((max_padded,), dtype=torch.int32, device=device)
     expert_ids = torch.empty((max_blocks,), dtype=torch.int32, device=device)
     num_post = torch.empty((1,), dtype=torch.int32, device=device)
+    # prefill-sized inputs: per-chunk counts -> prefix -> stable placement over a scratch table (same outputs; the one-workgroup
+    # kernel walks all slots once per expert: 21.9 ms at 32 768 tokens x top-8, round 6)
+    ws_ints = L.lib().ll_moe_align_workspace_ints(num_slots, int(num_experts))
+    ws = torch.empty((ws_ints,), dtype=torch.int32, device=device) if ws_ints > 0 else None
     L.check(
-        L.lib().ll_moe_align_block_size(
+        L.lib().ll_moe_align_block_size_ws(
             flat.data_ptr(), L.index_width(flat), num_slots, int(num_experts), int(block_size),
-            sorted_ids.data_ptr(), expert_ids.data_ptr(), num_post.data_ptr(), L.stream_ptr(),
+            sorted_ids.data_ptr(), expert_ids.data_ptr(), num_post.data_ptr(), L.ptr(ws), ws_ints, L.stream_ptr(),
         ),
         "moe_align_block_size",
     )

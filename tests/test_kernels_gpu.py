@@ -1074,6 +1074,38 @@ def test_moe_align_small_kernel_equals_the_general_kernel(slots, experts, block,
             assert torch.equal(got[1][: npost // block].cpu(), ref[1][: npost // block].to(torch.int32))
 
 
+@pytest.mark.parametrize("slots,experts,block", [(1025, 8, 16), (4096, 128, 64), (5000, 60, 32), (3001, 512, 64), (2048, 1, 64),
+                                                 (32768 * 8, 128, 64), (20000, 300, 256)])
+def test_moe_align_multi_workgroup_form_equals_oracle_and_the_one_workgroup_kernel(slots, experts, block):
+    """Prefill-sized inputs (round 6): per-chunk counts -> prefix over chunks and experts -> stable placement, three launches over
+    a scratch table -- every output word equal to the oracle's (fused_moe.py:45-99 protocol) and to the one-workgroup kernel's
+    (the raw ABI entry without a workspace), int32 and int64 ids, random / one expert for all / out-of-range ids."""
+    import lite_llama_amd._lib as L_
+    assert L_.lib().ll_moe_align_workspace_ints(slots, experts) == ((slots + 1023) // 1024 + 1) * experts
+    assert L_.lib().ll_moe_align_workspace_ints(1024, experts) == 0
+    g = torch.Generator().manual_seed(slots + experts)
+    cases = [torch.randint(0, experts, (slots,), generator=g), torch.full((slots,), experts - 1),
+             torch.randint(0, max(experts // 8, 1), (slots,), generator=g)]  # the last: most experts empty
+    for ci, ids in enumerate(cases):
+        ref = O.moe_align_block_size(ids.view(-1, 1), block, experts)
+        for dt in (torch.int32, torch.int64):
+            if ci and dt == torch.int32:
+                continue
+            idd = ids.to(dt).view(-1, 1).to(DEV)
+            got = K().moe_align_block_size(idd, block, experts)
+            assert torch.equal(got[2].cpu(), ref[2]) and torch.equal(got[0].cpu(), ref[0]) and torch.equal(got[1].cpu(), ref[1])
+            if ci == 0 and dt == torch.int32 and slots <= 40000:  # the one-workgroup kernel walks all slots per expert: small cases
+                one = [torch.empty_like(t) for t in got]
+                L_.check(L_.lib().ll_moe_align_block_size(idd.data_ptr(), L_.index_width(idd.view(-1)), slots, experts, block,
+                                                          one[0].data_ptr(), one[1].data_ptr(), one[2].data_ptr(), L_.stream_ptr()),
+                         "moe_align_block_size")
+                assert all(torch.equal(a, b) for a, b in zip(got, one))
+    wild = torch.randint(-3, experts + 3, (slots, 1), generator=g).to(DEV)  # folded onto valid experts, as the small kernels do
+    s_, e_, n_ = K().moe_align_block_size(wild, block, experts)
+    ref = O.moe_align_block_size(wild.cpu().clamp(0, experts - 1), block, experts)
+    assert torch.equal(s_.cpu(), ref[0]) and torch.equal(e_.cpu(), ref[1]) and torch.equal(n_.cpu(), ref[2])
+
+
 # ------------------------------------------------------------------------------------- #
 # decode-step fusions (extensions): bit-identical to the reference-shaped call sequences
 # ------------------------------------------------------------------------------------- #
