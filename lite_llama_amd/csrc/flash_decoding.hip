@@ -95,7 +95,9 @@ struct FdRope {
 // GROUPED (decode contexts of up to FD_GROUP_MAX partitions): ONE workgroup per (row, KV head group), one wave per
 // partition; the partials meet in LDS and wave 0 merges them -- no partial stores, no counter, no coherent
 // re-load: the merge tail shrinks from two global round trips (~5 us at batch 64 x ctx 512) to a barrier.
+#ifndef FD_GROUP_MAX
 #define FD_GROUP_MAX 8
+#endif
 // KV8 (extension): the pool holds OCP e4m3 bytes (ll_update_kv_buffer_fp8); fragments are gathered as 8-byte pieces and
 // widened to fp16 in registers (v_cvt_scalef32_pk_f16_fp8, exact), k_scale rides on the softmax scale and v_scale on
 // the final normalisation -- half the K/V bytes, the same MFMA arithmetic.  fp16 queries only, no in-kernel rope.
