@@ -82,6 +82,11 @@ def parse():
                          "collective: a ceiling of the scaling curve, not a scaling point (\"shard_sim\" in the line)")
     ap.add_argument("--as-shard-sim", type=int, default=0,
                     help="(used by --shard-sim) run as rank 0 of this TP degree with simulated collectives; bounded line")
+    ap.add_argument("--as-pmc-probe", action="store_true",
+                    help="(used by the live counter leg) build a 3-layer model of --model / --quant at its real widths, issue the "
+                         "dense projections' launch list eagerly a few times and exit: the workload of a rocprofv3 --pmc pass")
+    ap.add_argument("--no-live-pmc", action="store_true",
+                    help="skip the live rocprofv3 --pmc passes (roofline.traffic / mfma_util then carry the stored profile values)")
     ap.add_argument("--no-reference-order", action="store_true",
                     help="skip the bounded drop-in-route entry (\"reference_order\") of the default N = 1 int4 line")
     return ap.parse_args()
@@ -107,11 +112,9 @@ def algorithmic_bytes(geo, quant, batch, ctx, tp):
     return w_lin, w_head, batch * ctx * kv_tok
 
 
-def gemm_roofline(model, batch, quant, iters=6):
-    """Average launch duration of the dominant kernel (the weight-streaming dequant-GEMM) over every
-    projection of the model with its real weights -- the same calls the decode step makes (fused [q|k|v],
-    fused [gate|up] + swiglu, row-parallel projections in split-K partial mode) -- by HIP events on the
-    launch stream around hipGraph replays of the launch list (eager back-to-back launches as fallback)."""
+def projection_launches(model, quant):
+    """The launch list of the dense projections as the decode step issues them: (callable, input width, weights in the launch) --
+    fused [q|k|v] left as split-K partials, fused [gate|up] + swiglu, row-parallel projections in split-K partial mode at TP = 1."""
     from lite_llama_amd.distributed.parallel_state import collective_forced, get_tp_world_size
     from lite_llama_amd.linear import LinearBase, MergedColumnLinear, RowParallelLinear
 
@@ -134,6 +137,17 @@ def gemm_roofline(model, batch, quant, iters=6):
         if isinstance(m, LinearBase) and (m.quant is not None or quant == "none") and id(m) not in fused_members:
             fn = (lambda x, m=m: m(x, partials_ok=True)) if (isinstance(m, RowParallelLinear) and solo) else m.apply_linear
             launches_list.append((fn, m.input_size, m.input_size * m.output_size))
+    return launches_list, solo
+
+
+def gemm_roofline(model, batch, quant, iters=6, live_pmc=None):
+    """Average launch duration of the dominant kernel (the weight-streaming dequant-GEMM) over every
+    projection of the model with its real weights -- the same calls the decode step makes (fused [q|k|v],
+    fused [gate|up] + swiglu, row-parallel projections in split-K partial mode) -- by HIP events on the
+    launch stream around hipGraph replays of the launch list (eager back-to-back launches as fallback).
+    ``live_pmc``: the result of :func:`live_pmc_counters` of THIS run (HBM-side traffic + MFMA utilisation from rocprofv3 --pmc
+    passes over the same launch list); without it the stored profile values are reported, labelled so."""
+    launches_list, solo = projection_launches(model, quant)
     if not launches_list:
         return None
     dev = next(model.parameters()).device
@@ -174,7 +188,14 @@ def gemm_roofline(model, batch, quant, iters=6):
     achieved = bytes_per_launch / avg_s
     traffic, traffic_source, traffic_parts = None, None, None
     tpath = os.path.join(ROOT, "profiles", "pmc_traffic.json")
-    if quant == "int4" and solo and os.path.exists(tpath):  # the stored counters are those of the int4 engine at TP = 1 only
+    if live_pmc and live_pmc.get("traffic"):
+        tj = live_pmc["traffic"]
+        traffic = tj.get("wgemm_bytes_per_launch")
+        traffic_parts = {"fetch": tj.get("wgemm_fetch_bytes_per_launch"), "write": tj.get("wgemm_write_bytes_per_launch"),
+                         "per_kernel_KB": tj.get("per_kernel_KB")}
+        traffic_source = ("LIVE counters of this run: " + live_pmc["how"] + "; FETCH_SIZE x 1024 x 2 (the gfx950 correction of "
+                          "MI355X_MICROARCH.md), WRITE_SIZE x 1024 uncalibrated; mean over the launch kinds of a decoder layer")
+    elif quant == "int4" and solo and os.path.exists(tpath):  # the stored counters are those of the int4 engine at TP = 1 only
         try:
             tj = json.load(open(tpath))
             traffic = tj.get("wgemm_bytes_per_launch")
@@ -186,7 +207,13 @@ def gemm_roofline(model, batch, quant, iters=6):
             traffic = None
     mfma_util = None
     spath = os.path.join(ROOT, "profiles", "pmc_sq.json")
-    if os.path.exists(spath) and quant in ("int4", "smoothquant"):
+    if live_pmc and live_pmc.get("sq"):
+        mfma_util = {"source": "LIVE counters of this run: " + live_pmc["how"] + "; SQ_VALU_MFMA_BUSY_CYCLES / (1024 SIMDs x "
+                               "SQ_BUSY_CYCLES / 32)",
+                     "kernels": {r["kernel"]: {"mfma_util": r.get("mfma_util"), "lds_busy": r.get("lds_busy"),
+                                               "lds_bank_conflict_frac": r.get("lds_conflict_frac"),
+                                               "wave_wait_frac": r.get("wave_wait_frac")} for r in live_pmc["sq"]}}
+    elif os.path.exists(spath) and quant in ("int4", "smoothquant"):
         try:  # north_star's "MFMA-utilisation counters": stored values of the last tools/pmc_round.sh pass, not live counters
             sj = json.load(open(spath))
             pick = {"int4": ["wgemm4_kernel<5, 2>", "wgemm3_kernel<2, 1>", "wss_kernel<2, 4, 4, 8>", "wss_kernel<2, 2, 4, 14>"],
@@ -447,6 +474,104 @@ def shard_sim_points(args, degrees, timeout_s: float = 200.0):
     return {"what": "ONE rank's compute at the TP shard shapes on one GPU, every all-reduce replaced by a same-size local copy, "
                     "captured step, <= 32 steps: a ceiling of the scaling curve (no collective, no peers), NOT a scaling point",
             "points": out}
+
+
+def pmc_probe(args):
+    """--as-pmc-probe: the dense projections of THREE decoder layers of the model at its real widths (3 x 131 MB of int4 weights
+    for Qwen2.5-7B: more than the 256-MB Infinity Cache, so launches meet cold weights as in the step), issued eagerly like the
+    decode step issues them, four rounds.  Run under rocprofv3 --kernel-trace --pmc <counters> by live_pmc_counters()."""
+    import dataclasses
+
+    from lite_llama_amd.distributed import parallel_state as ps
+    from lite_llama_amd.model import GEOMETRY, CausalLM
+    from lite_llama_amd.quantization import QuantConfig
+
+    torch.cuda.set_device(0)
+    dev = torch.device("cuda", 0)
+    ps.init_parallel(0, tp_size=1, dp_size=1, master_port=int(os.environ.get("MASTER_PORT", 29500)))
+    geo = dataclasses.replace(GEOMETRY[args.model], num_layers=3, vocab_size=4096)
+    quant = None if args.quant == "none" else QuantConfig.for_runtime_scheme(args.quant)
+    with torch.device(dev):
+        model = CausalLM(geo, quant)
+    model.init_synthetic(seed=0, quant=quant, device=dev)
+    if args.dtype == "bf16":
+        model = model.to(torch.bfloat16)
+    if quant is not None:
+        model.compact_weights()
+    launches_list, _ = projection_launches(model, args.quant)
+    adt = next(model.parameters()).dtype if args.quant == "none" else torch.float16
+    xs = {k: (torch.randn(args.batch, k, device=dev) * 0.5).to(adt) for _, k, _ in launches_list}
+    for _ in range(4):
+        for fn, k, _ in launches_list:
+            fn(xs[k])
+    torch.cuda.synchronize()
+    print(json.dumps({"pmc_probe": "ok", "launches": 4 * len(launches_list)}), flush=True)
+
+
+def live_pmc_counters(args, budget_s: float = 150.0):
+    """HBM-side traffic and MFMA utilisation of the dense projections' kernels from LIVE counters: four rocprofv3 --kernel-trace
+    --pmc passes (FETCH_SIZE | WRITE_SIZE | two SQ sets; each in its own run, as MI355X_MICROARCH.md prescribes) over
+    ``bench.py --as-pmc-probe`` in a subprocess, bounded in time; ``None`` when rocprofv3 is missing, a pass fails or the budget
+    runs out (the line then carries the stored profile values, labelled so)."""
+    import shutil
+    import subprocess
+    import tempfile
+
+    prof = shutil.which("rocprofv3") or ("/opt/rocm/bin/rocprofv3" if os.path.exists("/opt/rocm/bin/rocprofv3") else None)
+    if prof is None:
+        return None
+    sys.path.insert(0, os.path.join(ROOT, "tools"))
+    try:
+        import pmc_sq
+        import pmc_traffic
+    except Exception:
+        return None
+    sets = {
+        "FETCH_SIZE": ["FETCH_SIZE"], "WRITE_SIZE": ["WRITE_SIZE"],
+        "A": "SQ_BUSY_CYCLES SQ_WAVE_CYCLES SQ_WAIT_ANY SQ_WAIT_INST_ANY SQ_ACTIVE_INST_ANY SQ_ACTIVE_INST_VALU SQ_ACTIVE_INST_LDS GRBM_GUI_ACTIVE".split(),
+        "B": "SQ_INSTS_MFMA SQ_VALU_MFMA_BUSY_CYCLES SQ_INSTS_VALU SQ_INSTS_LDS SQ_LDS_BANK_CONFLICT SQ_LDS_IDX_ACTIVE SQ_WAIT_INST_LDS GRBM_GUI_ACTIVE".split(),
+    }
+    t0 = time.perf_counter()
+    dbs, took = {}, {}
+    env = dict(os.environ, TMPDIR="/tmp")
+    env.pop("LL_LIB_OVERRIDE", None)
+    with tempfile.TemporaryDirectory(prefix="ll_pmc_", dir="/tmp") as tmp:
+        for tag, ctrs in sets.items():
+            left = budget_s - (time.perf_counter() - t0)
+            if left < 20:
+                break
+            out = os.path.join(tmp, tag)
+            cmd = [prof, "--kernel-trace", "--pmc", *ctrs, "-d", out, "-o", "p", "--", sys.executable, os.path.join(ROOT, "bench.py"),
+                   "--as-pmc-probe", "--model", args.model, "--quant", args.quant, "--dtype", args.dtype, "--batch", str(args.batch)]
+            t1 = time.perf_counter()
+            try:
+                r = subprocess.run(cmd, cwd=tmp, env=env, capture_output=True, text=True, timeout=min(left, 90.0))
+            except Exception:
+                continue
+            took[tag] = round(time.perf_counter() - t1, 1)
+            db = None
+            for dirpath, _, files in os.walk(out):
+                for f in files:
+                    if f.endswith("_results.db"):
+                        db = os.path.join(dirpath, f)
+            if r.returncode == 0 and db and '"pmc_probe": "ok"' in r.stdout:
+                dbs[tag] = db
+        res = {"how": "rocprofv3 --kernel-trace --pmc <one counter set per pass> over `bench.py --as-pmc-probe` (the projections of three "
+                      "decoder layers at the model's widths, eager launches, batch %d) in subprocesses of this run; passes (s): %s"
+                      % (args.batch, json.dumps(took))}
+        gemms = ["wgemm", "wss_kernel", "dense8", "dense_ss"]
+        try:
+            if "FETCH_SIZE" in dbs and "WRITE_SIZE" in dbs and args.quant == "int4":
+                gf = {k: v for k, v in pmc_traffic.per_kernel(dbs["FETCH_SIZE"], "FETCH_SIZE", gemms).items()}
+                gw = {k: v for k, v in pmc_traffic.per_kernel(dbs["WRITE_SIZE"], "WRITE_SIZE", gemms).items()}
+                if gf and gw:
+                    res["traffic"] = pmc_traffic.summarise(gf, gw, {}, {}, "live_run")
+            if "A" in dbs and "B" in dbs:
+                rows = pmc_sq.rows_from(pmc_sq.load(dbs["A"]), pmc_sq.load(dbs["B"]), gemms + ["wgemm16_rows"])
+                res["sq"] = [{k: (round(v, 4) if isinstance(v, float) else v) for k, v in r.items()} for r in rows]
+        except Exception as exc:
+            res["error"] = f"{type(exc).__name__}: {exc}"
+    return res if ("traffic" in res or "sq" in res) else None
 
 
 def moe_roofline(model, batch, iters=6):
@@ -779,6 +904,9 @@ def main():
         args.no_secondary = True
         if args.quant not in ("smoothquant", "fp8", "int8"):  # the 8-bit configurations carry their own TTFT (round-5 review, item 7)
             args.no_prefill = True
+    if args.as_pmc_probe:
+        pmc_probe(args)
+        return
     if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
         raise SystemExit(self_launch(args))
     rank = int(os.environ.get("RANK", 0))
@@ -980,7 +1108,14 @@ def main():
                 result["prefill"] = prefill_point(model, args, dev, act_dtype, geo, tp, prompt_len=min(args.ctx, 512))
             except Exception as exc:
                 result["prefill"] = {"error": f"{type(exc).__name__}: {exc}"}
-        rf = gemm_roofline(model, args.batch, args.quant)
+        live = None
+        if (world == 1 and not args.no_live_pmc and not args.as_secondary and not args.as_shard_sim and not geo.num_experts
+                and args.quant in ("int4", "smoothquant") and args.batch <= 64):
+            try:  # round-5 review, "weak" 10: counters of THIS run next to the timed launches (stored values only as a fallback)
+                live = live_pmc_counters(args)
+            except Exception:
+                live = None
+        rf = gemm_roofline(model, args.batch, args.quant, live_pmc=live)
         if geo.num_experts and quant is not None:
             try:  # the dominant kernel of a MoE model is the grouped expert GEMM; the dense projections stay as a second object
                 mrf = moe_roofline(model, args.batch)

@@ -28,9 +28,8 @@ def load(path):
     return out
 
 
-def main():
-    a, b = load(sys.argv[1]), load(sys.argv[2])
-    subs = sys.argv[3:] or ["wgemm4", "wgemm3", "dense8_kernel", "fd_stage1", "skip_rmsnorm_partials", "moe_gemm"]
+def rows_from(a, b, subs):
+    """Derived per-kernel rows (see the module docstring) from the two passes' tables for kernels whose name contains one of ``subs``."""
     rows = []
     for name in sorted(set(a) | set(b)):
         if not any(s in name for s in subs):
@@ -51,6 +50,13 @@ def main():
              "lds_conflict_frac": (g(cb, "SQ_LDS_BANK_CONFLICT") / g(cb, "SQ_LDS_IDX_ACTIVE")) if g(cb, "SQ_LDS_IDX_ACTIVE") else None,
              "wait_inst_lds_per_wave_cycle": (g(cb, "SQ_WAIT_INST_LDS") / wave) if wave and g(cb, "SQ_WAIT_INST_LDS") is not None else None}
         rows.append(r)
+    return rows
+
+
+def main():
+    a, b = load(sys.argv[1]), load(sys.argv[2])
+    subs = sys.argv[3:] or ["wgemm4", "wgemm3", "dense8_kernel", "fd_stage1", "skip_rmsnorm_partials", "moe_gemm"]
+    rows = rows_from(a, b, subs)
     f = lambda v, p=3: "-" if v is None else (f"{v:.{p}f}" if isinstance(v, float) else str(v))
     print("| kernel | launches | kernel cycles | MFMA util | LDS busy | wave wait | issue stall | wave active | VALU active | LDS conflict | MFMA / VALU / LDS insts |")
     print("|---|---|---|---|---|---|---|---|---|---|---|")
