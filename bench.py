@@ -140,7 +140,7 @@ def projection_launches(model, quant):
     return launches_list, solo
 
 
-def gemm_roofline(model, batch, quant, iters=6, live_pmc=None):
+def gemm_roofline(model, batch, quant, iters=6, live_pmc=None, time_it=True):
     """Average launch duration of the dominant kernel (the weight-streaming dequant-GEMM) over every
     projection of the model with its real weights -- the same calls the decode step makes (fused [q|k|v],
     fused [gate|up] + swiglu, row-parallel projections in split-K partial mode) -- by HIP events on the
@@ -155,35 +155,39 @@ def gemm_roofline(model, batch, quant, iters=6, live_pmc=None):
     xs = {k: (torch.randn(batch, k, device=dev) * 0.5).to(adt) for _, k, _ in launches_list}
     per_w = {"int4": 0.5 + 8.0 / 128, "int8": 1.0, "smoothquant": 1.0, "fp8": 1.0, "none": 2.0}[quant]
     nbytes = sum(w * per_w for _, _, w in launches_list)
-    stream = torch.cuda.current_stream()
-    for fn, k, _ in launches_list:  # warm
-        fn(xs[k])
-    torch.cuda.synchronize()
-    replay, how = None, "eager launches"
-    try:
-        g = torch.cuda.CUDAGraph()
-        with torch.cuda.graph(g):
-            for fn, k, _ in launches_list:
-                fn(xs[k])
-        g.replay()
+    elapsed_ms, how = 1.0, "not timed (counter merge only)"
+    if time_it:
+        stream = torch.cuda.current_stream()
+        for fn, k, _ in launches_list:  # warm
+            fn(xs[k])
         torch.cuda.synchronize()
-        replay, how = g.replay, "hipGraph replay of the launch list"
-    except Exception:  # capture refused: time the eager launches (gaps included)
+        replay, how = None, "eager launches"
+        try:
+            g = torch.cuda.CUDAGraph()
+            with torch.cuda.graph(g):
+                for fn, k, _ in launches_list:
+                    fn(xs[k])
+            for _ in range(3):  # warm replays (clocks, caches) in front of the timed ones
+                g.replay()
+            torch.cuda.synchronize()
+            replay, how = g.replay, "hipGraph replay of the launch list"
+        except Exception:  # capture refused: time the eager launches (gaps included)
+            torch.cuda.synchronize()
+        stream = torch.cuda.current_stream()
+        e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        e0.record(stream)
+        for _ in range(iters):
+            if replay is not None:
+                replay()
+            else:
+                for fn, k, _ in launches_list:
+                    fn(xs[k])
+        e1.record(stream)
         torch.cuda.synchronize()
-    stream = torch.cuda.current_stream()
-    e0, e1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-    e0.record(stream)
-    for _ in range(iters):
-        if replay is not None:
-            replay()
-        else:
-            for fn, k, _ in launches_list:
-                fn(xs[k])
-    e1.record(stream)
-    torch.cuda.synchronize()
+        elapsed_ms = e0.elapsed_time(e1)
     nl = len(launches_list)
     launches = iters * nl  # projections timed (a format's quantiser / finish launches ride inside their projection's share)
-    avg_s = e0.elapsed_time(e1) * 1e-3 / (iters * nl)
+    avg_s = elapsed_ms * 1e-3 / (iters * nl)
     bytes_per_launch = nbytes / nl
     achieved = bytes_per_launch / avg_s
     traffic, traffic_source, traffic_parts = None, None, None
@@ -1108,14 +1112,19 @@ def main():
                 result["prefill"] = prefill_point(model, args, dev, act_dtype, geo, tp, prompt_len=min(args.ctx, 512))
             except Exception as exc:
                 result["prefill"] = {"error": f"{type(exc).__name__}: {exc}"}
-        live = None
-        if (world == 1 and not args.no_live_pmc and not args.as_secondary and not args.as_shard_sim and not geo.num_experts
-                and args.quant in ("int4", "smoothquant") and args.batch <= 64):
+        live_wanted = (world == 1 and not args.no_live_pmc and not args.as_secondary and not args.as_shard_sim and not geo.num_experts
+                       and args.quant in ("int4", "smoothquant") and args.batch <= 64)
+        # the launches are timed FIRST, on the warm chip (the counter passes below leave this process idle for ~12 s: a timing taken
+        # after them starts on a chip that has dropped its clocks); the counters of the run are merged into the object afterwards
+        rf = gemm_roofline(model, args.batch, args.quant)
+        if live_wanted and rf is not None:
             try:  # round-5 review, "weak" 10: counters of THIS run next to the timed launches (stored values only as a fallback)
                 live = live_pmc_counters(args)
+                if live:
+                    rf_live = gemm_roofline(model, args.batch, args.quant, live_pmc=live, time_it=False)
+                    rf.update({k: rf_live[k] for k in ("traffic", "traffic_parts", "traffic_source", "mfma_util")})
             except Exception:
-                live = None
-        rf = gemm_roofline(model, args.batch, args.quant, live_pmc=live)
+                pass
         if geo.num_experts and quant is not None:
             try:  # the dominant kernel of a MoE model is the grouped expert GEMM; the dense projections stay as a second object
                 mrf = moe_roofline(model, args.batch)

@@ -743,7 +743,7 @@ extern "C" int ll_moe_gemm(void* c, const void* a, const void* w, const float* w
                            int64_t s_stride_k, int dtype, void* stream) {
   if (dtype != LL_F16) return LL_ERR_DTYPE;  // the reference MoE path is fp16 end to end
   if (wfmt != LL_W_F16 && wfmt != LL_W_FP8E4M3 && wfmt != LL_W_INT8) return LL_ERR_DTYPE;
-  if (block_m != 16 && block_m != 32 && block_m != 64) return LL_ERR_SHAPE;
+  if (block_m != 16 && block_m != 32 && block_m != 64 && block_m != 128) return LL_ERR_SHAPE;
   if (n <= 0 || k <= 0 || top_k <= 0 || k % 8 != 0 || a_stride_m % 8 != 0) return LL_ERR_SHAPE;
   if (mul_routed_weight < 0 || mul_routed_weight > 3 || ((mul_routed_weight & 2) && (n & 1))) return LL_ERR_SHAPE;
   if (wfmt != LL_W_F16 && (!w_scale || group_n <= 0 || group_k <= 0)) return LL_ERR_ARG;
@@ -763,9 +763,13 @@ extern "C" int ll_moe_gemm(void* c, const void* a, const void* w, const float* w
   const bool lines = !v1_forced && k % 128 == 0 && (w_stride_n * (wfmt == LL_W_F16 ? 2 : 1)) % 16 == 0 &&
                      (w_stride_e * (wfmt == LL_W_F16 ? 2 : 1)) % 16 == 0 && ll_aligned16(w) && ll_aligned16(a) &&
                      (wfmt == LL_W_F16 || group_k % 64 == 0);
+  // 128-row blocks (round 6: prefill-sized inputs, hundreds of rows per expert): the full-line form only -- a weight tile is
+  // dequantised once for four MFMA row tiles and re-read from L2 half as often as with 64-row blocks
+  if (block_m == 128 && !lines) return LL_ERR_SHAPE;
 #define LL_MOE(WF)                                                                  \
   if (lines) {                                                                      \
-    if (block_m == 64) moe_gemm_kernel2<WF, 2><<<grid, 256, 0, st>>>(p);            \
+    if (block_m == 128) moe_gemm_kernel2<WF, 4><<<grid, 256, 0, st>>>(p);           \
+    else if (block_m == 64) moe_gemm_kernel2<WF, 2><<<grid, 256, 0, st>>>(p);       \
     else moe_gemm_kernel2<WF, 1><<<grid, 256, 0, st>>>(p);                          \
   } else if (block_m == 64) moe_gemm_kernel<WF, 2><<<grid, 256, 0, st>>>(p);        \
   else moe_gemm_kernel<WF, 1><<<grid, 256, 0, st>>>(p)

@@ -145,6 +145,12 @@ def fused_moe(
     flat_weights = topk_weights.reshape(-1).to(dtype).contiguous()
 
     block_m = _block_m(num_tokens)
+    if (num_tokens * top_k >= 256 * num_experts and hidden % 128 == 0 and intermediate % 128 == 0
+            and (not wfmt or all(gk >= kdim or gk % 64 == 0 for gk, kdim in ((g1[1], hidden), (g2[1], intermediate))))
+            and w1.stride(1) % 16 == 0 and w2.stride(1) % 16 == 0 and w1.stride(0) % 16 == 0 and w2.stride(0) % 16 == 0):
+        # (extension, round 6) prefill-sized inputs -- 256+ rows per expert on average: 128-row blocks on the full-line grouped GEMM
+        # (a weight tile is dequantised once for four MFMA row tiles and re-read from L2 half as often); same values per slot
+        block_m = 128
     if aligned is not None and aligned[3] == block_m:  # (extension) moe_align_block_size already ran inside the router's launch
         sorted_ids, expert_ids, num_post = aligned[:3]
     else:

@@ -1017,6 +1017,52 @@ def test_fused_moe_routing_weight_and_quant():
         K().fused_moe(x.to(DEV), q1.to(DEV), w2.half().to(DEV), wts.to(DEV), ids.to(DEV), w1_scale=s1.to(DEV))
 
 
+@pytest.mark.parametrize("fmt", ["f16", "fp8_block", "int8_channel"])
+def test_fused_moe_prefill_sized_input_128_row_blocks_equal_64_row_blocks_and_oracle(fmt, monkeypatch):
+    """Round 6: 256+ rows per expert on average -> 128-row blocks on the full-line grouped GEMM (and the multi-workgroup align):
+    every output equal, bit for bit, to the 64-row-block route (same arithmetic per slot), and within 2e-2 of the oracle."""
+    import importlib
+    FM = importlib.import_module("lite_llama_amd.kernels.fused_moe")  # (the package attribute of that name is the function)
+    num_tokens, num_experts, top_k, hidden, inter = 1100, 4, 2, 256, 128
+    g = torch.Generator().manual_seed(77)
+    x = (torch.randn(num_tokens, hidden, generator=g) / hidden**0.5).half()
+    w1 = torch.randn(num_experts, 2 * inter, hidden, generator=g) / hidden**0.5
+    w2 = torch.randn(num_experts, hidden, inter, generator=g) / inter**0.5
+    ids = torch.randint(0, num_experts, (num_tokens, top_k), generator=g)
+    ids[:, 1] = (ids[:, 0] + 1 + torch.randint(0, num_experts - 1, (num_tokens,), generator=g)) % num_experts
+    wts = torch.softmax(torch.randn(num_tokens, top_k, generator=g), dim=-1).half()
+    if fmt == "f16":
+        ws, kw = (w1.half(), w2.half()), {}
+    elif fmt == "int8_channel":
+        (q1, s1), (q2, s2) = O.quantize_int8_per_channel(w1), O.quantize_int8_per_channel(w2)
+        ws, kw = (q1, q2), dict(w1_scale=s1, w2_scale=s2, group_n=1, group_k=hidden)
+    else:
+        q1 = (w1 * 8).to(torch.float8_e4m3fn).view(torch.uint8)
+        q2 = (w2 * 8).to(torch.float8_e4m3fn).view(torch.uint8)
+        s1 = (torch.rand(num_experts, 2 * inter // 128, hidden // 128, generator=g) + 0.5) / 8
+        s2 = (torch.rand(num_experts, hidden // 128, inter // 128, generator=g) + 0.5) / 8
+        ws, kw = (q1, q2), dict(w1_scale=s1, w2_scale=s2, group_n=128, group_k=128)
+    ref = O.fused_moe(x, ws[0], ws[1], wts, ids, **kw)
+    dkw = {k: (v.to(DEV) if torch.is_tensor(v) else v) for k, v in kw.items()}
+    blocks = []
+    real = FM._moe_gemm
+
+    def spy(*a):
+        blocks.append(a[-1])
+        return real(*a)
+
+    monkeypatch.setattr(FM, "_moe_gemm", spy)
+    big = K().fused_moe(x.to(DEV), ws[0].to(DEV), ws[1].to(DEV), wts.to(DEV), ids.to(DEV), **dkw)
+    assert blocks and all(b == 128 for b in blocks), blocks
+    close(big, ref, 2e-2)
+    blocks.clear()
+    monkeypatch.setattr(FM, "_block_m", lambda n: 64)
+    half = K().fused_moe(x[:500].to(DEV), ws[0].to(DEV), ws[1].to(DEV), wts[:500].to(DEV), ids[:500].to(DEV), **dkw)  # < 256 rows / expert
+    assert blocks and all(b == 64 for b in blocks), blocks
+    big500 = big[:500]
+    assert torch.equal(half, big500)
+
+
 def _interleave_rows(w):
     e, two_i = w.shape[0], w.shape[1]
     i = two_i // 2
