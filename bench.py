@@ -82,6 +82,10 @@ def parse():
                          "collective: a ceiling of the scaling curve, not a scaling point (\"shard_sim\" in the line)")
     ap.add_argument("--as-shard-sim", type=int, default=0,
                     help="(used by --shard-sim) run as rank 0 of this TP degree with simulated collectives; bounded line")
+    ap.add_argument("--parallelism", default="tp", choices=["tp", "dp"],
+                    help="--gpus N > 1: tp (default; BASELINE.json's metric is the TP = 1/2/4/8 curve) = the largest tensor-parallel "
+                         "degree with a shard plan, remaining ranks as replicas; dp = N independent replicas of the one-GPU step "
+                         "(no collective on the data path, weak scaling: batch 64 PER replica)")
     ap.add_argument("--as-pmc-probe", action="store_true",
                     help="(used by the live counter leg) build a 3-layer model of --model / --quant at its real widths, issue the "
                          "dense projections' launch list eagerly a few times and exit: the workload of a rocprofv3 --pmc pass")
@@ -956,6 +960,8 @@ def main():
         unit = scale_unit(None if args.quant == "none" else QuantConfig.for_runtime_scheme(args.quant), geo.intermediate_size)
         tp = admissible_tp(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, world, unit)  # the model's own rule
         plan_note = make_plan(geo.num_heads, geo.num_kv_heads, geo.head_dim, geo.intermediate_size, tp, unit).describe()
+    if args.parallelism == "dp" and not args.as_shard_sim:
+        tp, plan_note = 1, "replicas only (--parallelism dp): every rank runs the whole one-GPU step on its own batch, no collective"
     if args.as_shard_sim > 1:
         if world != 1:
             raise SystemExit("--as-shard-sim is a one-process mode")
