@@ -375,7 +375,7 @@ extern "C" int ll_moe_align_block_size_ws(const void* topk_ids, int ids_width, i
                                           int32_t* sorted_ids, int32_t* expert_ids, int32_t* num_post, int32_t* workspace,
                                           int64_t workspace_ints, void* stream) {
   const int64_t want = ll_moe_align_workspace_ints(num_slots, num_experts);
-  if (want == 0 || !workspace || workspace_ints < want || ids_width < 0 || (ids_width != LL_I32 && ids_width != LL_I64) ||
+  if (want == 0 || !workspace || workspace_ints < want || (ids_width != LL_I32 && ids_width != LL_I64) ||
       block_size <= 0 || num_slots + (int64_t)num_experts * (block_size - 1) >= (1ll << 31))
     return ll_moe_align_block_size(topk_ids, ids_width, num_slots, num_experts, block_size, sorted_ids, expert_ids, num_post, stream);
   const int max_padded = (int)num_slots + num_experts * (block_size - 1);
