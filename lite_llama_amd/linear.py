@@ -318,8 +318,10 @@ class MergedColumnLinear:
         """The merged projection left as fp32 split-K partials (:class:`PartialSums`, bias NOT added -- returned next
         to it) for a consumer that adds them up (``decode_attention_partials``); ``None`` when not served."""
         h = self._holder
-        if h is None or h.interleaved or not hasattr(h.quant_method, "apply_partials") or get_tp_world_size() != 1 \
-                or collective_forced():
+        # (column-parallel: the planes and their consumer are this rank's own -- no collective is involved, so a TP shard takes the
+        # route like the unsharded model; until round 6 it was declined under TP and a 1-MB q|k|v shard ran the finishing unit
+        # loop on 30 workgroups: 11 us per layer at TP 8)
+        if h is None or h.interleaved or not hasattr(h.quant_method, "apply_partials"):
             return None
         parts = h.quant_method.apply_partials(h, x, allow_bias=True, max_splits=8)  # the attention kernel adds <= 8 planes
         return None if parts is None else (parts, h.bias)
