@@ -237,6 +237,11 @@ int ll_w4a16_partials_count_ex(int64_t m, int64_t n, int64_t k, int group_size, 
  * groups per work item R, k-slices S (= planes), pieces per consumer wave (template bound), 64-k blocks per slice, slices with one
  * block more, LDS bytes]. */
 int ll_w4a16_short_plan(int64_t m, int64_t n, int64_t k, int group_size, int32_t* out8);
+/* ... and of its all-of-K form for narrow FINISHED outputs (gemm_short_full.hip; ll_w4a16_matmul_prepacked routes epilogues 0 / 1
+ * there when the row-group engine does not take the launch): out8 = [takes it 0 / 1, work items (= grid), row groups per item R,
+ * 32-row batch tiles per item, batch halves, pieces per consumer wave (template bound), ring slots, LDS bytes].
+ * Semantics: kernels/quantization/w4a16.py:152-207 (+ bias), kernels/swiglu.py:45-65 for the fused gate|up. */
+int ll_w4a16_short_full_plan(int64_t m, int64_t n, int64_t k, int group_size, int32_t* out8);
 int ll_w4a16_matmul_prepacked(void* out, const void* x, const void* wpacked, const void* spacked,
                               const void* bias, int64_t m, int64_t n, int64_t k, int group_size,
                               int64_t x_stride_m, float* workspace, int32_t* counters, int epilogue,

@@ -49,6 +49,7 @@ SIGNATURES = {
     "ll_w4a16_partials_count": [L, L, L, I],
     "ll_w4a16_partials_count_ex": [L, L, L, I, I],
     "ll_w4a16_short_plan": [L, L, L, I, P],
+    "ll_w4a16_short_full_plan": [L, L, L, I, P],
     "ll_skip_rmsnorm_partials": [P, P, I, P, P, L, L, F, I, P],
     "ll_skip_rmsnorm_slots": [P, P, I, P, P, L, L, F, I, P],
     "ll_w4a16_matmul_prepacked": [P, P, P, P, P, L, L, L, I, L, P, P, I, P],

@@ -95,5 +95,9 @@ int v4_launch(void* out, const void* x, const void* wpacked, const void* spacked
               int group_size, int64_t x_stride_m, int epilogue, int kslices, void* stream);
 // ... and the short-stream engine for split-K partial launches of a few tens of KB per CU (gemm_short.hip)
 int ss_partials_slices(int64_t m, int64_t n, int64_t k, int group_size);  // planes it leaves; 0: not its launch
+// the short-stream engine with finished outputs (gemm_short_full.hip): narrow projections that must leave fp16 rows
+int sf_wants(int64_t m, int64_t n, int64_t k, int group_size, int epilogue);
+int sf_launch(void* out, const void* x, const void* wpacked, const void* spacked, const void* bias, int64_t m, int64_t n, int64_t k,
+              int group_size, int64_t x_stride_m, int epilogue, void* stream);
 int ss_launch(void* out, const void* x, const void* wpacked, const void* spacked, int64_t m, int64_t n, int64_t k, int group_size,
               int64_t x_stride_m, void* stream);

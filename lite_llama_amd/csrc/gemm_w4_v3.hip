@@ -1048,6 +1048,10 @@ static int v3_launch(void* out, const void* x, const void* wpacked, const void* 
   // round 6: split-K partial launches whose stream is a few tens of KB per CU run on the short-stream engine (gemm_short.hip)
   if (partials && !((epilogue >> 8) & 3) && ss_partials_slices(m, n, k, group_size) > 0)
     return ss_launch(out, x, wpacked, spacked, m, n, k, group_size, x_stride_m, stream);
+  // ... and narrow FINISHED outputs (the reference-shaped layer's q / k|v / o calls, the fused gate|up of a TP >= 4 shard) on its
+  // all-of-K form (gemm_short_full.hip): the sums meet inside the workgroup, no slabs, no counters
+  if (!partials && !v4_wants(m, n, k, group_size, epilogue) && sf_wants(m, n, k, group_size, epilogue))
+    return sf_launch(out, x, wpacked, spacked, bias, m, n, k, group_size, x_stride_m, epilogue, stream);
   const V3Plan pl = v3_plan(n, k, (epilogue >> 8) & 3, partials);
   // round 5: the row-group engine (gemm_w4_v4.hip) takes the launch when its plan serves the shape -- same layouts, same planes
   if (v4_wants(m, n, k, group_size, epilogue))

@@ -444,10 +444,12 @@ struct V4Knobs {
                     // measure +-0 / +0.5 us on this body, DESIGN_NOTEBOOK.md 4.5)
   int rg_part = 4;  // LL_GEMM4_RGP: row groups per tile of a split-K partial launch (2 or 4)
   int min_fill = 3; // finished-output launches take this engine from min_fill row groups per CU on
+  int small = 0;    // LL_GEMM4_SMALL: ... and, below that fill, from this many row groups on (0: never; round 6, TP shards)
   V4Knobs() {
     if (const char* e = getenv("LL_GEMM4")) on = atoi(e);
     if (const char* e = getenv("LL_GEMM4_RGP")) rg_part = atoi(e) == 2 ? 2 : 4;
     if (const char* e = getenv("LL_GEMM4_MINFILL")) min_fill = atoi(e);
+    if (const char* e = getenv("LL_GEMM4_SMALL")) small = atoi(e);
   }
 };
 static const V4Knobs& v4_knobs() {
@@ -471,7 +473,13 @@ static int v4_full_nrgt(int64_t n) {
   const int cus = v4_num_cus();
   const int64_t rgs = n / 32;
   const int per = (int)((rgs + cus - 1) / cus);
-  if (rgs < (int64_t)v4_knobs().min_fill * cus) return 0;
+  if (rgs < (int64_t)v4_knobs().min_fill * cus) {
+    // fewer row groups than min_fill per CU -- the fused gate|up of a TP shard (592 / 296 / 148 row groups at TP 2 / 4 / 8): one
+    // workgroup per CU (or per row group) with 1 .. 4 row groups each on the 2- / 4-group instances, from `small` row groups on
+    const int small = v4_knobs().small;
+    if (small <= 0 || rgs < small) return 0;
+    return per <= 2 ? 2 : per <= 4 ? 4 : 0;
+  }
   return (per == 2 || per == 4 || per == 5) ? per : 0;
 }
 

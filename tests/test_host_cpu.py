@@ -76,6 +76,33 @@ def test_w4a16_short_stream_plan_host_side():
     assert plan(65, 4608, 3584)["takes"] == 0 and plan(64, 4608, 3584, 96)["takes"] == 0
 
 
+def test_w4a16_short_stream_full_k_plan_host_side():
+    """Host-side plan of the short-stream engine's all-of-K form (csrc/gemm_short_full.hip, round 6; 256 CUs assumed without a
+    device): narrow FINISHED outputs -- the reference-shaped layer's q / k|v / o calls, the fused gate|up of a TP >= 4 shard -- in one
+    round of workgroups, 32-row batch halves when they fit, <= 16 weight pieces per consumer wave; wide outputs and long K are left to
+    the row-group engine / unit loop."""
+    import ctypes
+    from lite_llama_amd import _lib
+
+    lib = _lib.lib()
+
+    def plan(m, n, k, g=128):
+        out = (ctypes.c_int32 * 8)()
+        assert lib.ll_w4a16_short_full_plan(m, n, k, g, out) == 0
+        return dict(zip(("takes", "items", "R", "MT", "halves", "P", "slots", "lds"), out))
+
+    for m, n, k, want in [(64, 3584, 3584, (1, 1, 2)), (64, 1024, 3584, (1, 1, 2)), (32, 3584, 3584, (1, 1, 1)), (64, 4608, 3584, (2, 1, 2)),
+                          (64, 9472, 3584, (2, 2, 1)), (17, 4096, 4096, (1, 1, 1)), (64, 2048, 1536, (1, 1, 2)), (64, 8192, 4096, (2, 1, 2))]:
+        p = plan(m, n, k)
+        assert p["takes"] == 1 and (p["R"], p["MT"], p["halves"]) == want, (m, n, k, p)
+        assert p["items"] == n // 32 // p["R"] * p["halves"] <= 256
+        kq = 8 // p["R"]
+        assert (k // 64 + kq - 1) // kq <= p["P"] <= 16 and p["P"] % 4 == 0
+        assert p["slots"] >= kq and p["slots"] * p["MT"] * 32 * 256 <= p["lds"] <= 160 * 1024   # >= two rounds of chunk tiles
+    for m, n, k in [(64, 37888, 3584), (64, 18944, 3584), (64, 3584, 18944), (65, 3584, 3584), (64, 256, 3584), (64, 3584, 9216)]:
+        assert plan(m, n, k)["takes"] == 0, (m, n, k)
+
+
 def test_kernel_names_match_reference_surface():
     import lite_llama_amd.kernels as k
 

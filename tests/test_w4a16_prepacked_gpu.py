@@ -222,6 +222,68 @@ def test_short_stream_unpack_bit_exact_at_every_k_position():
         assert torch.equal(got, nib[:, k0:k0 + 64].t().contiguous()), k0
 
 
+def _short_full_plan(m, n, k, gs=128):
+    import ctypes
+    import lite_llama_amd._lib as L_
+    out = (ctypes.c_int32 * 8)()
+    assert L_.lib().ll_w4a16_short_full_plan(m, n, k, gs, out) == 0
+    return dict(zip(("takes", "items", "R", "MT", "halves", "P", "slots", "lds"), out))
+
+
+def test_short_stream_full_k_unpack_bit_exact_at_every_k_position():
+    """Round 6, csrc/gemm_short_full.hip (finished outputs, all of K per workgroup, activations through a ring): x = one-hot rows,
+    scale 1, zero 0 -> the output IS the nibble matrix, for every k position -- K long enough that the ring wraps (36 chunks through
+    16 / 18 slots) -- for both batch halves and for a batch of 16 rows (whole-batch items); route asserted."""
+    n, k = 1024, 4608
+    qw = torch.randint(-(2**31), 2**31 - 1, (n, k // 8), dtype=torch.int64).to(torch.int32)
+    sc, zr = torch.ones(n, k // 128), torch.zeros(n, k // 128)
+    pw, ps = Q().pack_w4a16_weights(qw.to(DEV)), Q().pack_w4a16_scales(sc.to(DEV), zr.to(DEV))
+    nib = O.unpack_int4(qw).float()
+    for m in (64, 16):
+        p = _short_full_plan(m, n, k)
+        assert p["takes"] == 1 and p["halves"] == (2 if m > 32 else 1) and k // 128 > p["slots"], p
+        for k0 in range(0, k, m):
+            x = torch.zeros(m, k, dtype=torch.float16)
+            x[torch.arange(m), k0 + torch.arange(m)] = 1.0
+            got = Q().w4a16_matmul_prepacked(x.to(DEV), pw, ps).float().cpu()
+            assert torch.equal(got, nib[:, k0:k0 + m].t().contiguous()), (m, k0)
+
+
+@pytest.mark.parametrize("M", [1, 17, 32, 33, 64])
+@pytest.mark.parametrize("N,K_,gs,swiglu", [(3584, 3584, 128, False), (1024, 3584, 128, False), (4608, 3584, 128, True), (9472, 3584, 128, True),
+                                            (2048, 1536, 128, False), (4096, 4096, 256, False), (8192, 4096, 128, True), (512, 128, 128, False),
+                                            (1024, 256, 128, True), (640, 384, 128, False)])
+def test_short_stream_full_k_outputs_match_oracle_and_unit_loop(M, N, K_, gs, swiglu):
+    """The all-of-K short-stream form at the shapes it serves -- the reference-shaped layer's q / o / k|v projections, the fused
+    gate|up of TP 4 / 8 shards (swiglu epilogue on interleaved rows), other models' widths, every batch class incl. ragged halves --
+    against the unit loop (forced; same dequantiser, only the fp32 summation order differs: outputs equal up to one fp16 ulp of the
+    largest value) and the CPU oracle at 1e-2 (reference tolerance 5e-2, w4a16.py:152-207); bias on the plain form."""
+    g = torch.Generator().manual_seed(N * 3 + K_ + M)
+    x = (torch.randn(M, K_, generator=g) * 0.5).half()
+    qw = torch.randint(-(2**31), 2**31 - 1, (N, K_ // 8), dtype=torch.int64, generator=g).to(torch.int32)
+    sc = torch.rand(N, K_ // gs, generator=g) * 0.01 + 0.005
+    zr = torch.randint(0, 16, (N, K_ // gs), generator=g).float()
+    bias = None if swiglu else (torch.randn(N, generator=g) * 0.1).half()
+    pw, ps = Q().pack_w4a16_weights(qw.to(DEV)), Q().pack_w4a16_scales(sc.to(DEV), zr.to(DEV))
+    p = _short_full_plan(M, N, K_, gs)
+    assert p["takes"] == 1, p
+    kw = dict(group_size=gs, gate_up_swiglu=True) if swiglu else dict(group_size=gs, bias=bias.to(DEV))
+    a = Q().w4a16_matmul_prepacked(x.to(DEV), pw, ps, **kw)
+    b = Q().w4a16_matmul_prepacked(x.to(DEV), pw, ps, _tile_blocks=1, **kw)   # the unit loop, forced
+    again = Q().w4a16_matmul_prepacked(x.to(DEV), pw, ps, **kw)
+    assert torch.equal(a, again) and a.shape == (M, N // 2 if swiglu else N) and bool(torch.isfinite(a).all())
+    scale = b.float().abs().max().item()
+    assert (a.float() - b.float()).abs().max().item() <= scale * 2.0 ** -9 + 1e-6
+    if M in (17, 64) and N * K_ <= 4608 * 3584:
+        full = O.w4a16_matmul(x, qw, sc, zr, group_size=gs).float()
+        if swiglu:
+            f16 = full.half().float()
+            ref = torch.nn.functional.silu(f16[:, 0::2]) * f16[:, 1::2]
+        else:
+            ref = full + bias.float()
+        close(a, ref.half(), 3e-2 if swiglu else 1e-2)  # (silu(g) * u multiplies two fp16-rounded sums: W4A16's own bar is 5e-2)
+
+
 @pytest.mark.parametrize("M", [1, 17, 32, 33, 64])
 @pytest.mark.parametrize("N,K_,gs", [(4608, 3584, 128), (3584, 3584, 128), (2304, 3584, 128), (3584, 2432, 128), (4736 // 128 * 128, 3584, 128),
                                      (5120, 2048, 128), (2048, 4096, 256), (1024, 512, 512), (128, 128, 128)])
