@@ -3,7 +3,7 @@
 // Triton kernel tiles M x N and dequantises a [BLOCK_N, BLOCK_K] weight tile per k-step for a whole BLOCK_M of rows; the
 // decode engines (gemm_w4_v3 / v4) stream the weights once for <= 64 rows and gemm_wq.hip loops that 64-row tile over M
 // (32 768 prompt rows re-stream and re-dequantise the weights 512 times: 472 TFLOP/s, round-5 measurement).  Here:
-//   * tile 256 rows of X x 256 weight rows x 64 k; 8 waves = 2 (M halves) x 4 (N quarters), wave tile 128 x 64 -> 8 MFMA
+//   * tile 128 (round 6; 256 in round 5: LL_PF_WMH=2) rows of X x 256 weight rows x 64 k; 4 waves = N quarters (8 = 2 M halves x 4), wave tile 128 x 64 -> 8 MFMA
 //     32x32x16 accumulators (128 registers); A operand = dequantised weights, B operand = activations (so a lane ends up with
 //     consecutive output columns of ONE token row: 16-byte stores after one v_permlane32_swap, the decode engines' epilogue);
 //   * the weight tile is dequantised ONCE per 256 token rows: every thread fetches 16 B of the packed stream per k-step
@@ -20,11 +20,11 @@
 #include "common.h"
 #include "gemm_w4_common.h"
 
-#define PF_THREADS 512
-#define PF_BM 256
 #define PF_BN 256
 #define PF_BK 64
-#define PF_TILE (256 * PF_BK * 2)  // bytes of one [256][64] fp16 tile
+#ifndef PF_WMH_DEFAULT
+#define PF_WMH_DEFAULT 1  // 128-row M halves per workgroup (see the kernel; measured: 16.3 -> 15.2 ms per Qwen2.5-7B layer at 32 768 rows)
+#endif
 #ifndef PF_XR
 #define PF_XR 3  // activation-tile ring slots (32 KB each): tiles are requested PF_XR - 1 k-steps ahead
 #endif
@@ -44,7 +44,13 @@ struct PfParams {
 
 __device__ __forceinline__ int pf_swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
 
-__global__ __launch_bounds__(PF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void wgemm_prefill_kernel(const PfParams p) {
+// WMH: 128-row M halves per workgroup.  2 = the 256 x 256 tile on 8 waves, ONE workgroup per CU (round 5).  1 = a 128 x 256 tile on 4
+// waves (round 6): 48 KB of LDS and one wave per SIMD, so two or three workgroups share a CU and one's per-k-step barrier stall is
+// covered by the others' MFMAs (the weight fragment is dequantised once per 128 token rows either way).
+template <int WMH>
+__global__ __launch_bounds__(WMH * 256) __attribute__((amdgpu_waves_per_eu(2, WMH == 2 ? 2 : 3))) void wgemm_prefill_kernel(const PfParams p) {
+  constexpr int PF_BM = WMH * 128;
+  constexpr int PF_TILE = PF_BM * PF_BK * 2;  // bytes of one [PF_BM][64] fp16 tile
   extern __shared__ __attribute__((aligned(16))) unsigned char lds[];
   unsigned char* const xt = lds;  // [PF_XR][256 token rows][64 k] fp16, swizzled
   const int tid = threadIdx.x, lane = tid & 63;
@@ -84,7 +90,7 @@ __global__ __launch_bounds__(PF_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   // (wn & 1) * 2 + ni, k-half) holds the four words = k-octets h * 4 + 0..3 of weight row nl -- word kk IS the A operand of MFMA
   // k-step kk (the decode engines' pairing: a k-step contracts octets kk and 4 + kk), so nothing is staged through LDS and
   // nothing is written back; the two waves that share a weight quarter each dequantise it (VALU under the other wave's MFMAs).
-  const int wm = wv >> 2, wn = wv & 3;
+  const int wm = WMH == 2 ? wv >> 2 : 0, wn = wv & 3;
   const int nl = lane & 31, h = lane >> 5;
   const char* wsrc[2];
   const char* ssrc[2];
@@ -245,7 +251,7 @@ extern "C" int ll_w4a16_mtiled_supported(int64_t m, int64_t n, int64_t k, int gr
   const int gdiv = group_size / 128;
   if (gdiv & (gdiv - 1)) return 0;
   if (n * k / 2 >= (1ll << 31) || n * (k / 128) * 8 >= (1ll << 31)) return 0;  // 32-bit offsets into the packed streams
-  const int64_t tiles = ((m + PF_BM - 1) / PF_BM + 15) / 16 * 16 * ((n / PF_BN + 15) / 16 * 16);
+  const int64_t tiles = ((m + 127) / 128 + 15) / 16 * 16 * ((n / PF_BN + 15) / 16 * 16);
   return tiles < (1ll << 31) ? 1 : 0;
 }
 
@@ -268,16 +274,22 @@ extern "C" int ll_w4a16_matmul_prepacked_mtiled(void* out, const void* x, const 
   while ((128 << sh) < group_size) ++sh;
   p.gshift = sh;
   p.epi = epilogue;
-  p.tiles_m = (int)((m + PF_BM - 1) / PF_BM);
+  static const int wmh_env = getenv("LL_PF_WMH") ? atoi(getenv("LL_PF_WMH")) : 0;  // A/B knob, read once (1 / 2: force the tile height)
+  const int wmh = wmh_env == 1 || wmh_env == 2 ? wmh_env : PF_WMH_DEFAULT;
+  const int bm = wmh * 128;
+  p.tiles_m = (int)((m + bm - 1) / bm);
   p.tiles_n = (int)(n / PF_BN);
   const int64_t grid = (int64_t)((p.tiles_m + 15) / 16) * ((p.tiles_n + 15) / 16) * 256;
-  static bool attr_set[16] = {false};
+  static bool attr_set[16][2] = {{false}};
   int dev = 0;
   (void)hipGetDevice(&dev);
-  if (dev >= 0 && dev < 16 && !attr_set[dev]) {
-    (void)hipFuncSetAttribute((const void*)wgemm_prefill_kernel, hipFuncAttributeMaxDynamicSharedMemorySize, PF_XR * PF_TILE);
-    attr_set[dev] = true;
+  const int lds_bytes = PF_XR * bm * PF_BK * 2;
+  if (dev >= 0 && dev < 16 && !attr_set[dev][wmh - 1]) {
+    if (wmh == 2) (void)hipFuncSetAttribute((const void*)wgemm_prefill_kernel<2>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    else (void)hipFuncSetAttribute((const void*)wgemm_prefill_kernel<1>, hipFuncAttributeMaxDynamicSharedMemorySize, lds_bytes);
+    attr_set[dev][wmh - 1] = true;
   }
-  wgemm_prefill_kernel<<<dim3((unsigned)grid), PF_THREADS, PF_XR * PF_TILE, (hipStream_t)stream>>>(p);
+  if (wmh == 2) wgemm_prefill_kernel<2><<<dim3((unsigned)grid), 512, lds_bytes, (hipStream_t)stream>>>(p);
+  else wgemm_prefill_kernel<1><<<dim3((unsigned)grid), 256, lds_bytes, (hipStream_t)stream>>>(p);
   return LL_LAUNCH_CHECK();
 }

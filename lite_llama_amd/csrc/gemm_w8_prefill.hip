@@ -20,9 +20,10 @@
 #include "gemm_w4_common.h"
 #include "gemm_w8_common.h"
 
-#define P8_THREADS 512
-#define P8_BM 256
 #define P8_BN 256
+#ifndef P8_WMH_DEFAULT
+#define P8_WMH_DEFAULT 1  // 128-row M halves per workgroup: 1 = 128 x 256 tiles on 4 waves, two workgroups per CU (round 6; see gemm_w4_prefill.hip)
+#endif
 
 struct P8Params {
   uint16_t* out;            // fp16 [M][N]
@@ -40,11 +41,14 @@ struct P8Params {
 __device__ __forceinline__ int p8_swz(int row, int slot) { return slot ^ ((row >> 1) & 7); }
 
 // WF: 1 fp8 e4m3 weights, 2 int8 weights (fp16 activations; block scales), 3 int8 x int8 (per-token x per-channel scales)
-template <int WF>
-__global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2))) void w8_mtiled_kernel(const P8Params p) {
+// WMH: 128-row M halves per workgroup (2: the 256 x 256 tile on 8 waves, one workgroup per CU; 1: 128 x 256 on 4 waves, two per CU --
+// one's per-k-step barrier stall is covered by the other's MFMAs)
+template <int WF, int WMH>
+__global__ __launch_bounds__(WMH * 256) __attribute__((amdgpu_waves_per_eu(2, 2))) void w8_mtiled_kernel(const P8Params p) {
   constexpr bool I8A = WF == 3;
+  constexpr int P8_BM = WMH * 128;
   constexpr int BK = I8A ? 128 : 64;            // k per step
-  constexpr int XT = 256 * 128;                 // activation tile: 256 rows x 128 B
+  constexpr int XT = P8_BM * 128;               // activation tile: P8_BM rows x 128 B
   constexpr int WROW = I8A ? 128 : 64;          // bytes of a weight row per step
   constexpr int WT = 256 * WROW;
   constexpr int BUF = XT + WT;
@@ -74,18 +78,18 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
     if (row >= p.m) row = p.m - 1;  // rows >= M feed only unstored outputs
     xoff[j] = (uint32_t)(row * p.x_stride + p8_swz(r, ps) * 16);
   }
-  constexpr int WP = I8A ? 4 : 2;  // weight pieces (1 KB) per wave and step
+  constexpr int WP = (I8A ? 4 : 2) * (2 / WMH);  // weight pieces (1 KB) per wave and step (the 256-row weight tile over 4 or 8 waves)
   uint32_t woff[WP];
 #pragma unroll
   for (int j = 0; j < WP; ++j) {
     int r, src_slot;
     if constexpr (I8A) {
-      r = (wv * 4 + j) * 8 + (lane >> 3);
+      r = (wv * WP + j) * 8 + (lane >> 3);
       src_slot = p8_swz(r, lane & 7);
     } else {
       // LDS image: [128 row pairs][128 B]; physical slot ps of pair pr holds (row 2 pr + (ls >> 2), 16-byte piece ls & 3) with
       // ls = ps ^ ((pr >> 1) & 7): an 8-byte fragment read of 32 consecutive rows touches every bank pair at most twice
-      const int pr = (wv * 2 + j) * 8 + (lane >> 3), ls = p8_swz(pr, lane & 7);
+      const int pr = (wv * WP + j) * 8 + (lane >> 3), ls = p8_swz(pr, lane & 7);
       r = pr * 2 + (ls >> 2);
       src_slot = ls & 3;
     }
@@ -103,7 +107,7 @@ __global__ __launch_bounds__(P8_THREADS) __attribute__((amdgpu_waves_per_eu(2, 2
   };
 
   // ---- consumer geometry: wave (wm, wn) multiplies token rows wm * 128 .. + 127 by weight rows wn * 64 .. + 63 ----
-  const int wm = wv >> 2, wn = wv & 3;
+  const int wm = WMH == 2 ? wv >> 2 : 0, wn = wv & 3;
   const int nl = lane & 31, h = lane >> 5;
   int xrow_off[4], xsw[4];
 #pragma unroll
@@ -284,7 +288,7 @@ extern "C" int ll_w8_mtiled_supported(int64_t m, int64_t n, int64_t k, int wfmt,
   if (m <= 64 || n < 32 || n % 32 != 0 || k < bk || k % bk != 0) return 0;
   if (wfmt != 3 && group_k < k && group_k % bk != 0) return 0;
   if (n * k >= (1ll << 31) || m * k * (wfmt == 3 ? 1 : 2) >= (1ll << 32)) return 0;  // 32-bit offsets into the operands
-  const int64_t tiles = ((m + P8_BM - 1) / P8_BM + 15) / 16 * 16 * (((n + P8_BN - 1) / P8_BN + 15) / 16 * 16);
+  const int64_t tiles = ((m + 127) / 128 + 15) / 16 * 16 * (((n + P8_BN - 1) / P8_BN + 15) / 16 * 16);
   return tiles < (1ll << 31) ? 1 : 0;
 }
 
@@ -305,24 +309,37 @@ extern "C" int ll_w8_mtiled_try(void* out, const void* x, const void* w, const f
   p.bias = (const uint16_t*)bias; p.acc_out = acc_out;
   p.m = m; p.n = n; p.k = k; p.x_stride = x_stride * eb; p.w_stride = w_stride;
   p.s_stride_n = s_stride_n; p.s_stride_k = s_stride_k; p.group_k = group_k; p.group_n = group_n > 0 ? group_n : 1;
-  p.tiles_m = (int)((m + P8_BM - 1) / P8_BM);
+  static const int wmh_env = getenv("LL_P8_WMH") ? atoi(getenv("LL_P8_WMH")) : 0;  // A/B knob, read once (1 / 2: force the tile height)
+  // measured (benchmarks/prefill_gemm8.py, round 6): the 128-row tile (two workgroups per CU) wins where the widening VALU sits in front
+  // of the MFMAs (fp8 / int8 -> fp16: 487 -> 545, 393 -> 463 TFLOP/s) and loses on int8 x int8, whose MFMAs run twice as fast and leave
+  // the L2 -> LDS tile traffic as the bound (2.0 -> 1.6 POP/s): that form keeps the 256-row tile
+  const int wmh = wmh_env == 1 || wmh_env == 2 ? wmh_env : (wfmt == 3 ? 2 : P8_WMH_DEFAULT);
+  const int bm = wmh * 128;
+  p.tiles_m = (int)((m + bm - 1) / bm);
   p.tiles_n = (int)((n + P8_BN - 1) / P8_BN);
   const int64_t grid = (int64_t)((p.tiles_m + 15) / 16) * ((p.tiles_n + 15) / 16) * 256;
   hipStream_t st = (hipStream_t)stream;
   int dev = 0;
   (void)hipGetDevice(&dev);
-#define P8_GO(WF, BYTES)                                                                                              \
-  {                                                                                                                   \
-    static bool attr_[16] = {false};                                                                                  \
-    if (dev >= 0 && dev < 16 && !attr_[dev]) {                                                                        \
-      (void)hipFuncSetAttribute((const void*)w8_mtiled_kernel<WF>, hipFuncAttributeMaxDynamicSharedMemorySize, BYTES); \
-      attr_[dev] = true;                                                                                              \
-    }                                                                                                                 \
-    w8_mtiled_kernel<WF><<<dim3((unsigned)grid), P8_THREADS, BYTES, st>>>(p);                                          \
+#define P8_GO(WF, WH, WROWB)                                                                                              \
+  {                                                                                                                       \
+    const int bytes_ = 2 * (WH * 128 * 128 + 256 * WROWB);                                                                \
+    static bool attr_[16] = {false};                                                                                      \
+    if (dev >= 0 && dev < 16 && !attr_[dev]) {                                                                            \
+      (void)hipFuncSetAttribute((const void*)w8_mtiled_kernel<WF, WH>, hipFuncAttributeMaxDynamicSharedMemorySize, bytes_); \
+      attr_[dev] = true;                                                                                                  \
+    }                                                                                                                     \
+    w8_mtiled_kernel<WF, WH><<<dim3((unsigned)grid), WH * 256, bytes_, st>>>(p);                                          \
   }
-  if (wfmt == 1) P8_GO(1, 2 * (256 * 128 + 256 * 64))
-  else if (wfmt == 2) P8_GO(2, 2 * (256 * 128 + 256 * 64))
-  else P8_GO(3, 2 * (256 * 128 + 256 * 128))
+  if (wmh == 2) {
+    if (wfmt == 1) P8_GO(1, 2, 64)
+    else if (wfmt == 2) P8_GO(2, 2, 64)
+    else P8_GO(3, 2, 128)
+  } else {
+    if (wfmt == 1) P8_GO(1, 1, 64)
+    else if (wfmt == 2) P8_GO(2, 1, 64)
+    else P8_GO(3, 1, 128)
+  }
 #undef P8_GO
   return hipGetLastError() == hipSuccess ? 1 : LL_ERR_LAUNCH;
 }
