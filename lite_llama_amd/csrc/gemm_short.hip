@@ -23,7 +23,9 @@
 #include "gemm_w4_common.h"
 
 #define SS_CONSUMERS 8
-#define SS_LOADERS 4
+#ifndef SS_LOADERS
+#define SS_LOADERS 4  // (-DSS_LOADERS=8: A/B build, 16-wave workgroups)
+#endif
 #define SS_THREADS ((SS_CONSUMERS + SS_LOADERS) * 64)
 #define SS_MAX_CHUNKS 9      // activation chunks (128 k) of one k-slice resident in LDS
 #define SS_MAX_SLICES 8      // planes the consumers of a projection add up (flash_decoding.hip FD_QS_MAX)
