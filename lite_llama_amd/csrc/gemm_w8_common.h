@@ -21,14 +21,6 @@ __device__ __forceinline__ void d8_i8(uint32_t w, uint32_t s, uint32_t& o0, uint
 }
 // 4 fp8 e4m3 bytes -> 2 x (2 fp16) * (s * 256): the reference's bit surgery (w8a16.py:48-62)
 __device__ __forceinline__ void d8_fp8(uint32_t w, uint32_t s256, uint32_t& o0, uint32_t& o1) {
-#ifdef D8_HW_CVT  // A/B build: gfx950's packed fp8 -> fp16 conversion with the 2^-8 the bit surgery implies (NaN codes differ)
-  typedef _Float16 d8_h2 __attribute__((ext_vector_type(2)));
-  const d8_h2 a = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 0x1p-8f, false);
-  const d8_h2 b = __builtin_amdgcn_cvt_scalef32_pk_f16_fp8(w, 0x1p-8f, true);
-  o0 = d8_mul(__builtin_bit_cast(uint32_t, a), s256);
-  o1 = d8_mul(__builtin_bit_cast(uint32_t, b), s256);
-  return;
-#endif
   uint32_t p0 = __builtin_amdgcn_perm(0u, w, 0x010C000Cu);
   uint32_t p1 = __builtin_amdgcn_perm(0u, w, 0x030C020Cu);
   p0 = (p0 & 0x80008000u) | ((p0 >> 1) & 0x3F803F80u);
