@@ -325,16 +325,18 @@ def test_flash_decoding_one_launch_merge_equals_two_launch(monkeypatch):
     assert int(A._fd_counters[L_.scratch_keys(q.device)[0]].abs().sum()) == 0
 
 
-@pytest.mark.parametrize("ctx", [1025, 2049, 4096])
-def test_flash_decoding_beyond_eight_partitions_matches_oracle(ctx):
+@pytest.mark.parametrize("ctx,B", [(1025, 64), (2049, 64), (4096, 64), (8200, 32), (3000, 16)])
+def test_flash_decoding_beyond_eight_partitions_matches_oracle(ctx, B):
     """Round-3 review: every oracle comparison of flash_decoding by itself stopped at 300 tokens, and contexts past 1024
     (9 / 17 / 32 partitions: the reference's graph buckets reach 4096, executor/cuda_graph.py:27-28; the second bench point is
     prompt 2048) take the GLOBAL merge path -- partials written through, a counter, the last partition's wave merging -- that
     the one-workgroup LDS merge of <= 8 partitions never exercises.  Headline geometry (28 / 4 heads of 128, the model's fused
     [tokens, 2 Hkv, D] pool, scattered rows, int64 indices), batch 64 with ragged lengths up to ctx; tests/kernels/
     test_flash_decoding.py:102-122 is the reference's counterpart (tolerance 1e-2)."""
+    # (round 6: batch x KV heads >= 128 workgroups -- B = 64, 32 -- keep the one-workgroup form, whose 8 waves WALK the partitions, up
+    # to nine each at ctx 8200; B = 16 takes a workgroup per partition + the global merge)
     g = torch.Generator().manual_seed(ctx)
-    B, hq, hkv, d = 64, 28, 4, 128
+    hq, hkv, d = 28, 4, 128
     lens = torch.randint(ctx // 2, ctx + 1, (B,), generator=g).tolist()
     lens[0], lens[1], lens[2] = ctx, ctx - 1, 128 * ((ctx - 1) // 128) + 1   # full, one short, one token into the last partition
     tokens = sum(lens)
